@@ -1,0 +1,163 @@
+/*
+ * pangaea_feat.h -- C ABI of libpangaea_feat.so, the MI355X (gfx950) implementation of Pangaea's
+ * barcode-aware k-mer feature path.
+ *
+ * The reference has no in-process FFI on this path: src/feature.py shells out to two binaries
+ * (count_tnf, count_kmer) and to jellyfish, and reads their CSV files back.  This header is the
+ * boundary a maintainer binds instead (ctypes stub in INTEGRATION.md).  Every entry point names the
+ * reference interface it replaces.  Conventions:
+ *   - plain pointers and sizes only; no C++ or torch types;
+ *   - every function returns PG_OK (0) or a negative pg_status; pg_last_error() gives the message of the
+ *     last failure on the calling thread; nothing here calls exit();
+ *   - "device" pointers are HIP device pointers owned by the caller (e.g. torch tensors' data_ptr());
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).  Device functions only enqueue
+ *     work on `stream`; they never allocate, free or synchronise;
+ *   - host handles (pg_reads) are owned by the library until the matching free.
+ *
+ * Read-stream layout (host and device): the text the reference accumulates per barcode run --
+ * read1 + 'N' + read2 + 'N' per pair (count_tnf.cpp:248,251) -- is kept for the WHOLE file as one
+ * character stream in file order.  Character j lives in
+ *     codes[j / 32] bits [2*(j%32), 2*(j%32)+2)   A=0 C=1 T=2 G=3   (count_tnf.cpp:99: (c>>1)&3)
+ *     valid[j / 32] bit  (j % 32)                  1 iff the character is one of 'A','C','G','T'
+ * Separators, N, lower-case and IUPAC characters have valid=0 (and code 0).  Arrays are padded with
+ * invalid characters to a whole number of PG_WORD_ALIGN words.  A barcode run is a contiguous
+ * character range of the stream, so rows never need per-read offsets.
+ */
+#ifndef PANGAEA_FEAT_H
+#define PANGAEA_FEAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+#define PG_CHARS_PER_WORD 32
+#define PG_WORD_ALIGN 256 /* stream arrays are padded to a multiple of this many words */
+
+typedef enum {
+    PG_OK = 0,
+    PG_EINVAL = -1,      /* bad argument (unsupported k, null pointer, ...) */
+    PG_EIO = -2,         /* cannot open / read / write a file */
+    PG_EFORMAT = -3,     /* input the reference itself would abort on (header ending in a bare "BX:Z") */
+    PG_ENOMEM = -4,
+    PG_EHIP = -5,        /* a HIP runtime call or kernel launch failed */
+    PG_ETABLEFULL = -6,  /* hash table too small: enlarge log2_slots and count again */
+    PG_ENODEVICE = -7    /* no gfx950 device / code object not loadable */
+} pg_status;
+
+int pg_abi_version(void);
+const char *pg_last_error(void);
+/* number of visible HIP devices, or a negative pg_status */
+int pg_device_count(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Host ingest: FASTQ -> read stream + barcode runs.
+ * Replaces the single-threaded producer loops of count_tnf.cpp:174-289 and count_kmer.cpp:186-281
+ * together with getBarcode (count_tnf.cpp:23-52).  r2 == NULL selects the interleaved form (-i),
+ * otherwise r1/r2 are the -1/-2 files.  gzip or plain, as gzstream's gzopen.
+ * Runs are assembled exactly as the reference does (the pair is appended before the barcode
+ * comparison), so run i = [run_off[i], run_off[i+1]) in characters.  Reads that jellyfish counts but
+ * that belong to no run (paired mode, name/barcode mismatch, count_tnf.cpp:183) are placed after the
+ * last run, in [run_off[n_runs], n_chars).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pg_reads pg_reads;
+
+int pg_ingest_fastq(const char *r1_or_interleaved, const char *r2_or_null, pg_reads **out);
+void pg_reads_free(pg_reads *r);
+int64_t pg_reads_n_chars(const pg_reads *r);
+int64_t pg_reads_n_words(const pg_reads *r); /* padded word count of codes[] and valid[] */
+int64_t pg_reads_n_pairs(const pg_reads *r);
+int64_t pg_reads_n_unpaired(const pg_reads *r);
+int64_t pg_reads_n_runs(const pg_reads *r);
+const uint64_t *pg_reads_codes(const pg_reads *r);
+const uint32_t *pg_reads_valid(const pg_reads *r);
+const int64_t *pg_reads_run_off(const pg_reads *r); /* [n_runs + 1] */
+const char *pg_reads_run_name(const pg_reads *r, int64_t i);
+/* "" (undecided), "10x" or "stLFR": the header mode the file latched (count_tnf.cpp:27-32) */
+const char *pg_reads_mode(const pg_reads *r);
+/* Surviving rows: runs with a non-empty barcode and more than min_len characters
+ * (count_tnf.cpp:81 == count_kmer.cpp:62).  row_run may be NULL to obtain only the count. */
+int64_t pg_reads_rows(const pg_reads *r, int min_len, int64_t *row_run);
+
+/* ASCII run text -> stream words (the packing used by pg_ingest_fastq, exposed for callers that
+ * already hold reads in memory).  codes/valid must hold pg_words_for(n) words. */
+int64_t pg_words_for(int64_t n_chars);
+int pg_pack_ascii(const char *text, int64_t n_chars, uint64_t *codes, uint32_t *valid);
+
+/* Split rows into work segments of at most seg_chars characters (a multiple of 32).  Call with
+ * seg_row == NULL to obtain the number of segments.  Host arrays. */
+int64_t pg_plan_segments(const int64_t *row_start, const int64_t *row_end, int64_t n_rows, int64_t seg_chars,
+                         int32_t *seg_row, int64_t *seg_start, int64_t *seg_end);
+
+/* ----------------------------------------------------------------------------------------------
+ * TNF columns.  Column c of a TNF row counts the canonical k-mer with the c-th smallest code
+ * (std::map iteration order, count_tnf.cpp:108-109).  colmap[code] (4^k entries) gives the column of
+ * min(code, revcomp(code)).
+ * ---------------------------------------------------------------------------------------------- */
+#define PG_TNF_MAX_K 6
+int pg_tnf_ncols(int k);
+int pg_tnf_colmap(int k, uint16_t *colmap /* [4^k] host */, uint32_t *col_code /* [ncols] host, may be NULL */);
+
+/* ----------------------------------------------------------------------------------------------
+ * Global canonical k-mer multiplicities over every read (device).
+ * Replaces `jellyfish count -C -m k` + `jellyfish dump` (src/feature.py:94,103) and the dump reload
+ * of count_kmer.cpp:139-170.  Two table forms:
+ *   PG_TABLE_DENSE  k <= 16: uint32_t counts[4^k], indexed by the canonical code.
+ *   PG_TABLE_HASH   k <= 21: uint64_t slots[2^log2_slots], open addressing, linear probing;
+ *                   slot = (canonical code << 22) | count, 0 = empty.  The count field stops
+ *                   growing at PG_HASH_COUNT_SAT (2^21), far above any vector_size*window, so every
+ *                   histogram bin is exact.
+ * Tables must be zero-filled by the caller before the first count; counting accumulates, so a stream
+ * may be counted in pieces (and tables of several GPUs can be summed).
+ * ---------------------------------------------------------------------------------------------- */
+enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2 };
+#define PG_DENSE_MAX_K 16
+#define PG_HASH_MAX_K 21
+#define PG_HASH_COUNT_BITS 22
+#define PG_HASH_COUNT_SAT (1u << 21)
+
+typedef struct {
+    int32_t kind;       /* PG_TABLE_DENSE or PG_TABLE_HASH */
+    int32_t k;
+    int32_t log2_slots; /* hash only */
+    int32_t reserved;
+    void *data;         /* device: uint32_t[4^k] or uint64_t[2^log2_slots] */
+} pg_table;
+
+/* Count the k-mers ending in words [word_begin, word_end) of the stream into `t`.
+ * status (device uint32_t[2], zeroed by the caller): [0] is set non-zero when the hash table is full
+ * (check after synchronising: PG_ETABLEFULL condition), [1] unused.  May be NULL for dense tables. */
+int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                  const pg_table *t, uint32_t *status, void *stream);
+
+/* Add n (code,count) pairs -- `pairs[i] = (code << 22) | count`, the slot format -- into a hash table:
+ * the merge step after tables of other GPUs have been gathered. */
+int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t, uint32_t *status, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Per-run feature rows (device).  One launch fills both matrices.
+ *   tnf_out [n_rows, ncols(k_tnf)] int32: canonical k_tnf-mer counts        (count_tnf.cpp:78-113)
+ *   abd_out [n_rows, vsize]        int32: hist[count(kmer)/window]++ where the bin is < vsize
+ *                                          (count_kmer.cpp:55-108)
+ * Either output may be NULL (then its parameters are ignored).  Both must be zero-filled by the
+ * caller; segments of one row add into the same row.  seg_* are the device copies of
+ * pg_plan_segments' arrays; colmap is the device copy of pg_tnf_colmap's table.
+ * ---------------------------------------------------------------------------------------------- */
+int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,
+                const int32_t *seg_row, const int64_t *seg_start, const int64_t *seg_end, int64_t n_segs,
+                int k_tnf, const uint16_t *colmap, int32_t *tnf_out,
+                const pg_table *t, int window, int vsize, int32_t *abd_out, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Cache files.  Rows as the reference binaries print them: "<name>,v1,...,vD\n", numbers through
+ * ostream<<double (%g, six significant digits; count_tnf.cpp:293-303), gzip container.
+ * names: n_rows NUL-terminated strings back to back.  mat: host int32 [n_rows, n_cols].
+ * ---------------------------------------------------------------------------------------------- */
+int pg_write_csv_gz(const char *path, const char *names, const int32_t *mat, int64_t n_rows, int64_t n_cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANGAEA_FEAT_H */

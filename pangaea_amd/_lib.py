@@ -1,0 +1,100 @@
+"""ctypes binding of libpangaea_feat.so (include/pangaea_feat.h).
+
+The HIP library is the product path: there is no CPU fallback.  ``load()`` raises when the shared
+object is missing (build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C pangaea_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpangaea_feat.so")
+_LIB = None
+
+PG_OK = 0
+PG_ETABLEFULL = -6
+TABLE_DENSE, TABLE_HASH = 1, 2
+DENSE_MAX_K, HASH_MAX_K = 16, 21
+HASH_COUNT_BITS = 22
+HASH_COUNT_SAT = 1 << 21
+TNF_MAX_K = 6
+WORD_ALIGN = 256
+
+
+class PangaeaError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpangaea_feat: {msg} (status {code})")
+        self.code = code
+
+
+class pg_table(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("log2_slots", C.c_int32), ("reserved", C.c_int32),
+                ("data", C.c_void_p)]
+
+
+def build() -> None:
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)
+
+
+def load() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built (make -C pangaea_amd/csrc). "
+            "There is no CPU fallback for the feature path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, cp = C.c_void_p, C.c_int64, C.c_int, C.c_char_p
+    tp = C.POINTER(pg_table)
+    sig = {
+        "pg_abi_version": (i32, []),
+        "pg_last_error": (cp, []),
+        "pg_device_count": (i32, []),
+        "pg_ingest_fastq": (i32, [cp, cp, C.POINTER(vp)]),
+        "pg_reads_free": (None, [vp]),
+        "pg_reads_n_chars": (i64, [vp]),
+        "pg_reads_n_words": (i64, [vp]),
+        "pg_reads_n_pairs": (i64, [vp]),
+        "pg_reads_n_unpaired": (i64, [vp]),
+        "pg_reads_n_runs": (i64, [vp]),
+        "pg_reads_codes": (vp, [vp]),
+        "pg_reads_valid": (vp, [vp]),
+        "pg_reads_run_off": (vp, [vp]),
+        "pg_reads_run_name": (cp, [vp, i64]),
+        "pg_reads_mode": (cp, [vp]),
+        "pg_reads_rows": (i64, [vp, i32, vp]),
+        "pg_words_for": (i64, [i64]),
+        "pg_pack_ascii": (i32, [cp, i64, vp, vp]),
+        "pg_plan_segments": (i64, [vp, vp, i64, i64, vp, vp, vp]),
+        "pg_tnf_ncols": (i32, [i32]),
+        "pg_tnf_colmap": (i32, [i32, vp, vp]),
+        "pg_kmer_count": (i32, [vp, vp, i64, i64, tp, vp, vp]),
+        "pg_kmer_merge": (i32, [vp, i64, tp, vp, vp]),
+        "pg_features": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp, vp, tp, i32, i32, vp, vp]),
+        "pg_write_csv_gz": (i32, [cp, cp, vp, i64, i64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)           # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    if L.pg_abi_version() != 1:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {L.pg_abi_version()} != 1")
+    _LIB = L
+    return L
+
+
+EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_reads_free", "pg_reads_n_chars",
+           "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
+           "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
+           "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_merge",
+           "pg_features", "pg_write_csv_gz"]
+
+
+def check(rc: int) -> int:
+    """raise on a negative status; pass through counts"""
+    if rc < 0:
+        raise PangaeaError(rc, load().pg_last_error().decode(errors="replace"))
+    return rc

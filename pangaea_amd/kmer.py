@@ -1,0 +1,244 @@
+"""Device tables of global canonical k-mer multiplicities and the per-run feature rows.
+
+Mirrors, in one process and on the GPU, what ``src/feature.py`` obtains from three subprocesses:
+``jellyfish count/dump`` (feature.py:94,103) -> :class:`KmerTable`; ``count_tnf`` (feature.py:133) and
+``count_kmer`` (feature.py:109) -> :func:`features`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .reads import ReadStream, Rows
+
+DEFAULT_SEG_CHARS = 16384
+
+
+def _stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on a GPU: the k-mer kernels have no CPU path "
+                           f"(got a tensor on {t.device})")
+
+
+class KmerTable:
+    """exact multiplicity of every canonical k-mer over every read of the input.
+
+    ``dense``: int32 tensor of 4^k counters (k <= 16).  ``hash``: int64 tensor of 2^log2_slots slots,
+    slot = (code << 22) | count, 0 = empty (k <= 21).
+    """
+
+    def __init__(self, k: int, kind: str, data: torch.Tensor, log2_slots: int = 0):
+        self.k, self.kind, self.data, self.log2_slots = int(k), kind, data, int(log2_slots)
+        self.status = torch.zeros(2, dtype=torch.int32, device=data.device)
+        self._desc = _lib.pg_table(_lib.TABLE_DENSE if kind == "dense" else _lib.TABLE_HASH, self.k, self.log2_slots, 0,
+                                   data.data_ptr())
+
+    # ------------------------------------------------------------------ construction
+
+    @staticmethod
+    def default_kind(k: int) -> str:
+        if k < 1 or k > _lib.HASH_MAX_K:
+            raise ValueError(f"k-mer size {k} unsupported on the GPU path (1..{_lib.HASH_MAX_K})")
+        return "dense" if k <= 15 else "hash"
+
+    @classmethod
+    def alloc(cls, k: int, device, kind: str | None = None, distinct_hint: int | None = None,
+              load: float = 0.5) -> "KmerTable":
+        kind = kind or cls.default_kind(k)
+        device = torch.device(device)
+        if kind == "dense":
+            if k > _lib.DENSE_MAX_K:
+                raise ValueError(f"dense tables need k <= {_lib.DENSE_MAX_K}")
+            return cls(k, "dense", torch.zeros(4 ** k, dtype=torch.int32, device=device))
+        if kind != "hash":
+            raise ValueError(f"unknown table kind {kind!r}")
+        if k > _lib.HASH_MAX_K:
+            raise ValueError(f"hash tables need k <= {_lib.HASH_MAX_K}")
+        want = max(1024, int((distinct_hint or 1 << 20) / load))
+        log2 = max(10, math.ceil(math.log2(want)))
+        return cls(k, "hash", torch.zeros(1 << log2, dtype=torch.int64, device=device), log2)
+
+    @classmethod
+    def from_items(cls, k: int, codes, counts, device, kind: str | None = None) -> "KmerTable":
+        """table holding exactly the given (canonical code, count) entries -- e.g. a parsed jellyfish dump
+        (count_kmer.cpp:139-170 assigns, it does not add: later duplicates must already be resolved)"""
+        codes = torch.as_tensor(np.asarray(codes).astype(np.int64))
+        counts = torch.as_tensor(np.asarray(counts).astype(np.int64))
+        table = cls.alloc(k, device, kind, distinct_hint=max(1024, codes.numel()))
+        if table.kind == "dense":
+            table.data[codes.to(table.device)] = counts.to(table.device, torch.int32)
+        else:
+            sat = torch.clamp(counts, max=_lib.HASH_COUNT_SAT)
+            table.merge(((codes << _lib.HASH_COUNT_BITS) | sat)[sat > 0])
+        return table
+
+    @property
+    def device(self) -> torch.device:
+        return self.data.device
+
+    @property
+    def nbytes(self) -> int:
+        return self.data.numel() * self.data.element_size()
+
+    def desc(self):
+        return C.byref(self._desc)
+
+    # ------------------------------------------------------------------ counting
+
+    def count(self, stream: ReadStream, word_begin: int = 0, word_end: int | None = None, check: bool = True) -> "KmerTable":
+        """add the k-mers ending in words [word_begin, word_end) of the stream (asynchronous unless ``check``)"""
+        _require_gpu(stream.codes, "the read stream")
+        if stream.device != self.device:
+            raise ValueError("stream and table are on different devices")
+        word_end = stream.n_words if word_end is None else word_end
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_kmer_count(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end,
+                                                 self.desc(), self.status.data_ptr(), _stream_ptr(self.device)))
+        if check:
+            self.check_status()
+        return self
+
+    def check_status(self) -> None:
+        if self.kind == "hash" and int(self.status[0].item()) != 0:
+            raise _lib.PangaeaError(_lib.PG_ETABLEFULL, f"hash table with 2^{self.log2_slots} slots is full")
+
+    def merge(self, pairs: torch.Tensor, check: bool = True) -> "KmerTable":
+        """add (code << 22 | count) pairs, e.g. the compacted table of another GPU"""
+        if self.kind != "hash":
+            raise ValueError("merge() is for hash tables; dense tables are summed with all_reduce")
+        pairs = pairs.to(self.device, torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_kmer_merge(pairs.data_ptr(), pairs.numel(), self.desc(), self.status.data_ptr(),
+                                                 _stream_ptr(self.device)))
+        if check:
+            self.check_status()
+        return self
+
+    def compact(self) -> torch.Tensor:
+        """occupied slots of a hash table as an int64 vector (slot format)"""
+        if self.kind != "hash":
+            raise ValueError("compact() is for hash tables")
+        return self.data[self.data != 0]
+
+    def occupancy(self) -> float:
+        if self.kind != "hash":
+            return float("nan")
+        return float(torch.count_nonzero(self.data).item()) / self.data.numel()
+
+    def items(self):
+        """(codes uint64, counts uint64) sorted by code -- host copies, for tests"""
+        if self.kind == "dense":
+            t = self.data.cpu().numpy().view(np.uint32)
+            codes = np.nonzero(t)[0].astype(np.uint64)
+            return codes, t[codes.astype(np.int64)].astype(np.uint64)
+        s = self.compact().cpu().numpy().view(np.uint64)
+        codes, counts = s >> np.uint64(_lib.HASH_COUNT_BITS), s & np.uint64((1 << _lib.HASH_COUNT_BITS) - 1)
+        order = np.argsort(codes)
+        return codes[order], counts[order]
+
+
+def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hint: int | None = None,
+                max_log2_slots: int = 36) -> KmerTable:
+    """build the table of one stream; a full hash table is re-built with four times the slots"""
+    table = KmerTable.alloc(k, stream.device, kind, distinct_hint if distinct_hint else max(1 << 16, stream.n_chars // 8))
+    while True:
+        try:
+            return table.count(stream)
+        except _lib.PangaeaError as e:
+            if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
+                raise
+            log2 = min(max_log2_slots, table.log2_slots + 2)
+            del table
+            table = KmerTable(k, "hash", torch.zeros(1 << log2, dtype=torch.int64, device=stream.device), log2)
+
+
+# ---------------------------------------------------------------------------------------- TNF columns
+
+_COLMAP_CACHE: dict = {}
+
+
+def tnf_ncols(k: int) -> int:
+    return _lib.check(_lib.load().pg_tnf_ncols(k))
+
+
+def tnf_colmap(k: int, device=None):
+    """(colmap int16-as-uint16 tensor [4^k], column codes uint32 [ncols])"""
+    key = (k, str(device))
+    if key not in _COLMAP_CACHE:
+        n = tnf_ncols(k)
+        colmap = np.zeros(4 ** k, dtype=np.uint16)
+        codes = np.zeros(n, dtype=np.uint32)
+        _lib.check(_lib.load().pg_tnf_colmap(k, colmap.ctypes.data, codes.ctypes.data))
+        t = torch.from_numpy(colmap.view(np.int16))
+        _COLMAP_CACHE[key] = (t.to(device) if device is not None else t, codes)
+    return _COLMAP_CACHE[key]
+
+
+# ---------------------------------------------------------------------------------------- rows
+
+
+def plan_segments(rows: Rows, seg_chars: int = DEFAULT_SEG_CHARS):
+    L = _lib.load()
+    start = np.ascontiguousarray(rows.start, dtype=np.int64)
+    end = np.ascontiguousarray(rows.end, dtype=np.int64)
+    n = _lib.check(L.pg_plan_segments(start.ctypes.data, end.ctypes.data, len(start), seg_chars, None, None, None))
+    seg_row = np.zeros(n, dtype=np.int32)
+    seg_start = np.zeros(n, dtype=np.int64)
+    seg_end = np.zeros(n, dtype=np.int64)
+    _lib.check(L.pg_plan_segments(start.ctypes.data, end.ctypes.data, len(start), seg_chars, seg_row.ctypes.data,
+                                  seg_start.ctypes.data, seg_end.ctypes.data))
+    return seg_row, seg_start, seg_end
+
+
+class Plan:
+    """device copy of the work segments of a row set (re-usable across launches)"""
+
+    def __init__(self, rows: Rows, device, seg_chars: int = DEFAULT_SEG_CHARS):
+        r, s, e = plan_segments(rows, seg_chars)
+        self.n_rows, self.n_segs = len(rows), len(r)
+        self.seg_row = torch.from_numpy(r).to(device)
+        self.seg_start = torch.from_numpy(s).to(device)
+        self.seg_end = torch.from_numpy(e).to(device)
+
+
+def features(stream: ReadStream, rows: Rows | Plan, k_tnf: int | None = 4, table: KmerTable | None = None,
+             window: int = 10, vsize: int = 400, seg_chars: int = DEFAULT_SEG_CHARS,
+             out_tnf: torch.Tensor | None = None, out_abd: torch.Tensor | None = None):
+    """(tnf int32 [N, D] or None, abd int32 [N, V] or None) on the stream's device.
+
+    tnf[r, c]  = occurrences of the c-th canonical k_tnf-mer in run r            (count_tnf.cpp:78-113)
+    abd[r, b]  = k-mer occurrences of run r whose global multiplicity // window == b < vsize
+                                                                                 (count_kmer.cpp:55-108)
+    """
+    _require_gpu(stream.codes, "the read stream")
+    dev = stream.device
+    plan = rows if isinstance(rows, Plan) else Plan(rows, dev, seg_chars)
+    n = plan.n_rows
+    tnf = abd = None
+    colmap_ptr = None
+    if k_tnf:
+        colmap, _ = tnf_colmap(k_tnf, dev)
+        colmap_ptr = colmap.data_ptr()
+        tnf = out_tnf.zero_() if out_tnf is not None else torch.zeros((n, tnf_ncols(k_tnf)), dtype=torch.int32, device=dev)
+    if table is not None:
+        if table.device != dev:
+            raise ValueError("stream and table are on different devices")
+        abd = out_abd.zero_() if out_abd is not None else torch.zeros((n, vsize), dtype=torch.int32, device=dev)
+    if tnf is None and abd is None:
+        raise ValueError("nothing to compute: give k_tnf and/or a table")
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().pg_features(
+            stream.codes.data_ptr(), stream.valid.data_ptr(), stream.n_words,
+            plan.seg_row.data_ptr(), plan.seg_start.data_ptr(), plan.seg_end.data_ptr(), plan.n_segs,
+            k_tnf or 0, colmap_ptr, tnf.data_ptr() if tnf is not None else None,
+            table.desc() if table is not None else None, window, vsize,
+            abd.data_ptr() if abd is not None else None, _stream_ptr(dev)))
+    return tnf, abd

@@ -1,0 +1,115 @@
+"""The packed read stream and its barcode runs (layout: include/pangaea_feat.h).
+
+``ReadStream`` is what the reference's two producer loops hand to their worker threads
+(count_tnf.cpp:238-289, count_kmer.cpp:239-281), kept for the whole file at once: 2-bit codes + 1-bit
+validity for every character of ``read1 N read2 N ...`` in file order, plus the character offsets of the runs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def words_for(n_chars: int) -> int:
+    return int(_lib.check(_lib.load().pg_words_for(int(n_chars))))
+
+
+@dataclass
+class Rows:
+    """surviving runs: non-empty barcode and more than ``min_len`` characters (count_tnf.cpp:81)"""
+    run_index: np.ndarray          # int64 [N]
+    names: list                    # barcode of each row
+    start: np.ndarray              # int64 [N] character range in the stream
+    end: np.ndarray
+
+    def __len__(self) -> int:
+        return len(self.names)
+
+
+@dataclass
+class ReadStream:
+    codes: torch.Tensor            # int64 [n_words]: 32 characters per word, 2 bits each (A0 C1 T2 G3)
+    valid: torch.Tensor            # int32 [n_words]: bit j set iff character j is one of ACGT
+    n_chars: int
+    run_off: np.ndarray            # int64 [n_runs + 1]
+    run_names: list
+    n_pairs: int = 0
+    n_unpaired: int = 0
+    mode: str = ""
+    _dev: dict = field(default_factory=dict, repr=False)
+
+    @property
+    def n_words(self) -> int:
+        return int(self.codes.numel())
+
+    @property
+    def device(self) -> torch.device:
+        return self.codes.device
+
+    # ------------------------------------------------------------------ constructors
+
+    @classmethod
+    def from_fastq(cls, reads1: str, reads2: str | None = None, device: str | torch.device = "cpu") -> "ReadStream":
+        """ingest an interleaved FASTQ (``reads2`` None) or an R1/R2 pair; gzip or plain"""
+        L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(L.pg_ingest_fastq(str(reads1).encode(), str(reads2).encode() if reads2 else None, C.byref(h)))
+        try:
+            nw, nr = L.pg_reads_n_words(h), L.pg_reads_n_runs(h)
+            codes = np.ctypeslib.as_array(C.cast(L.pg_reads_codes(h), C.POINTER(C.c_int64)), shape=(nw,)).copy()
+            valid = np.ctypeslib.as_array(C.cast(L.pg_reads_valid(h), C.POINTER(C.c_int32)), shape=(nw,)).copy()
+            run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
+            names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
+            out = cls(torch.from_numpy(codes), torch.from_numpy(valid), int(L.pg_reads_n_chars(h)), run_off, names,
+                      int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode())
+        finally:
+            L.pg_reads_free(h)
+        return out.to(device)
+
+    @classmethod
+    def from_runs(cls, runs, device: str | torch.device = "cpu") -> "ReadStream":
+        """``runs`` = [(barcode, text)] with text already in run form (reads each followed by a non-base)"""
+        L = _lib.load()
+        text = b"".join(t if isinstance(t, bytes) else t.encode() for _, t in runs)
+        off = np.zeros(len(runs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(t) for _, t in runs])
+        nw = words_for(len(text))
+        codes = np.zeros(nw, dtype=np.int64)
+        valid = np.zeros(nw, dtype=np.int32)
+        _lib.check(L.pg_pack_ascii(text, len(text), codes.ctypes.data, valid.ctypes.data))
+        return cls(torch.from_numpy(codes), torch.from_numpy(valid), len(text), off, [n for n, _ in runs]).to(device)
+
+    def to(self, device) -> "ReadStream":
+        device = torch.device(device)
+        if device == self.codes.device:
+            return self
+        return ReadStream(self.codes.to(device), self.valid.to(device), self.n_chars, self.run_off, self.run_names,
+                          self.n_pairs, self.n_unpaired, self.mode)
+
+    # ------------------------------------------------------------------ rows
+
+    def rows(self, min_len: int) -> Rows:
+        lens = np.diff(self.run_off)
+        keep = np.array([bool(n) for n in self.run_names], dtype=bool) & (lens > int(min_len))
+        idx = np.nonzero(keep)[0].astype(np.int64)
+        return Rows(idx, [self.run_names[i] for i in idx], self.run_off[idx].copy(), self.run_off[idx + 1].copy())
+
+    # ------------------------------------------------------------------ host decode (tests / FASTQ export)
+
+    def decode(self, start: int = 0, end: int | None = None) -> bytes:
+        """characters [start, end) as text: bases for valid positions, 'N' for everything else"""
+        end = self.n_chars if end is None else end
+        w0, w1 = start // 32, (end + 31) // 32
+        c = self.codes[w0:w1].cpu().numpy().view(np.uint64)
+        v = self.valid[w0:w1].cpu().numpy().view(np.uint32)
+        sh = np.arange(32, dtype=np.uint64)
+        code = ((c[:, None] >> (2 * sh)[None, :]) & np.uint64(3)).astype(np.uint8).ravel()
+        ok = ((v[:, None] >> sh.astype(np.uint32)[None, :]) & np.uint32(1)).astype(bool).ravel()
+        txt = np.frombuffer(b"ACTG", dtype=np.uint8)[code]
+        txt = np.where(ok, txt, np.uint8(ord("N")))
+        return txt[start - 32 * w0:end - 32 * w0].tobytes()

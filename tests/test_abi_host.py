@@ -1,0 +1,158 @@
+"""CPU-only checks of the C-ABI library: it loads, exports what include/pangaea_feat.h declares, and its host
+half (ingest, packing, planning, TNF columns, CSV writer) agrees with the oracle.  No kernel is launched here."""
+import ctypes as C
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from pangaea_amd import _lib, kmer
+from pangaea_amd.reads import ReadStream, words_for
+
+from .conftest import GOLDEN, ROOT
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    _MAN = json.load(_f)
+_INPUTS = {json.dumps(c["input"], sort_keys=True): c["input"] for c in _MAN["cases"]}
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pangaea_feat.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, f"declared in pangaea_feat.h but not exported: {missing}"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.load().pg_abi_version() == 1
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "pangaea_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")) or fn == "Makefile":
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def _np_pack(text: bytes):
+    n = len(text)
+    nw = words_for(n)
+    a = np.frombuffer(text, dtype=np.uint8)
+    ok = np.isin(a, np.frombuffer(b"ACGT", dtype=np.uint8))
+    code = np.where(ok, (a >> 1) & 3, 0).astype(np.uint64)
+    pad = nw * 32 - n
+    code = np.concatenate([code, np.zeros(pad, np.uint64)]).reshape(nw, 32)
+    okp = np.concatenate([ok, np.zeros(pad, bool)]).reshape(nw, 32).astype(np.uint64)
+    sh = np.arange(32, dtype=np.uint64)
+    return (code << (2 * sh)).sum(axis=1).astype(np.uint64), (okp << sh).sum(axis=1).astype(np.uint32)
+
+
+def test_pack_ascii_layout():
+    rng = np.random.RandomState(1)
+    for n in (0, 1, 31, 32, 33, 1000, 8191, 8192, 8193):
+        text = bytes(rng.choice(list(b"ACGTNacgtRY\r"), size=n).astype(np.uint8))
+        s = ReadStream.from_runs([("x", text)])
+        cw, vw = _np_pack(text)
+        assert s.n_words % _lib.WORD_ALIGN == 0 and s.n_words >= 1
+        assert np.array_equal(s.codes.numpy().view(np.uint64), cw)
+        assert np.array_equal(s.valid.numpy().view(np.uint32), vw)
+        want = bytes(c if c in b"ACGT" else ord("N") for c in text)
+        assert s.decode() == want
+
+
+@pytest.mark.parametrize("spec", list(_INPUTS.values()), ids=lambda s: s.get("i") or s["1"])
+def test_ingest_matches_oracle_runs(spec):
+    r1 = os.path.join(GOLDEN, spec.get("i") or spec["1"])
+    r2 = os.path.join(GOLDEN, spec["2"]) if "2" in spec else None
+    rd = oracle.Reads(r1, r2)
+    s = ReadStream.from_fastq(r1, r2)
+    assert s.run_names == rd.names
+    assert np.array_equal(s.run_off, rd.seq_off)
+    assert (s.n_pairs, s.n_unpaired, s.mode) == (rd.n_pairs, rd.n_unpaired, rd.mode)
+    norm = lambda b: bytes(c if c in b"ACGT" else ord("N") for c in b)
+    for i in range(rd.n_runs):
+        assert s.decode(int(s.run_off[i]), int(s.run_off[i + 1])) == norm(rd.seq(i))
+    # every read of the input is in the stream exactly once (what the global counter sees)
+    k = 9
+    a = oracle.Table(k).count(rd.all_seq())
+    b = oracle.Table(k).count(s.decode())
+    assert all(np.array_equal(x, y) for x, y in zip(a.items(), b.items()))
+    for mlen in (0, 100, 168, 2000):
+        assert list(s.rows(mlen).run_index) == rd.surviving(mlen)
+
+
+def test_ingest_errors_are_reported_not_fatal(tmp_path):
+    L = _lib.load()
+    h = C.c_void_p()
+    assert L.pg_ingest_fastq(b"/nonexistent/file.fq", None, C.byref(h)) == -2
+    assert b"cannot open" in L.pg_last_error()
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@r1 BX:Z\nACGT\n+\nIIII\n@r1 BX:Z\nACGT\n+\nIIII\n")
+    assert L.pg_ingest_fastq(str(bad).encode(), None, C.byref(h)) == -3
+    with pytest.raises(_lib.PangaeaError):
+        ReadStream.from_fastq(str(bad))
+    with pytest.raises(RuntimeError):           # oracle refuses the same input
+        oracle.Reads(str(bad))
+
+
+def test_plan_segments_partitions_rows():
+    rng = np.random.RandomState(3)
+    start = np.cumsum(rng.randint(1, 5000, size=50)).astype(np.int64)
+    end = start + rng.randint(0, 4000, size=50)
+    from pangaea_amd.reads import Rows
+    rows = Rows(np.arange(50), [str(i) for i in range(50)], start, end)
+    for seg in (32, 64, 1024):
+        r, s, e = kmer.plan_segments(rows, seg)
+        assert ((e - s) > 0).all() and ((e - s) <= seg).all()
+        for i in range(50):
+            m = r == i
+            if end[i] == start[i]:
+                assert not m.any()
+                continue
+            assert s[m][0] == start[i] and e[m][-1] == end[i] and np.array_equal(s[m][1:], e[m][:-1])
+    L = _lib.load()
+    assert L.pg_plan_segments(start.ctypes.data, end.ctypes.data, 50, 48, None, None, None) == -1
+
+
+def test_tnf_columns_follow_reference_order():
+    for k in range(1, _lib.TNF_MAX_K + 1):
+        colmap, codes = kmer.tnf_colmap(k)
+        assert np.array_equal(codes, oracle.tnf_columns(k))
+        cm = colmap.numpy().view(np.uint16)
+        for c in range(4 ** k):
+            canon = min(c, oracle.revcomp(c, k))
+            assert codes[cm[c]] == canon
+    assert kmer.tnf_ncols(4) == 136
+    with pytest.raises(_lib.PangaeaError):
+        kmer.tnf_ncols(7)
+
+
+def test_csv_writer_prints_like_the_reference(tmp_path):
+    # golden rows of the poly-A input hold a count above 999999 (exponent form) -- rebuild them from integers
+    with open(os.path.join(GOLDEN, "polya.tnf.k4.l1000.csv")) as f:
+        golden = f.read()
+    rd = oracle.Reads(os.path.join(GOLDEN, "polya.fq.gz"))
+    names, tnf, _ = rd.features(1000, k_tnf=4)
+    mat = np.ascontiguousarray(tnf, dtype=np.int32)
+    blob = b"".join(n.encode() + b"\0" for n in names)
+    out = str(tmp_path / "t.gz")
+    _lib.check(_lib.load().pg_write_csv_gz(out.encode(), blob, mat.ctypes.data, mat.shape[0], mat.shape[1]))
+    with gzip.open(out, "rt") as f:
+        assert f.read() == golden
+    assert "1.23981e+06" in golden
+
+
+def test_kernels_refuse_cpu_tensors():
+    s = ReadStream.from_runs([("x", b"ACGTACGTACGTN")])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        kmer.features(s, s.rows(0), k_tnf=4)
+    with pytest.raises(ValueError):
+        kmer.KmerTable.default_kind(22)

@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the reference's golden outputs.
+
+Bit-exact throughout: these are integer counts.  Run on the GPU box: ``pytest -m gpu``.
+"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from pangaea_amd import _lib, kmer, synth
+from pangaea_amd.reads import ReadStream, Rows
+
+from .conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    _CASES = json.load(_f)["cases"]
+
+DEV = "cuda:0"
+
+
+def _stream(spec):
+    r1 = os.path.join(GOLDEN, spec.get("i") or spec["1"])
+    r2 = os.path.join(GOLDEN, spec["2"]) if "2" in spec else None
+    return ReadStream.from_fastq(r1, r2, device=DEV), oracle.Reads(r1, r2)
+
+
+def _csv_bytes(tmp_path, names, mat_i32):
+    mat = np.ascontiguousarray(mat_i32.cpu().numpy(), dtype=np.int32)
+    blob = b"".join(n.encode() + b"\0" for n in names)
+    out = str(tmp_path / "o.gz")
+    _lib.check(_lib.load().pg_write_csv_gz(out.encode(), blob, mat.ctypes.data, mat.shape[0], mat.shape[1]))
+    with gzip.open(out, "rb") as f:
+        return f.read()
+
+
+def test_loaded_library_is_the_in_tree_hip_build():
+    assert torch.cuda.is_available()
+    assert os.path.dirname(_lib.LIB_PATH).endswith("pangaea_amd")
+    assert _lib.load().pg_device_count() >= 1
+
+
+# ------------------------------------------------------------------ golden vectors of the reference binaries
+
+
+@pytest.mark.parametrize("case", [c for c in _CASES if c["tool"] == "count_tnf"], ids=lambda c: c["expect"])
+def test_tnf_golden(case, tmp_path):
+    s, _ = _stream(case["input"])
+    rows = s.rows(case["min_len"])
+    if case["k"] > _lib.TNF_MAX_K:
+        pytest.skip("k_tnf beyond the LDS histogram")
+    tnf, _ = kmer.features(s, rows, k_tnf=case["k"])
+    with open(os.path.join(GOLDEN, case["expect"]), "rb") as f:
+        assert _csv_bytes(tmp_path, rows.names, tnf) == f.read()
+
+
+@pytest.mark.parametrize("kind", ["default", "hash"])
+@pytest.mark.parametrize("case", [c for c in _CASES if c["tool"] == "count_kmer"], ids=lambda c: c["expect"])
+def test_abundance_golden(case, kind, tmp_path):
+    k = case["k"]
+    if k > _lib.HASH_MAX_K:
+        with pytest.raises(ValueError):
+            kmer.KmerTable.default_kind(k)
+        return
+    s, _ = _stream(case["input"])
+    rows = s.rows(case["min_len"])
+    # the table the reference was given: the (possibly holed) dump, loaded with its own loader semantics
+    codes, counts = oracle.Table.from_dump(os.path.join(GOLDEN, case["dump"]), k).items()
+    table = kmer.KmerTable.from_items(k, codes, counts, DEV, None if kind == "default" else "hash")
+    if table.kind == "hash" and case["window"] * case["vsize"] > _lib.HASH_COUNT_SAT:
+        with pytest.raises(_lib.PangaeaError):      # bins beyond the exact range of the slot counter are refused
+            kmer.features(s, rows, k_tnf=None, table=table, window=case["window"], vsize=case["vsize"])
+        return
+    _, abd = kmer.features(s, rows, k_tnf=None, table=table, window=case["window"], vsize=case["vsize"])
+    with open(os.path.join(GOLDEN, case["expect"]), "rb") as f:
+        assert _csv_bytes(tmp_path, rows.names, abd) == f.read()
+    if not case["holes"]:
+        # and the table the GPU counts by itself is the dump
+        mine = kmer.count_kmers(s, k, kind=None if kind == "default" else "hash")
+        c2, n2 = mine.items()
+        assert np.array_equal(c2, codes) and np.array_equal(n2, np.minimum(counts, _lib.HASH_COUNT_SAT) if mine.kind == "hash" else counts)
+
+
+# ------------------------------------------------------------------ seeded synthetic reads vs the oracle
+
+
+def _oracle_rows(s: ReadStream, rows: Rows, k_tnf, k, window, vsize):
+    text = s.decode()
+    table = oracle.Table(k, threads=4).count(text) if k else None
+    tnf = np.stack([oracle.tnf_row(text[a:b], k_tnf) for a, b in zip(rows.start, rows.end)]) if k_tnf else None
+    abd = np.stack([oracle.abd_row(text[a:b], k, table, window, vsize) for a, b in zip(rows.start, rows.end)]) if k else None
+    return table, tnf, abd
+
+
+@pytest.mark.parametrize("k,kind,k_tnf,window,vsize,seg", [
+    (15, "dense", 4, 10, 400, 16384), (21, "hash", 4, 10, 400, 16384), (21, "hash", 3, 1, 6, 64),
+    (11, "dense", 5, 2, 50, 32), (11, "hash", 6, 3, 1500, 4096), (17, "hash", 1, 7, 33, 1024), (4, "dense", 2, 100, 400, 512),
+])
+def test_synthetic_against_oracle(k, kind, k_tnf, window, vsize, seg):
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=37, n_genomes=3, genome_len=30_000, fragment=8_000,
+                            sub_rate=0.01, n_rate=0.2, seed=100 + k)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    assert len(rows) == 37
+    table = kmer.count_kmers(s, k, kind=kind)
+    tnf, abd = kmer.features(s, rows, k_tnf=k_tnf, table=table, window=window, vsize=vsize, seg_chars=seg)
+    otab, otnf, oabd = _oracle_rows(s, rows, k_tnf, k, window, vsize)
+    gc, gn = table.items()
+    oc, on = otab.items()
+    assert np.array_equal(gc, oc) and np.array_equal(gn, on)
+    assert np.array_equal(tnf.cpu().numpy(), otnf)
+    assert np.array_equal(abd.cpu().numpy(), oabd)
+
+
+def test_ragged_and_degenerate_runs():
+    runs = [("", b"ACGTACGTN"), ("a", b""), ("b", b"N"), ("c", b"ACGN"), ("d", b"ACGTN" * 3), ("e", b"A" * 5000 + b"N"),
+            ("f", b"NNNNACGTACGTACGTACGTACGTACGTNNNN"), ("g", b"acgtacgtacgtN"), ("h", (b"ACGT" * 9 + b"N") * 40),
+            ("i", b"ACGTTGCAN" * 7), ("j", b"G" * 31 + b"N"), ("k", b"C" * 32 + b"N"), ("l", b"T" * 33 + b"N")]
+    s = ReadStream.from_runs(runs, device=DEV)
+    for k, kind in ((4, "dense"), (21, "hash"), (9, "hash")):
+        rows = s.rows(-1)             # every named run, even the empty one
+        assert len(rows) == len(runs) - 1
+        table = kmer.count_kmers(s, k, kind=kind)
+        tnf, abd = kmer.features(s, rows, k_tnf=4, table=table, window=1, vsize=64, seg_chars=32)
+        otab, otnf, oabd = _oracle_rows(s, rows, 4, k, 1, 64)
+        assert all(np.array_equal(x, y) for x, y in zip(table.items(), otab.items()))
+        assert np.array_equal(tnf.cpu().numpy(), otnf) and np.array_equal(abd.cpu().numpy(), oabd)
+    none = Rows(np.zeros(0, np.int64), [], np.zeros(0, np.int64), np.zeros(0, np.int64))
+    tnf, _ = kmer.features(s, none, k_tnf=4)
+    assert tuple(tnf.shape) == (0, 136)
+
+
+def test_counting_in_pieces_accumulates():
+    cfg = synth.SynthConfig(n_pairs=4096, n_barcodes=16, n_genomes=2, genome_len=50_000, fragment=10_000, seed=5)
+    s = synth.generate(cfg, device=DEV)
+    for k, kind in ((13, "dense"), (21, "hash")):
+        whole = kmer.count_kmers(s, k, kind=kind)
+        parts = kmer.KmerTable.alloc(k, DEV, kind, distinct_hint=s.n_chars)
+        cut = (s.n_words // 3) + 7
+        parts.count(s, 0, cut).count(s, cut, s.n_words)
+        assert all(np.array_equal(x, y) for x, y in zip(whole.items(), parts.items()))
+        # merging a compacted table doubles every count
+        if kind == "hash":
+            twice = kmer.KmerTable.alloc(k, DEV, kind, distinct_hint=s.n_chars)
+            twice.merge(whole.compact()).merge(whole.compact())
+            c1, n1 = whole.items()
+            c2, n2 = twice.items()
+            assert np.array_equal(c1, c2) and np.array_equal(2 * n1, n2)
+
+
+def test_hash_table_full_is_reported_and_regrown():
+    cfg = synth.SynthConfig(n_pairs=2048, n_barcodes=8, n_genomes=2, genome_len=200_000, fragment=50_000, seed=9)
+    s = synth.generate(cfg, device=DEV)
+    tiny = kmer.KmerTable.alloc(21, DEV, "hash", distinct_hint=512)
+    with pytest.raises(_lib.PangaeaError) as e:
+        tiny.count(s)
+    assert e.value.code == _lib.PG_ETABLEFULL
+    grown = kmer.count_kmers(s, 21, kind="hash", distinct_hint=512)
+    want = oracle.Table(21, threads=4).count(s.decode())
+    assert all(np.array_equal(x, y) for x, y in zip(grown.items(), want.items()))
+
+
+def test_saturating_counts_do_not_change_bins():
+    # 3.1 M identical 21-mers: the slot count stops at 2^21, every bin below vsize*window stays exact
+    s = ReadStream.from_runs([("a", b"A" * 1_600_000 + b"N" + b"T" * 1_500_040 + b"N"), ("b", b"ACGT" * 600 + b"N")], device=DEV)
+    table = kmer.count_kmers(s, 21, kind="hash")
+    codes, counts = table.items()
+    assert counts.max() >= _lib.HASH_COUNT_SAT and counts.max() < (1 << _lib.HASH_COUNT_BITS)
+    rows = s.rows(0)
+    _, abd = kmer.features(s, rows, k_tnf=None, table=table, window=10, vsize=400)
+    _, _, oabd = _oracle_rows(s, rows, None, 21, 10, 400)
+    assert np.array_equal(abd.cpu().numpy(), oabd)
+    with pytest.raises(_lib.PangaeaError):
+        kmer.features(s, rows, k_tnf=None, table=table, window=1 << 12, vsize=1 << 10)
+
+
+# ------------------------------------------------------------------ BASELINE-size properties (config 2)
+
+
+def _valid_kmer_ends(valid_words: torch.Tensor, k: int) -> torch.Tensor:
+    """per word: number of positions ending a run of >= k valid characters (torch restatement)"""
+    v = valid_words.to(torch.int64) & 0xFFFFFFFF
+    prev = torch.cat([v.new_zeros(1), v[:-1]])
+    m = (v << 32) | prev                     # bit 63 may be set: arithmetic below only uses & and <<
+    r = m
+    ln = 1
+    while 2 * ln <= k:
+        r = r & (r << ln)
+        ln *= 2
+    if ln < k:
+        r = r & (r << (k - ln))
+    hi = (r >> 32) & 0xFFFFFFFF
+    cnt = torch.zeros_like(hi)
+    for b in range(32):
+        cnt += (hi >> b) & 1
+    return cnt
+
+
+def test_full_size_invariants():
+    """10 M pairs / 50 k barcodes / k=21 (BASELINE config 2): size-independent properties"""
+    cfg = synth.SynthConfig(n_pairs=10_000_000, n_barcodes=50_000)
+    s = synth.generate(cfg, device=DEV, chunk_pairs=1 << 17, with_names=False)
+    rows = s.rows(2000)
+    assert len(rows) == 50_000
+    table = kmer.count_kmers(s, 21, kind="hash", distinct_hint=260_000_000)
+    tnf, abd = kmer.features(s, rows, k_tnf=4, table=table, window=10, vsize=400)
+    torch.cuda.synchronize()
+    n21 = _valid_kmer_ends(s.valid, 21)
+    n4 = _valid_kmer_ends(s.valid, 4)
+    # (1) the table accounts for every valid 21-mer occurrence of every read
+    slots = table.compact()
+    assert int((slots & ((1 << 22) - 1)).sum().item()) == int(n21.sum().item())
+    # (2) TNF rows + the two complement ranges (first pair, unbarcoded tail) account for every valid 4-mer end;
+    #     rows tile [302, end of the last barcoded run) without gaps
+    cpp = cfg.chars_per_pair
+    assert rows.start[0] == cpp and (np.diff(rows.start) == 200 * cpp).all() and (rows.end[:-1] == rows.start[1:]).all()
+    comp = Rows(np.arange(2), ["head", "tail"], np.array([0, int(rows.end[-1])]), np.array([cpp, s.n_chars]))
+    tnf_c, abd_c = kmer.features(s, comp, k_tnf=4, table=table, window=1 << 11, vsize=1 << 10)
+    assert int(tnf.to(torch.int64).sum().item()) + int(tnf_c.sum().item()) == int(n4.sum().item())
+    # (3) abundance rows: every valid 21-mer of a row is binned unless its multiplicity is >= 4000
+    #     (window * vsize = 2^21 = the saturation point, far above any multiplicity here: nothing is dropped)
+    _, abd_all = kmer.features(s, rows, k_tnf=None, table=table, window=1 << 11, vsize=1 << 10)
+    assert int(abd_all.to(torch.int64).sum().item()) + int(abd_c.sum().item()) == int(n21.sum().item())
+    assert (abd.to(torch.int64).sum(1) <= abd_all.to(torch.int64).sum(1)).all()
+    # (4) idempotence: a second launch into fresh outputs gives the same matrices
+    tnf2, abd2 = kmer.features(s, rows, k_tnf=4, table=table, window=10, vsize=400)
+    assert torch.equal(tnf, tnf2) and torch.equal(abd, abd2)
+    # (5) spot rows against the oracle (first, middle, last)
+    text_rows = [0, 24_999, 49_999]
+    for r in text_rows:
+        txt = s.decode(int(rows.start[r]), int(rows.end[r]))
+        assert np.array_equal(tnf[r].cpu().numpy(), oracle.tnf_row(txt, 4))
