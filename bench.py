@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- read-pairs/s through the barcode feature path + VAE encode (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path over one batch of synthetic barcoded read pairs that are already resident
+in HBM in packed form: clear + build the global canonical 21-mer table (K2), exchange it between ranks (N > 1),
+count TNF + abundance rows for every barcode (K1+K3), L1-normalise, VAE encode -> mu[N,32].
+Workload at N=1 = BASELINE.json configs[1]: 10 M 150 bp pairs, 50 k barcodes, k=21, k_tnf=4, V=400, W=10.
+For N > 1 every rank holds its own 10 M-pair shard of one N x 10 M-pair data set (weak scaling); launched as
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+K_ABD, K_TNF, WINDOW, VSIZE, MIN_LEN, READ_LEN = 21, 4, 10, 400, 2000, 150
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+# Algorithmic bytes per read pair (restated in DESIGN.md), L=150, k=21, n_k = 2(L-k+1) = 260:
+#   stream  : 302 characters x (2-bit code + 1-bit validity) = 113.25 B
+#   K2 hash : stream + n_k x 16 B (8-B slot read + 8-B slot write-back)      = 4273.25 B
+#   K3 hash : stream + n_k x 8 B (slot read) + (136+400) x 4 B / 200 pairs   = 2203.97 B
+STREAM_B = 302 * 3 / 8
+ALG_BYTES = {"kmer_count": STREAM_B + 260 * 16, "features": STREAM_B + 260 * 8 + (136 + 400) * 4 / 200}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (default: BASELINE config 2)")
+    ap.add_argument("--barcodes", type=int, default=0, help="barcodes per GPU (default pairs/200)")
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="pairs in the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(stream, cfg, n_sample: int, state: dict) -> dict:
+    """the reference's CPU path on the first n_sample pairs of the same workload, on this box's host cores:
+    count_tnf + count_kmer are the REFERENCE binaries (oracle/_ref) when present, else the oracle port; the
+    jellyfish stage (absent everywhere) is the oracle's exact counter; then data.py normalise + VAE encode."""
+    from oracle import oracle
+    from pangaea_amd import synth
+
+    cores = min(len(os.sched_getaffinity(0)), 16)      # the one-GPU box's CPU share
+    oracle.lib()
+    tmp = tempfile.mkdtemp(prefix="pg_cpu_")
+    fq = os.path.join(tmp, "sample.fq")
+    n = synth.write_fastq(stream, cfg, fq, n_sample)
+    ref_tnf, ref_kmer = oracle.ref_tool("count_tnf"), oracle.ref_tool("count_kmer")
+    t = {}
+    t0 = time.perf_counter()
+    rd = oracle.Reads(fq)
+    text = np.frombuffer(rd.all_seq(), dtype=np.uint8)
+    t["parse(port)"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    table = oracle.Table(K_ABD, threads=cores).count(text)
+    dump = os.path.join(tmp, "k.dump")
+    table.dump(dump)
+    t["jellyfish-standin(port)"] = time.perf_counter() - t0
+    kind = "reference" if ref_tnf and ref_kmer else "port"
+    if kind == "reference":
+        t0 = time.perf_counter()
+        subprocess.run([ref_tnf, "-i", fq, "-k", str(K_TNF), "-l", str(MIN_LEN), "-t", str(cores), "-o", os.path.join(tmp, "t.gz")],
+                       check=True, stdout=subprocess.DEVNULL)
+        t["count_tnf(reference)"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        subprocess.run([ref_kmer, "-i", fq, "-g", dump, "-k", str(K_ABD), "-l", str(MIN_LEN), "-w", str(WINDOW), "-v", str(VSIZE),
+                        "-t", str(cores), "-o", os.path.join(tmp, "a.gz")], check=True, stdout=subprocess.DEVNULL)
+        t["count_kmer(reference)"] = time.perf_counter() - t0
+        names, tnf, abd = rd.features(MIN_LEN, k_tnf=K_TNF, k_abd=K_ABD, table=table, window=WINDOW, vsize=VSIZE, threads=cores)
+    else:
+        t0 = time.perf_counter()
+        names, tnf, abd = rd.features(MIN_LEN, k_tnf=K_TNF, k_abd=K_ABD, table=table, window=WINDOW, vsize=VSIZE, threads=cores)
+        t["count_tnf+count_kmer(port)"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    a, b, _ = oracle.data_normalize(abd, tnf)
+    torch.set_num_threads(cores)
+    oracle.vae_embedding(state, a, b)
+    t["normalise+encode(torch cpu)"] = time.perf_counter() - t0
+    counted = {k: v for k, v in t.items() if not k.startswith("parse")}
+    total = sum(counted.values())
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+    return {"value": n / total, "unit": "pairs/s", "cores": cores, "kind": kind,
+            "sample": f"first {n} pairs of the workload as FASTQ; seconds: " + ", ".join(f"{k} {v:.2f}" for k, v in counted.items())}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the feature path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pangaea_amd import dist as pdist
+    from pangaea_amd import kmer, synth
+    from pangaea_amd.data import Data
+    from pangaea_amd.models.VAENET import VAENET
+
+    n_bc = args.barcodes or max(1, args.pairs // 200)
+    cfg = synth.SynthConfig(n_pairs=args.pairs, n_barcodes=n_bc, read_len=READ_LEN, seed=2022, first_pair=rank * args.pairs)
+    stream = synth.generate(cfg, device=dev, chunk_pairs=1 << 17, with_names=False)
+    rows = stream.rows(MIN_LEN)
+    plan = kmer.Plan(rows, dev)
+    # distinct 21-mers: <= 128 M genomic + ~21 per substitution error; sized for the union over ranks at load <= 0.5
+    distinct_hint = int(130e6 + 0.7e8 * world * args.pairs / 10e6) if args.pairs >= 1_000_000 else stream.n_chars
+    table = kmer.KmerTable.alloc(K_ABD, dev, "hash", distinct_hint=distinct_hint)
+    tnf = torch.zeros((len(rows), kmer.tnf_ncols(K_TNF)), dtype=torch.int32, device=dev)
+    abd = torch.zeros((len(rows), VSIZE), dtype=torch.int32, device=dev)
+    torch.manual_seed(2021)
+    vae = VAENET(VSIZE, tnf.shape[1], 32, 30, 1, True, 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+    vae.network.eval()
+    names = np.array(rows.names, dtype=object)
+
+    ev = {k: [] for k in ("kmer_count", "features")}
+
+    def step(timed: bool):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        table.data.zero_()
+        table.status.zero_()
+        e[0].record()
+        table.count(stream, check=False)
+        e[1].record()
+        pdist.exchange_table(table, check=False)
+        e[2].record()
+        kmer.features(stream, plan, k_tnf=K_TNF, table=table, window=WINDOW, vsize=VSIZE, out_tnf=tnf, out_abd=abd)
+        e[3].record()
+        d = Data(names, abd, tnf, device=dev)
+        mu = vae.encode(d)
+        if timed:
+            ev["kmer_count"].append((e[0], e[1]))
+            ev["features"].append((e[2], e[3]))
+        return mu
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mu = step(False)
+    fence()
+    table.check_status()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mu = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    table.check_status()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert tuple(mu.shape) == (len(rows), 32) and bool(torch.isfinite(mu).all())
+
+    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    dominant = max(kern_ms, key=kern_ms.get)
+    achieved = ALG_BYTES[dominant] * args.pairs / (kern_ms[dominant] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")        # per-launch HBM bytes from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("pairs") == args.pairs:
+            traffic = tj.get("kernels", {}).get(dominant)
+
+    if rank == 0:
+        out = {
+            "metric": "barcoded read-pairs/sec through feature+VAE-encode",
+            "value": world * args.pairs * args.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {args.pairs} x 150 bp read pairs and {n_bc} barcodes per GPU, k=21 hash table "
+                                   f"(2^{table.log2_slots} slots), TNF k=4 + abundance V=400 W=10, L1-normalise, VAE 536-512-512-32 encode",
+                       "pairs_per_gpu": args.pairs, "barcodes_per_gpu": n_bc, "rows_per_gpu": len(rows),
+                       "parallelism": f"run-sharded x{world}, table all-gather+merge" if world > 1 else "single GPU",
+                       "input": "packed reads resident in HBM"},
+            "kernel_ms": kern_ms,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "alg_bytes_per_pair": ALG_BYTES[dominant]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            state = {k: v.detach().cpu().numpy() for k, v in vae.network.state_dict().items()}
+            try:
+                out["cpu_baseline"] = cpu_baseline(stream, cfg, min(args.cpu_sample, args.pairs), state)
+            except Exception as e:          # the baseline is reporting only; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

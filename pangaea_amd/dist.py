@@ -1,0 +1,97 @@
+"""Multi-GPU decomposition of the feature path (one process per GPU, torch.distributed; "nccl" is RCCL on ROCm).
+
+The reference is single-process; the decomposition is the build's own:
+  * rows (barcode runs) are independent -> every rank takes a contiguous range of runs, balanced by characters,
+    and produces its own block of the count matrices: no data-path collective for K1/K3 or the VAE encode;
+  * the k-mer multiplicity table is a global sum -> ONE exchange after counting: dense tables (k <= 16) are
+    summed with an all-reduce; hash tables are compacted, all-gathered and merged, after which every rank holds
+    the full table and looks up locally.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .kmer import KmerTable
+from .reads import ReadStream
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def balanced_run_ranges(run_off: np.ndarray, world: int) -> list[tuple[int, int]]:
+    """contiguous run ranges [(first, last+1)] per rank with roughly equal character counts; ranges tile all runs"""
+    n = len(run_off) - 1
+    total = int(run_off[-1] - run_off[0])
+    cuts = [0]
+    for r in range(1, world):
+        target = run_off[0] + total * r // world
+        i = int(np.searchsorted(run_off, target, side="left"))
+        cuts.append(min(max(i, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def shard_stream(stream: ReadStream, rank: int, world: int) -> ReadStream:
+    """the part of a (host) stream a rank counts and builds rows for: its run range, word aligned.
+
+    Runs keep their reference shape (own pairs 2..n + first pair of the next barcode) because sharding happens
+    AFTER run assembly: the one-pair halo of SURVEY 8e is already inside the run.  Characters outside every run
+    (reads of skipped pairs, stored after the last run) go to the last rank; they only feed the global table.
+    """
+    first, last = balanced_run_ranges(stream.run_off, world)[rank]
+    c0 = int(stream.run_off[first])
+    c1 = int(stream.run_off[last]) if rank < world - 1 else stream.n_chars
+    w0, w1 = c0 // 32, (c1 + 31) // 32
+    codes = stream.codes[w0:w1].clone()
+    valid = stream.valid[w0:w1].clone()
+    # characters of neighbouring ranks that share the first / last word are masked out (they are counted there)
+    if codes.numel():
+        lo, hi = c0 - 32 * w0, c1 - 32 * (w1 - 1)
+        keep_first = ~((1 << lo) - 1) & 0xFFFFFFFF
+        keep_last = ((1 << hi) - 1) & 0xFFFFFFFF if hi < 32 else 0xFFFFFFFF
+        v = valid.to(torch.int64) & 0xFFFFFFFF
+        v[0] &= keep_first
+        v[-1] &= keep_last
+        valid = torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32)
+    from .reads import words_for
+    pad = words_for((w1 - w0) * 32) - (w1 - w0)
+    if pad:
+        codes = torch.cat([codes, codes.new_zeros(pad)])
+        valid = torch.cat([valid, valid.new_zeros(pad)])
+    run_off = stream.run_off[first:last + 1] - 32 * w0
+    return ReadStream(codes, valid, c1 - 32 * w0, run_off.astype(np.int64), stream.run_names[first:last], mode=stream.mode)
+
+
+def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
+    """all-gather of variable-length int64 vectors (padded to the longest); returns one tensor per rank"""
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    buf = local.new_zeros(cap)
+    buf[:local.numel()] = local
+    out = [local.new_zeros(cap) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return [o[:s] for o, s in zip(out, sizes)]
+
+
+def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTable:
+    """turn per-rank partial tables into the global table on every rank (the path's only collective)"""
+    if not is_distributed():
+        return table
+    if table.kind == "dense":
+        dist.all_reduce(table.data, op=dist.ReduceOp.SUM, group=group)     # int32 sum == uint32 sum (mod 2^32)
+        return table
+    me = dist.get_rank(group)
+    parts = gather_pairs(table.compact(), group)
+    for r, pairs in enumerate(parts):
+        if r != me and pairs.numel():
+            table.merge(pairs, check=False)
+    if check:
+        table.check_status()
+    return table

@@ -234,6 +234,8 @@ def features(stream: ReadStream, rows: Rows | Plan, k_tnf: int | None = 4, table
         abd = out_abd.zero_() if out_abd is not None else torch.zeros((n, vsize), dtype=torch.int32, device=dev)
     if tnf is None and abd is None:
         raise ValueError("nothing to compute: give k_tnf and/or a table")
+    if plan.n_segs == 0:            # no rows (or only empty ones): the zero-filled matrices are the answer
+        return tnf, abd
     with torch.cuda.device(dev):
         _lib.check(_lib.load().pg_features(
             stream.codes.data_ptr(), stream.valid.data_ptr(), stream.n_words,

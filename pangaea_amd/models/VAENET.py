@@ -1,0 +1,201 @@
+"""``VAENET`` / ``VaritionalAutoEncoder`` -- device-resident counterpart of /root/reference/src/models/VAENET.py.
+
+Interface kept: ``VAENET(abd_dim, tnf_dim, latent_size, num_classes, epochs, cuda, num_gpus, lr, dropout, alpha,
+w_kl, weight_decay).train(train_loader, val_loader, dataloader, model_path, patience)`` writes
+``train_model.pk`` (state_dict with the reference's keys ``encoder.{0,1,4,5}``, ``l_mu``, ``l_sigma``,
+``decoder.{0,1,4,5}``, ``output``), ``latent.npz``, ``barcodes.npz`` and ``model_finished`` (VAENET.py:35,128-149).
+
+Behaviour reproduced on purpose:
+  * ``nn.LeakyReLU(True)`` -- negative_slope=True == 1.0, i.e. the identity (VAENET.py:205,217);
+  * hidden sizes [512, 512] and latent 32 whatever ``latent_size`` says; it only scales ``w_kl`` (VAENET.py:20,25).
+Changed on purpose: the network really lives on the GPU (the reference unwraps DataParallel and draws epsilon on
+the CPU, VAENET.py:26-29,227, so its ``-g`` flag cannot work); ``encode`` embeds a whole ``Data`` set from its
+device copies in dataset order instead of going through a shuffling DataLoader -- ``barcodes.npz`` carries the
+order, as in the reference.
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from ..utils import EarlyStopping
+
+
+class VaritionalAutoEncoder(nn.Module):
+    def __init__(self, input_abd_size, input_tnf_size, hidden_sizes=(512, 512), latent_size=32, dropout=0.2):
+        super().__init__()
+        hidden_sizes = list(hidden_sizes)
+        self.abd_size, self.tnf_size = input_abd_size, input_tnf_size
+        self.input_size = input_abd_size + input_tnf_size
+
+        def stack(sizes):
+            layers = []
+            for n_in, n_out in zip(sizes[:-1], sizes[1:]):
+                layers += [nn.Linear(n_in, n_out), nn.BatchNorm1d(n_out), nn.LeakyReLU(True), nn.Dropout(dropout)]
+            return nn.Sequential(*layers)
+
+        self.encoder = stack([self.input_size] + hidden_sizes)
+        self.l_mu = nn.Linear(hidden_sizes[-1], latent_size)
+        self.l_sigma = nn.Linear(hidden_sizes[-1], latent_size)
+        self.softplus = nn.Softplus()
+        self.decoder = stack([latent_size] + hidden_sizes[::-1])
+        self.output = nn.Linear(hidden_sizes[0], self.input_size)
+
+    def calcu_latent(self, abd, tnf, epsilon=None):
+        hidden = self.encoder(torch.cat((abd, tnf), 1))
+        mu = self.l_mu(hidden)
+        logsigma = self.softplus(self.l_sigma(hidden))
+        if epsilon is None:
+            epsilon = torch.randn(mu.size(0), mu.size(1), device=mu.device)
+        latent = mu + epsilon * torch.exp(logsigma / 2)
+        return mu, logsigma, latent
+
+    def emebdding(self, abd, tnf):          # (sic) the reference's spelling, VAENET.py:232
+        return self.l_mu(self.encoder(torch.cat((abd, tnf), 1)))
+
+    def forward(self, abd, tnf, epsilon=None):
+        mu, logsigma, latent = self.calcu_latent(abd, tnf, epsilon)
+        out = self.output(self.decoder(latent))
+        return {
+            "abd": abd, "tnf": tnf,
+            "abd_rec": F.softmax(out.narrow(1, 0, self.abd_size), dim=1),
+            "tnf_rec": F.softmax(out.narrow(1, self.abd_size, self.tnf_size), dim=1),
+            "mu": mu, "logsigma": logsigma,
+        }
+
+
+class VAENET:
+    def __init__(self, abd_dim, tnf_dim, latent_size, num_classes, epochs, cuda, num_gpus, lr, dropout, alpha, w_kl,
+                 weight_decay):
+        self.num_epochs = epochs
+        self.num_classes = num_classes
+        self.latent_size = latent_size
+        self.input_size = abd_dim + tnf_dim
+        self.learning_rate = lr
+        self.weight_decay = weight_decay
+        self.w_kl = w_kl * 100 / latent_size
+        self.wa = alpha * 100 / np.log(abd_dim)
+        self.wt = (1 - alpha) * 100 / np.log(tnf_dim)
+        self.cuda = bool(cuda)
+        self.eps = 1e-9
+        self.device = torch.device("cuda", torch.cuda.current_device()) if self.cuda else torch.device("cpu")
+        self.network = VaritionalAutoEncoder(abd_dim, tnf_dim, dropout=dropout).to(self.device)
+
+    # ------------------------------------------------------------------ loss (VAENET.py:161-184)
+
+    def reconstruction_loss(self, real, predicted):
+        return -(torch.log(predicted + self.eps) * real).sum(-1).mean()
+
+    def unlabeled_loss(self, out_net):
+        mu, logsigma = out_net["mu"], out_net["logsigma"]
+        loss_abd = self.reconstruction_loss(out_net["abd"], out_net["abd_rec"])
+        loss_tnf = self.reconstruction_loss(out_net["tnf"], out_net["tnf_rec"])
+        loss_kl = -0.5 * (1 + logsigma - mu.pow(2) - logsigma.exp()).sum(dim=1).mean()
+        total = self.wa * loss_abd + self.wt * loss_tnf + self.w_kl * loss_kl
+        return {"total": total, "abd_rec": loss_abd, "tnf_rec": loss_tnf, "kl_loss": loss_kl}
+
+    # ------------------------------------------------------------------ encode (VAENET.py:126-149)
+
+    @torch.no_grad()
+    def encode(self, data, batch_rows: int = 1 << 16) -> torch.Tensor:
+        """mu for every row of a ``pangaea_amd.data.Data`` set, in dataset order, on the device"""
+        self.network.eval()
+        abd, tnf = data.abd_dev.to(self.device), data.tnf_dev.to(self.device)
+        out = torch.empty((abd.shape[0], self.network.l_mu.out_features), dtype=torch.float32, device=self.device)
+        for a in range(0, abd.shape[0], batch_rows):
+            out[a:a + batch_rows] = self.network.emebdding(abd[a:a + batch_rows], tnf[a:a + batch_rows])
+        return out
+
+    def _to_dev(self, batch):
+        return torch.as_tensor(batch["abd"]).to(self.device), torch.as_tensor(batch["tnf"]).to(self.device)
+
+    @torch.no_grad()
+    def _validate(self, loader) -> float:
+        self.network.eval()
+        losses = []
+        for batch in loader:
+            abd, tnf = self._to_dev(batch)
+            losses.append(self.unlabeled_loss(self.network(abd, tnf))["total"].item())
+        return float(np.average(losses))
+
+    # ------------------------------------------------------------------ train (VAENET.py:31-149)
+
+    def train(self, train_loader, val_loader, dataloader, model_path, patience):
+        if not os.path.isdir(model_path):
+            raise Exception("model path not exist")
+        train_model = os.path.join(model_path, "train_model.pk")
+        early = EarlyStopping(patience=patience, delta=1e-6, path=train_model)
+        if not os.path.exists(train_model):
+            logging.info("train start")
+            opt = torch.optim.Adam(self.network.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+            hist = {"total": [], "abd_rec": [], "tnf_rec": [], "kl_loss": []}
+
+            def report(epoch, batch, val):
+                logging.info(
+                    f"epoch {epoch}/{self.num_epochs} batch {batch + 1}/{len(train_loader)}: train {np.average(hist['total']):.8f} "
+                    f"abd {np.average(hist['abd_rec']):.8f} tnf {np.average(hist['tnf_rec']):.8f} "
+                    f"kl {np.average(hist['kl_loss']):.8f} | test {val:.8f}")
+                for v in hist.values():
+                    v.clear()
+
+            for epoch in range(1, self.num_epochs + 1):
+                batch = -1
+                for batch, data in enumerate(train_loader):
+                    self.network.train()
+                    opt.zero_grad()
+                    abd, tnf = self._to_dev(data)
+                    losses = self.unlabeled_loss(self.network(abd, tnf))
+                    for key in hist:
+                        hist[key].append(losses[key].item())
+                    losses["total"].backward()
+                    opt.step()
+                    if (batch + 1) % 100 == 0:          # validation + early stopping every 100 batches
+                        val = self._validate(val_loader)
+                        report(epoch, batch, val)
+                        early(val, self.network)
+                    if early.early_stop:
+                        logging.info("early stop triggered")
+                        break
+                if early.early_stop:
+                    logging.info("early stop triggered")
+                    break
+                val = self._validate(val_loader)
+                report(epoch, batch, val)
+                if len(train_loader) % 100 != 0:
+                    early(val, self.network)
+                    if early.early_stop:
+                        logging.info("early stop triggered")
+                        break
+            if not os.path.exists(train_model):
+                torch.save(self.network.state_dict(), train_model)
+        else:
+            logging.info("trainning model already saved")
+
+        latent_path = os.path.join(model_path, "latent.npz")
+        barcodes_path = os.path.join(model_path, "barcodes.npz")
+        if not os.path.exists(latent_path) or not os.path.exists(barcodes_path):
+            self.network.load_state_dict(torch.load(train_model, map_location=self.device))
+            self.network.eval()
+            dataset = getattr(dataloader, "dataset", None)
+            if dataset is not None and hasattr(dataset, "abd_dev"):
+                embedding = self.encode(dataset).cpu().numpy()
+                barcodes = list(dataset.bc)
+            else:
+                chunks, barcodes = [], []
+                with torch.no_grad():
+                    for data in dataloader:
+                        abd, tnf = self._to_dev(data)
+                        chunks.append(self.network.emebdding(abd, tnf).cpu().numpy())
+                        barcodes.extend(data["bc"])
+                embedding = np.concatenate(chunks, axis=0)
+            np.savez(barcodes_path, barcodes)
+            np.savez(latent_path, embedding)
+        else:
+            logging.info("latent and barcodes already saved")
+        with open(os.path.join(model_path, "model_finished"), "w") as f:
+            f.write("model finished")

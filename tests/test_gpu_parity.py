@@ -218,7 +218,7 @@ def test_full_size_invariants():
     # (2) TNF rows + the two complement ranges (first pair, unbarcoded tail) account for every valid 4-mer end;
     #     rows tile [302, end of the last barcoded run) without gaps
     cpp = cfg.chars_per_pair
-    assert rows.start[0] == cpp and (np.diff(rows.start) == 200 * cpp).all() and (rows.end[:-1] == rows.start[1:]).all()
+    assert rows.start[0] == cpp and (np.diff(rows.start) == cfg.pairs_per_barcode * cpp).all() and (rows.end[:-1] == rows.start[1:]).all()
     comp = Rows(np.arange(2), ["head", "tail"], np.array([0, int(rows.end[-1])]), np.array([cpp, s.n_chars]))
     tnf_c, abd_c = kmer.features(s, comp, k_tnf=4, table=table, window=1 << 11, vsize=1 << 10)
     assert int(tnf.to(torch.int64).sum().item()) + int(tnf_c.sum().item()) == int(n4.sum().item())
