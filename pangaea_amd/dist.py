@@ -65,9 +65,16 @@ def shard_stream(stream: ReadStream, rank: int, world: int) -> ReadStream:
     return ReadStream(codes, valid, c1 - 32 * w0, run_off.astype(np.int64), stream.run_names[first:last], mode=stream.mode)
 
 
+def _staged(t: torch.Tensor, group=None) -> torch.Tensor:
+    """gloo cannot all-gather device tensors: stage through the host there (RCCL takes them as they are)"""
+    return t.cpu() if t.is_cuda and dist.get_backend(group) == "gloo" else t
+
+
 def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
     """all-gather of variable-length int64 vectors (padded to the longest); returns one tensor per rank"""
     world = dist.get_world_size(group)
+    home = local.device
+    local = _staged(local, group)
     n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
@@ -77,7 +84,7 @@ def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
     buf[:local.numel()] = local
     out = [local.new_zeros(cap) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
-    return [o[:s] for o, s in zip(out, sizes)]
+    return [o[:s].to(home) for o, s in zip(out, sizes)]
 
 
 def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTable:
@@ -85,7 +92,10 @@ def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTabl
     if not is_distributed():
         return table
     if table.kind == "dense":
-        dist.all_reduce(table.data, op=dist.ReduceOp.SUM, group=group)     # int32 sum == uint32 sum (mod 2^32)
+        data = _staged(table.data, group)
+        dist.all_reduce(data, op=dist.ReduceOp.SUM, group=group)           # int32 sum == uint32 sum (mod 2^32)
+        if data is not table.data:
+            table.data.copy_(data)
         return table
     me = dist.get_rank(group)
     parts = gather_pairs(table.compact(), group)

@@ -1,0 +1,119 @@
+"""world_size-2 checks of the multi-GPU decomposition over gloo: run sharding, the variable-length
+all-gather used for hash tables, and the dense-table all-reduce.  On the CPU the kernels cannot run, so the oracle
+plays the counter; the gpu-marked variant runs the real kernels on two ranks sharing cuda:0."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle
+from pangaea_amd import dist as pdist
+from pangaea_amd import kmer, synth
+from pangaea_amd.reads import ReadStream
+
+from .conftest import GOLDEN
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn(fn, world, *args):
+    port = _free_port()
+    mp.spawn(fn, args=(world, port) + args, nprocs=world, join=True)
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def test_shards_tile_the_runs_and_the_characters():
+    cfg = synth.SynthConfig(n_pairs=1500, n_barcodes=23, n_genomes=2, genome_len=30_000, fragment=8_000, n_rate=0.1)
+    host = synth.generate(cfg)
+    for world in (1, 2, 3, 8):
+        names, total_valid = [], 0
+        full_rows = host.rows(2000)
+        k = 11
+        want = oracle.Table(k).count(host.decode())
+        got = {}
+        for r in range(world):
+            sh = pdist.shard_stream(host, r, world)
+            assert sh.n_words % 256 == 0
+            rows = sh.rows(2000)
+            names += rows.names
+            for a, b, nm in zip(rows.start, rows.end, rows.names):
+                i = full_rows.names.index(nm)
+                assert sh.decode(int(a), int(b)) == host.decode(int(full_rows.start[i]), int(full_rows.end[i]))
+            c, n = oracle.Table(k).count(sh.decode()).items()
+            for ci, ni in zip(c, n):
+                got[int(ci)] = got.get(int(ci), 0) + int(ni)
+        assert names == full_rows.names
+        wc, wn = want.items()
+        assert got == {int(c): int(n) for c, n in zip(wc, wn)}        # every character counted on exactly one rank
+
+
+def _gloo_worker(rank, world, port, fastq):
+    _init(rank, world, port)
+    try:
+        host = ReadStream.from_fastq(fastq)
+        sh = pdist.shard_stream(host, rank, world)
+        # hash-table form: compact (code << 22 | count) vectors of different lengths, gathered on every rank
+        k = 21
+        c, n = oracle.Table(k).count(sh.decode()).items()
+        mine = torch.from_numpy(((c << np.uint64(22)) | n).astype(np.int64))
+        parts = pdist.gather_pairs(mine)
+        assert len(parts) == world and torch.equal(parts[rank], mine)
+        merged = {}
+        for p in parts:
+            for v in p.numpy().view(np.uint64):
+                merged[int(v >> np.uint64(22))] = merged.get(int(v >> np.uint64(22)), 0) + int(v & np.uint64((1 << 22) - 1))
+        wc, wn = oracle.Table(k).count(host.decode()).items()
+        assert merged == {int(a): int(b) for a, b in zip(wc, wn)}
+        # dense form: the all-reduce of the path
+        k = 6
+        t = kmer.KmerTable.alloc(k, "cpu", "dense")
+        c, n = oracle.Table(k).count(sh.decode()).items()
+        t.data[torch.from_numpy(c.astype(np.int64))] = torch.from_numpy(n.astype(np.int32))
+        pdist.exchange_table(t)
+        wc, wn = oracle.Table(k).count(host.decode()).items()
+        gc, gn = t.items()
+        assert np.array_equal(gc, wc) and np.array_equal(gn, wn)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_cpu():
+    _spawn(_gloo_worker, 2, os.path.join(GOLDEN, "tenx_mixed.fq"))
+
+
+def _gpu_worker(rank, world, port, fastq, outdir):
+    _init(rank, world, port)
+    try:
+        from pangaea_amd import feature
+        torch.cuda.set_device(0)
+        names, tnf, abd = feature.compute_features(fastq, None, 21, 4, 1, 6, 100)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "r.npz"), names=np.array(names), tnf=tnf, abd=abd)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_real_kernels_match_single_process(tmp_path):
+    """two processes share cuda:0, shard the runs, exchange the hash table (gather + merge kernel) and gather rows"""
+    fq = os.path.join(GOLDEN, "tenx_mixed.fq")
+    _spawn(_gpu_worker, 2, fq, str(tmp_path))
+    got = np.load(str(tmp_path / "r.npz"))
+    rd = oracle.Reads(fq)
+    table = oracle.Table(21).count(rd.all_seq())
+    names, tnf, abd = rd.features(100, k_tnf=4, k_abd=21, table=table, window=1, vsize=6)
+    assert list(got["names"]) == names
+    assert np.array_equal(got["tnf"], tnf) and np.array_equal(got["abd"], abd)

@@ -1,0 +1,94 @@
+"""The reference-facing interfaces on the GPU: ``Feature`` (src/feature.py) and the two CLI tools."""
+import argparse
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from .conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(tmp_path, **kw):
+    d = dict(reads1="", reads2="", interleaved_reads="", output=str(tmp_path / "out"), min_length=2000, kmer=15,
+             tnf_kmer=4, window_size=10, vector_size=400, threads=4)
+    d.update(kw)
+    os.makedirs(d["output"], exist_ok=True)
+    return argparse.Namespace(**d)
+
+
+def test_feature_matches_reference_flow(tmp_path):
+    """names / abundance / tnf equal what the reference's Feature returns: pandas' reading of the CSVs written by its
+    binaries (goldens), and the cache files are in place for -st 2,3,4 resumes"""
+    from pangaea_amd.feature import Feature
+    args = _args(tmp_path, interleaved_reads=os.path.join(GOLDEN, "tenx_clean.fq.gz"))
+    feat = Feature(args, ROOT)
+    names, abd, tnf = feat.extract_features()
+    ref_t = pd.read_csv(os.path.join(GOLDEN, "tenx_clean.tnf.k4.l2000.csv"), header=None)
+    ref_a = pd.read_csv(os.path.join(GOLDEN, "tenx_clean.abd.k15.w10.v400.l2000.csv"), header=None)
+    assert (names == ref_t[0].to_numpy()).all() and names.dtype == ref_t[0].to_numpy().dtype
+    assert np.array_equal(tnf, ref_t.drop(columns=0).to_numpy()) and tnf.dtype == np.int64
+    assert np.array_equal(abd, ref_a.drop(columns=0).to_numpy()) and abd.dtype == np.int64
+    fdir = os.path.join(args.output, "1.features")
+    for fn in ("tnf.m2000.gz", "tnf.m2000.pkl", "abundance.k15.v400.w10.m2000.gz", "abundance.k15.v400.w10.m2000.pkl", "feature_finished"):
+        assert os.path.isfile(os.path.join(fdir, fn)), fn
+    with gzip.open(os.path.join(fdir, "tnf.m2000.gz"), "rb") as f, open(os.path.join(GOLDEN, "tenx_clean.tnf.k4.l2000.csv"), "rb") as g:
+        assert f.read() == g.read()
+    # resume: a new object loads the caches without touching the reads
+    args2 = _args(tmp_path, interleaved_reads="/nonexistent.fq")
+    n2, a2, t2 = Feature(args2, ROOT).load_features()
+    assert (n2 == names).all() and np.array_equal(a2, abd) and np.array_equal(t2, tnf)
+    n3, a3, t3 = Feature(args2, ROOT).extract_features()
+    assert (n3 == names).all() and np.array_equal(a3, abd) and np.array_equal(t3, tnf)
+
+
+def test_feature_paired_inputs_and_exponent_counts(tmp_path):
+    from pangaea_amd.feature import Feature
+    args = _args(tmp_path, reads1=os.path.join(GOLDEN, "pair_R1.fq"), reads2=os.path.join(GOLDEN, "pair_R2.fq"),
+                 min_length=100, kmer=15, window_size=1, vector_size=6)
+    names, abd, tnf = Feature(args, ROOT).extract_features()
+    ref_t = pd.read_csv(os.path.join(GOLDEN, "pair.tnf.k4.l100.csv"), header=None)
+    ref_a = pd.read_csv(os.path.join(GOLDEN, "pair.abd.k15.w1.v6.l100.csv"), header=None)
+    assert (names == ref_t[0].to_numpy()).all()
+    assert np.array_equal(tnf, ref_t.drop(columns=0).to_numpy()) and np.array_equal(abd, ref_a.drop(columns=0).to_numpy())
+    # counts >= 1e6 come back the way pandas reads "%g" text
+    args = _args(tmp_path / "p", interleaved_reads=os.path.join(GOLDEN, "polya.fq.gz"), min_length=1000)
+    os.makedirs(args.output, exist_ok=True)
+    names, abd, tnf = Feature(args, ROOT).extract_features()
+    ref_t = pd.read_csv(os.path.join(GOLDEN, "polya.tnf.k4.l1000.csv"), header=None)
+    assert tnf.dtype == np.float64 and np.array_equal(tnf, ref_t.drop(columns=0).to_numpy())
+
+
+def _run(tool, *argv):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "pangaea_amd", "bin", tool), *argv], capture_output=True, text=True)
+
+
+def test_cli_tools_write_the_reference_files(tmp_path):
+    out = str(tmp_path / "t.gz")
+    r = _run("count_tnf", "-i", os.path.join(GOLDEN, "stlfr.fq"), "-k", "4", "-l", "100", "-t", "3", "-o", out)
+    assert r.returncode == 0, r.stderr
+    with gzip.open(out, "rb") as f, open(os.path.join(GOLDEN, "stlfr.tnf.k4.l100.csv"), "rb") as g:
+        assert f.read() == g.read()
+    # count_kmer with an existing (holed) dump: reference loader semantics
+    out = str(tmp_path / "a.gz")
+    r = _run("count_kmer", "-i", os.path.join(GOLDEN, "tenx_mixed.fq"), "-g", os.path.join(GOLDEN, "tenx_mixed.k21.holes.dump"),
+             "-k", "21", "-w", "10", "-v", "400", "-l", "0", "-o", out)
+    assert r.returncode == 0, r.stderr
+    with gzip.open(out, "rb") as f, open(os.path.join(GOLDEN, "tenx_mixed.abd.k21.w10.v400.l0.holes.csv"), "rb") as g:
+        assert f.read() == g.read()
+    # without a dump file the multiplicities are counted on the GPU (what jellyfish would have dumped)
+    out = str(tmp_path / "b.gz")
+    r = _run("count_kmer", "-1", os.path.join(GOLDEN, "pair_R1.fq"), "-2", os.path.join(GOLDEN, "pair_R2.fq"),
+             "-g", str(tmp_path / "absent.dump"), "-k", "15", "-w", "1", "-v", "6", "-l", "100", "-o", out)
+    assert r.returncode == 0, r.stderr
+    with gzip.open(out, "rb") as f, open(os.path.join(GOLDEN, "pair.abd.k15.w1.v6.l100.csv"), "rb") as g:
+        assert f.read() == g.read()
+    # bad usage exits 1 like cmdline.h
+    assert _run("count_tnf", "-i", "x.fq").returncode == 1
+    assert _run("count_kmer", "-i", "x.fq", "-o", out).returncode == 1
+    assert _run("count_tnf", "-1", "only_one.fq", "-o", out).returncode == 1
