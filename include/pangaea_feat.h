@@ -108,7 +108,11 @@ int pg_tnf_colmap(int k, uint16_t *colmap /* [4^k] host */, uint32_t *col_code /
  *   PG_TABLE_HASH   k <= 21: uint64_t slots[2^log2_slots], open addressing, linear probing;
  *                   slot = (canonical code << 22) | count, 0 = empty.  The count field stops
  *                   growing at PG_HASH_COUNT_SAT (2^21), far above any vector_size*window, so every
- *                   histogram bin is exact.
+ *                   histogram bin is exact.  A key's home slot is the top log2_slots bits of
+ *                   murmur3's 64-bit finaliser of its code.  With log2_bucket_slots = b > 0 the table
+ *                   is split into buckets of 2^b consecutive slots and probing wraps inside the
+ *                   bucket (b = 0: one bucket = the whole table); pg_kmer_count_bucketed needs
+ *                   b <= PG_BUCKET_MAX_LOG2_SLOTS so that one bucket fits in LDS.
  * Tables must be zero-filled by the caller before the first count; counting accumulates, so a stream
  * may be counted in pieces (and tables of several GPUs can be summed).
  * ---------------------------------------------------------------------------------------------- */
@@ -117,12 +121,14 @@ enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2 };
 #define PG_HASH_MAX_K 21
 #define PG_HASH_COUNT_BITS 22
 #define PG_HASH_COUNT_SAT (1u << 21)
+#define PG_BUCKET_MAX_LOG2_SLOTS 14   /* 2^14 slots x 8 B = 128 KiB of the CU's 160 KiB LDS */
+#define PG_BUCKET_MAX_LOG2_BUCKETS 15
 
 typedef struct {
     int32_t kind;       /* PG_TABLE_DENSE or PG_TABLE_HASH */
     int32_t k;
-    int32_t log2_slots; /* hash only */
-    int32_t reserved;
+    int32_t log2_slots;        /* hash only */
+    int32_t log2_bucket_slots; /* hash only; 0 = unbucketed */
     void *data;         /* device: uint32_t[4^k] or uint64_t[2^log2_slots] */
 } pg_table;
 
@@ -131,6 +137,19 @@ typedef struct {
  * (check after synchronising: PG_ETABLEFULL condition), [1] unused.  May be NULL for dense tables. */
 int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
                   const pg_table *t, uint32_t *status, void *stream);
+
+/* The same result as pg_kmer_count for a bucketed hash table, without random HBM traffic: the k-mer
+ * occurrences of the word range are hash-partitioned into the table's buckets by two streaming scatter
+ * passes, each bucket is counted inside LDS by one workgroup and written back as its slice of the table.
+ *   accumulate = 0: the table is taken to be empty and every slice is overwritten (no clearing needed);
+ *   accumulate = 1: slices are loaded first, so counts add to what the table holds.
+ * workspace: device scratch of pg_kmer_count_workspace_bytes(word_end - word_begin, t) bytes, 256-B aligned
+ * (two record buffers of 8 B per character of the range + counters).  status as for pg_kmer_count:
+ * [0] != 0 after synchronising means a bucket overflowed (PG_ETABLEFULL condition). */
+int64_t pg_kmer_count_workspace_bytes(int64_t n_words, const pg_table *t);
+int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                           const pg_table *t, int accumulate, void *workspace, int64_t workspace_bytes,
+                           uint32_t *status, void *stream);
 
 /* Add n (code,count) pairs -- `pairs[i] = (code << 22) | count`, the slot format -- into a hash table:
  * the merge step after tables of other GPUs have been gathered. */

@@ -21,6 +21,7 @@ HASH_COUNT_BITS = 22
 HASH_COUNT_SAT = 1 << 21
 TNF_MAX_K = 6
 WORD_ALIGN = 256
+BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 15
 
 
 class PangaeaError(RuntimeError):
@@ -30,7 +31,7 @@ class PangaeaError(RuntimeError):
 
 
 class pg_table(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("log2_slots", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("log2_slots", C.c_int32), ("log2_bucket_slots", C.c_int32),
                 ("data", C.c_void_p)]
 
 
@@ -73,6 +74,8 @@ def load() -> C.CDLL:
         "pg_tnf_ncols": (i32, [i32]),
         "pg_tnf_colmap": (i32, [i32, vp, vp]),
         "pg_kmer_count": (i32, [vp, vp, i64, i64, tp, vp, vp]),
+        "pg_kmer_count_workspace_bytes": (i64, [i64, tp]),
+        "pg_kmer_count_bucketed": (i32, [vp, vp, i64, i64, tp, i32, vp, i64, vp, vp]),
         "pg_kmer_merge": (i32, [vp, i64, tp, vp, vp]),
         "pg_features": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp, vp, tp, i32, i32, vp, vp]),
         "pg_write_csv_gz": (i32, [cp, cp, vp, i64, i64]),
@@ -89,7 +92,8 @@ def load() -> C.CDLL:
 EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_reads_free", "pg_reads_n_chars",
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
            "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
-           "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_merge",
+           "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_count_workspace_bytes",
+           "pg_kmer_count_bucketed", "pg_kmer_merge",
            "pg_features", "pg_write_csv_gz"]
 
 

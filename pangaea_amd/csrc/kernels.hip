@@ -1,19 +1,26 @@
 // kernels.hip -- gfx950 kernels of the barcode k-mer feature path + their C-ABI launchers.
 //
 // Replaces (reference file:line, /root/reference/src):
-//   K2  pg_kmer_count   jellyfish count -C (feature.py:94) + dump reload (cpptools/count_kmer.cpp:139-170)
+//   K2  pg_kmer_count*  jellyfish count -C (feature.py:94) + dump reload (cpptools/count_kmer.cpp:139-170)
 //   K1  pg_features/tnf cpptools/count_tnf.cpp:78-113  (per-run canonical k_tnf-mer counts)
 //   K3  pg_features/abd cpptools/count_kmer.cpp:55-108 (per-run histogram of global multiplicities)
 //
-// Work decomposition (wave64, 256-thread workgroups):
+// Work decomposition (wave64):
 //   * the read stream is 2-bit codes + 1-bit validity, 32 characters per word (include/pangaea_feat.h);
 //     one lane owns one word per step, so a wave reads 512 B of codes + 256 B of validity, coalesced;
 //   * a lane rolls the forward and reverse-complement codes over its 32 characters after pre-rolling
 //     the k-1 characters before its word (taken from the previous word), so no cross-lane traffic;
 //   * which positions end a valid k-mer comes from one bit-parallel pass over the 64-bit validity
 //     window (runs of >= k ones), not from a per-character run counter;
-//   * integer counting only: LDS histograms per wavefront, global atomics into the count tables.
+//   * integer counting only: LDS histograms / LDS hash tables, global atomics only where unavoidable.
 //     No MFMA -- there is no contraction on this path.
+//
+// Two ways to build the hash table:
+//   direct    (kmer_count_kernel)   one random 64-B line + one memory-side atomic per k-mer occurrence;
+//   bucketed  (pg_kmer_count_bucketed) occurrences are hash-partitioned with two streaming scatter passes
+//             (<= 256-way then <= 512-way, LDS-staged so HBM sees whole runs), every final bucket is then
+//             counted inside LDS by one workgroup and its LDS image is written back as that bucket's slice
+//             of the table.  HBM only sees streaming traffic; all counting atomics are LDS atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,6 +37,24 @@ constexpr uint32_t HASH_SAT = PG_HASH_COUNT_SAT;
 constexpr uint32_t MAX_PROBE = 1u << 14;
 
 enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2 };
+
+// hash table as the kernels see it: 2^log2_slots slots in buckets of 2^log2_bucket slots; a key's home
+// slot is the top log2_slots bits of its hash, probing wraps inside the bucket
+struct HashView {
+    uint64_t *slots;
+    int log2_slots;
+    int log2_bucket;
+    __device__ __forceinline__ uint64_t home(uint64_t h) const { return h >> (64 - log2_slots); }
+    __device__ __forceinline__ uint64_t next(uint64_t s) const
+    {
+        const uint64_t bm = (1ull << log2_bucket) - 1;
+        return (s & ~bm) | ((s + 1) & bm);
+    }
+    __device__ __forceinline__ uint32_t probe_limit() const
+    {
+        return log2_bucket < 14 ? (1u << log2_bucket) : MAX_PROBE;
+    }
+};
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -55,53 +80,84 @@ template <typename KT> __device__ __forceinline__ KT low_mask(int k)
     return (2 * k >= (int)(8 * sizeof(KT))) ? (KT)~(KT)0 : (KT)(((KT)1 << (2 * k)) - 1);
 }
 
+// One lane's walk over word w of the stream: calls f(canon) for every position of the word that ends a
+// valid k-mer (ascending position order).  Returns without calling when the word ends none.
+template <typename KT, typename F>
+__device__ __forceinline__ void for_each_kmer(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, int64_t w, int k, F &&f)
+{
+    const uint64_t cw = codes[w];
+    const uint32_t vw = valid[w];
+    const uint64_t pw = w > 0 ? codes[w - 1] : 0;
+    const uint32_t pv = w > 0 ? valid[w - 1] : 0;
+    const uint32_t ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
+    if (ok == 0) return;
+    const KT kmask = low_mask<KT>(k);
+    const int rc_shift = 2 * (k - 1);
+    KT fw = 0, rc = 0;
+    for (int i = 33 - k; i < 32; ++i) {                    // pre-roll the k-1 characters before the word
+        KT c = (KT)((pw >> (2 * i)) & 3);
+        fw = (KT)(fw << 2) | c;
+        rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        KT c = (KT)((cw >> (2 * j)) & 3);
+        fw = (KT)(fw << 2) | c;
+        rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
+        if ((ok >> j) & 1) {
+            KT fm = fw & kmask;
+            f(fm < rc ? fm : rc);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------- table access
 
 __device__ __forceinline__ void dense_add(uint32_t *table, uint32_t code) { atomicAdd(&table[code], 1u); }
 
 // slot = (code << 22) | count ; 0 = empty.  Keys never change once written, so a stale (cached)
 // read can only show "empty", and the compare-and-swap then returns the real occupant.
-__device__ __forceinline__ void hash_add_from(uint64_t *slots, uint64_t mask, uint64_t h, uint64_t cur, uint64_t code, uint32_t *status)
+__device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, uint32_t *status)
 {
-    const uint32_t limit = mask < MAX_PROBE ? (uint32_t)mask + 1u : MAX_PROBE;
+    const uint32_t limit = t.probe_limit();
     for (uint32_t probe = 0; probe < limit; ++probe) {
         if (cur == 0) {
-            cur = atomicCAS((unsigned long long *)&slots[h], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
+            cur = atomicCAS((unsigned long long *)&t.slots[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
             if (cur == 0) return;
         }
         if ((cur >> HASH_CBITS) == code) {
             // stop growing at SAT; overshoot is bounded by the threads in flight (< 2^20 < 2^22 - SAT)
-            if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd((unsigned long long *)&slots[h], 1ull);
+            if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd((unsigned long long *)&t.slots[s], 1ull);
             return;
         }
-        h = (h + 1) & mask;
-        cur = slots[h];
+        s = t.next(s);
+        cur = t.slots[s];
     }
     atomicOr(status, 1u);
 }
 
-__device__ __forceinline__ uint32_t hash_probe(const uint64_t *slots, uint64_t mask, uint64_t h, uint64_t cur, uint64_t code, bool *found)
+__device__ __forceinline__ uint32_t hash_probe(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, bool *found)
 {
-    for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
+    const uint32_t limit = t.probe_limit();
+    for (uint32_t probe = 0; probe < limit; ++probe) {
         if (cur == 0) break;
         if ((cur >> HASH_CBITS) == code) { *found = true; return (uint32_t)(cur & HASH_CMASK); }
-        h = (h + 1) & mask;
-        cur = slots[h];
+        s = t.next(s);
+        cur = t.slots[s];
     }
     *found = false;
     return 0;
 }
 
-// -------------------------------------------------------------------------------- K2: global counts
+// -------------------------------------------------------------------------------- K2 direct: global counts
 
 template <typename KT, int TK>
 __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                           int64_t word_begin, int64_t word_end, int k, void *table,
-                                                           int log2_slots, uint32_t *status)
+                                                           int64_t word_begin, int64_t word_end, int k, uint32_t *dense,
+                                                           HashView t, uint32_t *status)
 {
     const KT kmask = low_mask<KT>(k);
     const int rc_shift = 2 * (k - 1);
-    const uint64_t smask = TK == TK_HASH ? (1ull << log2_slots) - 1 : 0;
     for (int64_t w = word_begin + (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * BLOCK) {
         const uint64_t cw = codes[w];
         const uint32_t vw = valid[w];
@@ -110,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
         const uint32_t ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
         if (ok == 0) continue;
         KT fw = 0, rc = 0;
-        for (int i = 33 - k; i < 32; ++i) {                // pre-roll the k-1 characters before the word
+        for (int i = 33 - k; i < 32; ++i) {
             KT c = (KT)((pw >> (2 * i)) & 3);
             fw = (KT)(fw << 2) | c;
             rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
@@ -126,54 +182,227 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
                 KT c = (KT)((cw >> (2 * j)) & 3);
                 fw = (KT)(fw << 2) | c;
                 rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
-                KT f = fw & kmask;
-                canon[u] = f < rc ? f : rc;
+                KT fm = fw & kmask;
+                canon[u] = fm < rc ? fm : rc;
                 if ((ok >> j) & 1) {
                     if (TK == TK_DENSE) {
-                        dense_add((uint32_t *)table, (uint32_t)canon[u]);
+                        dense_add(dense, (uint32_t)canon[u]);
                     } else {                       // issue the first probe of the whole batch before resolving any
-                        hh[u] = mix64((uint64_t)canon[u]) >> (64 - log2_slots);
-                        cur[u] = ((const uint64_t *)table)[hh[u]];
+                        hh[u] = t.home(mix64((uint64_t)canon[u]));
+                        cur[u] = t.slots[hh[u]];
                     }
                 }
             }
             if (TK == TK_HASH) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if ((ok >> (b * 8 + u)) & 1) hash_add_from((uint64_t *)table, smask, hh[u], cur[u], (uint64_t)canon[u], status);
+                    if ((ok >> (b * 8 + u)) & 1) hash_add_from(t, hh[u], cur[u], (uint64_t)canon[u], status);
             }
         }
     }
 }
 
 // merge (code,count) pairs of another table; counts saturate at SAT exactly (CAS loop; not a hot path)
-__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, uint64_t *slots,
-                                                           int log2_slots, uint32_t *status)
+__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, HashView t, uint32_t *status)
 {
-    const uint64_t mask = (1ull << log2_slots) - 1;
+    const uint32_t limit = t.probe_limit();
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         const uint64_t p = pairs[i];
         if (p == 0) continue;
         const uint64_t code = p >> HASH_CBITS;
         uint32_t add = (uint32_t)(p & HASH_CMASK);
         if (add > HASH_SAT) add = HASH_SAT;
-        uint64_t h = mix64(code) >> (64 - log2_slots);
+        uint64_t s = t.home(mix64(code));
         bool done = false;
-        for (uint32_t probe = 0; probe < MAX_PROBE && !done; ++probe) {
-            uint64_t cur = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t probe = 0; probe < limit && !done; ++probe) {
+            uint64_t cur = __hip_atomic_load(&t.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {
                 if (cur != 0 && (cur >> HASH_CBITS) != code) break;          // occupied by another key
                 uint32_t have = (uint32_t)(cur & HASH_CMASK);
                 uint32_t sum = have + add > HASH_SAT ? HASH_SAT : have + add;
                 uint64_t want = (code << HASH_CBITS) | sum;
-                uint64_t old = atomicCAS((unsigned long long *)&slots[h], (unsigned long long)cur, (unsigned long long)want);
+                uint64_t old = atomicCAS((unsigned long long *)&t.slots[s], (unsigned long long)cur, (unsigned long long)want);
                 if (old == cur) { done = true; break; }
                 cur = old;
             }
-            h = (h + 1) & mask;
+            s = t.next(s);
         }
         if (!done) atomicOr(status, 1u);
     }
+}
+
+// -------------------------------------------------------------------------------- K2 bucketed: partition + LDS counting
+
+constexpr int HIST_BLOCK = 1024;
+constexpr int TILE = 8192;            // records staged per scatter tile: 256 lanes x 32 characters
+constexpr int MAX_FAN_BITS = 9;       // <= 512-way scatter per pass
+constexpr uint64_t REC_KEY_MASK = (1ull << 42) - 1;
+
+// A0: histogram of final bucket ids (top `bits` bits of the hash) over every valid k-mer of the word range
+__global__ __launch_bounds__(HIST_BLOCK) void bucket_hist_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                                 int64_t word_begin, int64_t word_end, int k, int bits,
+                                                                 unsigned long long *__restrict__ hist)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int n_bins = 1 << bits;
+    for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK) lds[i] = 0;
+    __syncthreads();
+    const int sh = 64 - bits;
+    for (int64_t w = word_begin + (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * HIST_BLOCK)
+        for_each_kmer<uint64_t>(codes, valid, w, k, [&](uint64_t canon) { atomicAdd(&lds[mix64(canon) >> sh], 1u); });
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK)
+        if (lds[i]) atomicAdd(&hist[i], (unsigned long long)lds[i]);
+}
+
+// exclusive prefix sum of hist[n] -> off[n+1] (one workgroup; n <= 2^17)
+__global__ __launch_bounds__(HIST_BLOCK) void bucket_scan_kernel(const unsigned long long *__restrict__ hist, int n, unsigned long long *__restrict__ off)
+{
+    __shared__ unsigned long long part[HIST_BLOCK];
+    const int per = (n + HIST_BLOCK - 1) / HIST_BLOCK;
+    const int a = threadIdx.x * per, b = min(n, a + per);
+    unsigned long long s = 0;
+    for (int i = a; i < b; ++i) s += hist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < HIST_BLOCK; ++i) { unsigned long long v = part[i]; part[i] = run; run += v; }
+        off[n] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int i = a; i < b; ++i) { off[i] = run; run += hist[i]; }
+}
+
+// A1 / A2: one scatter pass.  SRC 0 reads k-mers from the stream (tile = 256 words), SRC 1 reads records of the
+// region blockIdx.y of a previous pass.  Records are split by digit = (hash >> shift) & (2^bits - 1): counted and
+// bucket-sorted inside LDS, then every digit's run is appended to its destination region (one global cursor add
+// per digit and tile), so HBM receives contiguous runs instead of single records.
+//   destination of digit d: out[off[base_index + (d << base_shift)] + cursor[base_index' + d] ...]
+template <int SRC>
+__global__ __launch_bounds__(BLOCK) void scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                        int64_t word_begin, int64_t word_end, int k,
+                                                        const uint64_t *__restrict__ rec_in, int in_region_shift,
+                                                        uint64_t *__restrict__ rec_out, const unsigned long long *__restrict__ off,
+                                                        unsigned long long *__restrict__ cursor, int shift, int bits, int base_shift)
+{
+    __shared__ uint64_t buf[TILE];
+    __shared__ uint32_t cnt[1 << MAX_FAN_BITS];
+    __shared__ uint32_t start[(1 << MAX_FAN_BITS) + 1];
+    __shared__ uint32_t fill[1 << MAX_FAN_BITS];
+    __shared__ unsigned long long gbase[1 << MAX_FAN_BITS];
+    __shared__ uint32_t wave_tot[WAVES];
+    const int n_dig = 1 << bits;
+    const uint64_t dmask = (uint64_t)n_dig - 1;
+    const int region = SRC == 1 ? blockIdx.y : 0;
+    const int64_t base_index = SRC == 1 ? ((int64_t)region << bits) : 0;      // first destination bucket of this region
+    int64_t r0 = 0, r1 = 0;
+    if (SRC == 1) {
+        r0 = (int64_t)off[(int64_t)region << in_region_shift];
+        r1 = (int64_t)off[((int64_t)region + 1) << in_region_shift];
+    }
+    const int64_t n_tiles = SRC == 0 ? (word_end - word_begin + BLOCK - 1) / BLOCK : (r1 - r0 + TILE - 1) / TILE;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < n_dig; i += BLOCK) cnt[i] = 0;
+        __syncthreads();
+        // ---- phase 1: digit histogram of the tile
+        const int64_t w = word_begin + tile * BLOCK + threadIdx.x;
+        const int64_t t0 = r0 + tile * TILE;
+        const int64_t t1 = t0 + TILE < r1 ? t0 + TILE : r1;
+        if (SRC == 0) {
+            if (w < word_end)
+                for_each_kmer<uint64_t>(codes, valid, w, k, [&](uint64_t canon) { atomicAdd(&cnt[(mix64(canon) >> shift) & dmask], 1u); });
+        } else {
+            for (int64_t i = t0 + threadIdx.x; i < t1; i += BLOCK)
+                atomicAdd(&cnt[(mix64(rec_in[i] & REC_KEY_MASK) >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        // ---- exclusive scan of cnt -> start (n_dig <= 512: two entries per lane)
+        {
+            const int i0 = 2 * threadIdx.x, i1 = i0 + 1;
+            uint32_t a = i0 < n_dig ? cnt[i0] : 0, b = i1 < n_dig ? cnt[i1] : 0;
+            uint32_t v = a + b, incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t o = __shfl_up(incl, d);
+                if ((threadIdx.x & 63) >= d) incl += o;
+            }
+            if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += wave_tot[wv];
+            const uint32_t excl = before + incl - v;
+            if (i0 < n_dig) { start[i0] = excl; fill[i0] = excl; }
+            if (i1 < n_dig) { start[i1] = excl + a; fill[i1] = excl + a; }
+            if (threadIdx.x == BLOCK - 1) start[n_dig] = before + incl;
+        }
+        __syncthreads();
+        // ---- reserve the destination runs (one cursor add per non-empty digit)
+        for (int d = threadIdx.x; d < n_dig; d += BLOCK)
+            if (cnt[d]) gbase[d] = off[base_index + ((int64_t)d << base_shift)] + atomicAdd(&cursor[base_index + d], (unsigned long long)cnt[d]);
+        // ---- phase 2: place the records bucket-sorted in LDS
+        if (SRC == 0) {
+            if (w < word_end)
+                for_each_kmer<uint64_t>(codes, valid, w, k, [&](uint64_t canon) {
+                    buf[atomicAdd(&fill[(mix64(canon) >> shift) & dmask], 1u)] = canon;
+                });
+        } else {
+            for (int64_t i = t0 + threadIdx.x; i < t1; i += BLOCK) {
+                const uint64_t r = rec_in[i];
+                buf[atomicAdd(&fill[(mix64(r & REC_KEY_MASK) >> shift) & dmask], 1u)] = r;
+            }
+        }
+        __syncthreads();
+        // ---- copy out: consecutive LDS entries of one digit go to consecutive addresses
+        const uint32_t total = start[n_dig];
+        for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {
+            const uint64_t r = buf[i];
+            const uint32_t d = (uint32_t)((mix64(r & REC_KEY_MASK) >> shift) & dmask);
+            rec_out[gbase[d] + (i - start[d])] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// B: one workgroup per final bucket.  The bucket's slice of the table (2^log2_bucket slots) lives in LDS while the
+// bucket's records stream through; the LDS image is then written back as the slice.
+__global__ __launch_bounds__(HIST_BLOCK) void bucket_count_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                  HashView t, int accumulate, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    const uint32_t smask = n_slots - 1;
+    uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    if (r0 == r1 && accumulate) return;                         // nothing to add, slice stays as it is
+    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) tab[i] = accumulate ? slice[i] : 0ull;
+    __syncthreads();
+    const int hsh = 64 - t.log2_slots;
+    bool full = false;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += HIST_BLOCK) {
+        const uint64_t code = rec[i] & REC_KEY_MASK;
+        uint32_t s = (uint32_t)(mix64(code) >> hsh) & smask;
+        bool done = false;
+        for (uint32_t probe = 0; probe < n_slots; ++probe) {
+            unsigned long long cur = tab[s];
+            if (cur == 0) {
+                cur = atomicCAS(&tab[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
+                if (cur == 0) { done = true; break; }
+            }
+            if ((cur >> HASH_CBITS) == code) {
+                if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
+                done = true;
+                break;
+            }
+            s = (s + 1) & smask;
+        }
+        full |= !done;
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) slice[i] = tab[i];
 }
 
 // -------------------------------------------------------------------------------- K1 + K3: per-run rows
@@ -185,8 +414,8 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                                                          int64_t n_words, const int32_t *__restrict__ seg_row,
                                                          const int64_t *__restrict__ seg_start, const int64_t *__restrict__ seg_end,
                                                          int k_tnf, const uint16_t *__restrict__ colmap, int tnf_cols, int tnf_copies, int abd_copies,
-                                                         int32_t *__restrict__ tnf_out, int k, const void *__restrict__ table,
-                                                         int log2_slots, uint32_t window, int vsize, int32_t *__restrict__ abd_out)
+                                                         int32_t *__restrict__ tnf_out, int k, const uint32_t *__restrict__ dense, HashView t,
+                                                         uint32_t window, int vsize, int32_t *__restrict__ abd_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const bool do_tnf = tnf_out != nullptr;
@@ -208,7 +437,6 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
     const KT kmask = low_mask<KT>(do_abd ? k : 1);
     const int rc_shift = do_abd ? 2 * (k - 1) : 0;
     const uint32_t tmask = do_tnf ? (uint32_t)n_raw - 1u : 0u;
-    const uint64_t smask = TK == TK_HASH ? (1ull << log2_slots) - 1 : 0;
 
     for (int64_t w = (s0 >> 5) + threadIdx.x; w <= ((s1 - 1) >> 5) && w < n_words; w += BLOCK) {
         const uint64_t cw = codes[w];
@@ -245,15 +473,15 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                 if (do_abd) rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
                 if (do_tnf && ((ok_t >> j) & 1)) atomicAdd(&my_tnf[(uint32_t)fw & tmask], 1u);
                 if (TK != TK_NONE) {
-                    KT f = fw & kmask;
-                    canon[u] = f < rc ? f : rc;
+                    KT fm = fw & kmask;
+                    canon[u] = fm < rc ? fm : rc;
                     cur[u] = 0;
                     if ((ok_a >> j) & 1) {
                         if (TK == TK_DENSE) {
-                            cur[u] = ((const uint32_t *)table)[(uint32_t)canon[u]];
+                            cur[u] = dense[(uint32_t)canon[u]];
                         } else {
-                            hh[u] = mix64((uint64_t)canon[u]) >> (64 - log2_slots);
-                            cur[u] = ((const uint64_t *)table)[hh[u]];
+                            hh[u] = t.home(mix64((uint64_t)canon[u]));
+                            cur[u] = t.slots[hh[u]];
                         }
                     }
                 }
@@ -269,7 +497,7 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                             cnt = (uint32_t)cur[u];
                             found = cnt != 0;       // absent from the table <=> never counted
                         } else {
-                            cnt = hash_probe((const uint64_t *)table, smask, hh[u], cur[u], (uint64_t)canon[u], &found);
+                            cnt = hash_probe(t, hh[u], cur[u], (uint64_t)canon[u], &found);
                         }
                         if (found) {
                             uint32_t bin = cnt / window;
@@ -299,6 +527,8 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
     }
 }
 
+// -------------------------------------------------------------------------------- launch helpers
+
 int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -306,9 +536,9 @@ int check_launch(const char *what)
     return PG_OK;
 }
 
-int grid_for(int64_t items)
+int grid_for(int64_t items, int block = BLOCK)
 {
-    int64_t blocks = (items + BLOCK - 1) / BLOCK;
+    int64_t blocks = (items + block - 1) / block;
     const int64_t cap = 256 * 16;     // 256 CUs x 16 resident workgroups' worth, grid-stride beyond
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -323,9 +553,53 @@ int check_table(const pg_table *t)
     } else if (t->kind == PG_TABLE_HASH) {
         if (t->k < 1 || t->k > PG_HASH_MAX_K) return pg_fail(PG_EINVAL, "hash table needs 1 <= k <= %d (got %d)", PG_HASH_MAX_K, t->k);
         if (t->log2_slots < 10 || t->log2_slots > 40) return pg_fail(PG_EINVAL, "log2_slots %d out of range [10,40]", t->log2_slots);
+        if (t->log2_bucket_slots != 0 && (t->log2_bucket_slots < 4 || t->log2_bucket_slots > t->log2_slots))
+            return pg_fail(PG_EINVAL, "log2_bucket_slots %d out of range [4,%d]", t->log2_bucket_slots, t->log2_slots);
     } else {
         return pg_fail(PG_EINVAL, "unknown table kind %d", t->kind);
     }
+    return PG_OK;
+}
+
+HashView view_of(const pg_table *t)
+{
+    HashView v;
+    v.slots = (uint64_t *)t->data;
+    v.log2_slots = t->log2_slots;
+    v.log2_bucket = t->log2_bucket_slots ? t->log2_bucket_slots : t->log2_slots;
+    return v;
+}
+
+// workspace carving of the bucketed counter
+struct BucketPlan {
+    int bits, bits1, bits2;           // bucket id bits, split over the two scatter passes
+    int64_t cap;                      // record capacity of each of the two record buffers
+    size_t hist_off, off_off, cur1_off, cur2_off, bufa_off, bufb_off, total;
+};
+
+int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
+{
+    if (t->kind != PG_TABLE_HASH || t->log2_bucket_slots == 0)
+        return pg_fail(PG_EINVAL, "bucketed counting needs a hash table with log2_bucket_slots set");
+    if (t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS)
+        return pg_fail(PG_EINVAL, "log2_bucket_slots %d exceeds the LDS-resident maximum %d", t->log2_bucket_slots, PG_BUCKET_MAX_LOG2_SLOTS);
+    p->bits = t->log2_slots - t->log2_bucket_slots;
+    if (p->bits < 1 || p->bits > PG_BUCKET_MAX_LOG2_BUCKETS)
+        return pg_fail(PG_EINVAL, "bucketed counting needs 1 <= log2_slots - log2_bucket_slots <= %d (got %d)", PG_BUCKET_MAX_LOG2_BUCKETS, p->bits);
+    p->bits1 = p->bits < 8 ? p->bits : 8;
+    p->bits2 = p->bits - p->bits1;
+    if (p->bits2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many buckets for two scatter passes");
+    p->cap = n_words * 32;
+    const size_t nb = (size_t)1 << p->bits;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    p->hist_off = take(nb * 8);
+    p->off_off = take((nb + 1) * 8);
+    p->cur1_off = take(((size_t)1 << p->bits1) * 8);
+    p->cur2_off = take(nb * 8);
+    p->bufa_off = take((size_t)p->cap * 8);
+    p->bufb_off = p->bits2 ? take((size_t)p->cap * 8) : p->bufa_off;
+    p->total = o;
     return PG_OK;
 }
 
@@ -350,13 +624,87 @@ extern "C" int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64
     if (word_end == word_begin) return PG_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = grid_for(word_end - word_begin);
-    if (t->kind == PG_TABLE_DENSE)
+    if (t->kind == PG_TABLE_DENSE) {
+        HashView none{nullptr, 0, 0};
         hipLaunchKernelGGL((kmer_count_kernel<uint32_t, TK_DENSE>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end,
-                           t->k, t->data, 0, status);
-    else
+                           t->k, (uint32_t *)t->data, none, status);
+    } else {
         hipLaunchKernelGGL((kmer_count_kernel<uint64_t, TK_HASH>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end,
-                           t->k, t->data, t->log2_slots, status);
+                           t->k, (uint32_t *)nullptr, view_of(t), status);
+    }
     return check_launch("pg_kmer_count");
+}
+
+extern "C" int64_t pg_kmer_count_workspace_bytes(int64_t n_words, const pg_table *t)
+{
+    if (n_words < 0) return pg_fail(PG_EINVAL, "negative word count");
+    int rc = check_table(t);
+    if (rc) return rc;
+    BucketPlan p;
+    rc = plan_buckets(t, n_words, &p);
+    if (rc) return rc;
+    return (int64_t)p.total;
+}
+
+extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                                      const pg_table *t, int accumulate, void *workspace, int64_t workspace_bytes,
+                                      uint32_t *status, void *stream)
+{
+    if (!codes || !valid || !workspace || !status) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: null argument");
+    if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: bad word range");
+    int rc = check_table(t);
+    if (rc) return rc;
+    BucketPlan p;
+    rc = plan_buckets(t, word_end - word_begin, &p);
+    if (rc) return rc;
+    if ((int64_t)p.total > workspace_bytes)
+        return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)p.total);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: workspace must be 256-byte aligned");
+    if (word_end == word_begin) return PG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    auto *hist = (unsigned long long *)(ws + p.hist_off);
+    auto *off = (unsigned long long *)(ws + p.off_off);
+    auto *cur1 = (unsigned long long *)(ws + p.cur1_off);
+    auto *cur2 = (unsigned long long *)(ws + p.cur2_off);
+    auto *bufa = (uint64_t *)(ws + p.bufa_off);
+    auto *bufb = (uint64_t *)(ws + p.bufb_off);
+    const int nb = 1 << p.bits;
+    // counters are contiguous at the front of the workspace: one clear
+    if (hipMemsetAsync(ws, 0, p.bufa_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_kmer_count_bucketed: memset failed");
+    const int64_t n_words = word_end - word_begin;
+
+    // both LDS-heavy kernels may need more than the default 64 KiB of dynamic LDS
+    if (((size_t)nb * 4 > 64 * 1024 || ((size_t)8 << t->log2_bucket_slots) > 64 * 1024)) {
+        if (hipFuncSetAttribute((const void *)bucket_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)bucket_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return pg_fail(PG_EHIP, "pg_kmer_count_bucketed: cannot raise the dynamic LDS limit");
+    }
+    // A0 histogram of final bucket ids, then offsets
+    {
+        int grid = (int)((n_words + HIST_BLOCK - 1) / HIST_BLOCK);
+        if (grid > 512) grid = 512;
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(HIST_BLOCK), (size_t)nb * 4, s, codes, valid, word_begin, word_end, t->k, p.bits, hist);
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(HIST_BLOCK), 0, s, hist, nb, off);
+    }
+    // A1: stream -> 2^bits1 regions (region d1 = final buckets [d1 << bits2, (d1+1) << bits2))
+    {
+        int64_t tiles = (n_words + BLOCK - 1) / BLOCK;
+        int grid = (int)(tiles > 8192 ? 8192 : tiles);
+        hipLaunchKernelGGL((scatter_kernel<0>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k,
+                           (const uint64_t *)nullptr, 0, bufa, off, cur1, 64 - p.bits1, p.bits1, p.bits2);
+    }
+    // A2: every region -> its 2^bits2 final buckets
+    if (p.bits2) {
+        hipLaunchKernelGGL((scatter_kernel<1>), dim3(64, 1 << p.bits1), dim3(BLOCK), 0, s, (const uint64_t *)nullptr, (const uint32_t *)nullptr,
+                           (int64_t)0, (int64_t)0, t->k, bufa, p.bits2, bufb, off, cur2, 64 - p.bits, p.bits2, 0);
+    }
+    // B: count every bucket inside LDS and write its slice of the table
+    {
+        const size_t lds = (size_t)8 << t->log2_bucket_slots;
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(HIST_BLOCK), lds, s, p.bits2 ? bufb : bufa, off, view_of(t), accumulate ? 1 : 0, status);
+    }
+    return check_launch("pg_kmer_count_bucketed");
 }
 
 extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t, uint32_t *status, void *stream)
@@ -366,8 +714,7 @@ extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t
     if (t->kind != PG_TABLE_HASH) return pg_fail(PG_EINVAL, "pg_kmer_merge: hash tables only (dense tables are summed with an all-reduce)");
     if (n < 0 || (n > 0 && !pairs) || !status) return pg_fail(PG_EINVAL, "pg_kmer_merge: bad arguments");
     if (n == 0) return PG_OK;
-    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, (uint64_t *)t->data,
-                       t->log2_slots, status);
+    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, view_of(t), status);
     return check_launch("pg_kmer_merge");
 }
 
@@ -390,8 +737,9 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
         n_raw = 1 << (2 * k_tnf);
         tnf_copies = k_tnf <= 4 ? WAVES : 1;
     }
-    int kind = TK_NONE, k = 0, log2_slots = 0;
-    const void *data = nullptr;
+    int kind = TK_NONE, k = 0;
+    HashView view{nullptr, 0, 0};
+    const uint32_t *dense = nullptr;
     if (do_abd) {
         int rc = check_table(t);
         if (rc) return rc;
@@ -400,7 +748,9 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
             return pg_fail(PG_EINVAL, "pg_features: window*vector_size %lld exceeds the exact range of the hash table (%u)",
                            (long long)window * vsize, PG_HASH_COUNT_SAT);
         kind = t->kind == PG_TABLE_DENSE ? TK_DENSE : TK_HASH;
-        k = t->k; log2_slots = t->log2_slots; data = t->data;
+        k = t->k;
+        if (kind == TK_DENSE) dense = (const uint32_t *)t->data;
+        else view = view_of(t);
     }
     if (n_segs == 0) return PG_OK;
     const int abd_copies = do_abd ? (vsize <= 1024 ? WAVES : 1) : 0;
@@ -409,7 +759,7 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
     dim3 grid((unsigned)n_segs), block(BLOCK);
 #define PG_LAUNCH(KT, TK)                                                                                                   \
     hipLaunchKernelGGL((features_kernel<KT, TK>), grid, block, lds_bytes, s, codes, valid, n_words, seg_row, seg_start, seg_end, \
-                       k_tnf, colmap, tnf_cols, tnf_copies, abd_copies, tnf_out, k, data, log2_slots, (uint32_t)window, vsize, abd_out)
+                       k_tnf, colmap, tnf_cols, tnf_copies, abd_copies, tnf_out, k, dense, view, (uint32_t)window, vsize, abd_out)
     if (kind == TK_NONE) PG_LAUNCH(uint32_t, TK_NONE);
     else if (kind == TK_DENSE) PG_LAUNCH(uint32_t, TK_DENSE);
     else PG_LAUNCH(uint64_t, TK_HASH);

@@ -32,14 +32,20 @@ class KmerTable:
     """exact multiplicity of every canonical k-mer over every read of the input.
 
     ``dense``: int32 tensor of 4^k counters (k <= 16).  ``hash``: int64 tensor of 2^log2_slots slots,
-    slot = (code << 22) | count, 0 = empty (k <= 21).
+    slot = (code << 22) | count, 0 = empty (k <= 21), optionally split into buckets of 2^log2_bucket slots
+    (probing wraps inside a bucket); bucketed tables are built by the partition + LDS-count pipeline
+    (``pg_kmer_count_bucketed``), unbucketed ones by one global atomic per occurrence (``pg_kmer_count``).
     """
 
-    def __init__(self, k: int, kind: str, data: torch.Tensor, log2_slots: int = 0):
-        self.k, self.kind, self.data, self.log2_slots = int(k), kind, data, int(log2_slots)
+    WORKSPACE_BUDGET = 96 << 30          # bytes of scratch one bucketed launch may use; longer streams go in pieces
+
+    def __init__(self, k: int, kind: str, data: torch.Tensor, log2_slots: int = 0, log2_bucket: int = 0):
+        self.k, self.kind, self.data, self.log2_slots, self.log2_bucket = int(k), kind, data, int(log2_slots), int(log2_bucket)
         self.status = torch.zeros(2, dtype=torch.int32, device=data.device)
-        self._desc = _lib.pg_table(_lib.TABLE_DENSE if kind == "dense" else _lib.TABLE_HASH, self.k, self.log2_slots, 0,
-                                   data.data_ptr())
+        self._desc = _lib.pg_table(_lib.TABLE_DENSE if kind == "dense" else _lib.TABLE_HASH, self.k, self.log2_slots,
+                                   self.log2_bucket, data.data_ptr())
+        self._empty = True               # nothing counted since allocation / reset()
+        self._workspace = None
 
     # ------------------------------------------------------------------ construction
 
@@ -49,9 +55,18 @@ class KmerTable:
             raise ValueError(f"k-mer size {k} unsupported on the GPU path (1..{_lib.HASH_MAX_K})")
         return "dense" if k <= 15 else "hash"
 
+    @staticmethod
+    def default_log2_bucket(log2_slots: int) -> int:
+        """bucket size for a table of 2^log2_slots slots, 0 when the table cannot be bucketed: buckets hold at most
+        2^14 slots (LDS) and there are at most 2^15 of them (two scatter passes)"""
+        if log2_slots < 14:
+            return 0                                       # small tables: the direct kernel is as good
+        lb = min(_lib.BUCKET_MAX_LOG2_SLOTS, max(10, log2_slots - 12))
+        return lb if 1 <= log2_slots - lb <= _lib.BUCKET_MAX_LOG2_BUCKETS else 0
+
     @classmethod
     def alloc(cls, k: int, device, kind: str | None = None, distinct_hint: int | None = None,
-              load: float = 0.5) -> "KmerTable":
+              load: float = 0.5, log2_bucket: int | None = None) -> "KmerTable":
         kind = kind or cls.default_kind(k)
         device = torch.device(device)
         if kind == "dense":
@@ -64,7 +79,12 @@ class KmerTable:
             raise ValueError(f"hash tables need k <= {_lib.HASH_MAX_K}")
         want = max(1024, int((distinct_hint or 1 << 20) / load))
         log2 = max(10, math.ceil(math.log2(want)))
-        return cls(k, "hash", torch.zeros(1 << log2, dtype=torch.int64, device=device), log2)
+        return cls.with_slots(k, device, log2, log2_bucket)
+
+    @classmethod
+    def with_slots(cls, k: int, device, log2_slots: int, log2_bucket: int | None = None) -> "KmerTable":
+        lb = cls.default_log2_bucket(log2_slots) if log2_bucket is None else log2_bucket
+        return cls(k, "hash", torch.zeros(1 << log2_slots, dtype=torch.int64, device=device), log2_slots, lb)
 
     @classmethod
     def from_items(cls, k: int, codes, counts, device, kind: str | None = None) -> "KmerTable":
@@ -93,15 +113,43 @@ class KmerTable:
 
     # ------------------------------------------------------------------ counting
 
+    def reset(self) -> "KmerTable":
+        """forget every count.  Bucketed tables are not even cleared: the next count overwrites every slice."""
+        if not (self.kind == "hash" and self.log2_bucket):
+            self.data.zero_()
+        self.status.zero_()
+        self._empty = True
+        return self
+
+    def _workspace_for(self, n_words: int) -> torch.Tensor:
+        need = _lib.check(_lib.load().pg_kmer_count_workspace_bytes(n_words, self.desc()))
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
     def count(self, stream: ReadStream, word_begin: int = 0, word_end: int | None = None, check: bool = True) -> "KmerTable":
         """add the k-mers ending in words [word_begin, word_end) of the stream (asynchronous unless ``check``)"""
         _require_gpu(stream.codes, "the read stream")
         if stream.device != self.device:
             raise ValueError("stream and table are on different devices")
         word_end = stream.n_words if word_end is None else word_end
+        L = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().pg_kmer_count(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end,
-                                                 self.desc(), self.status.data_ptr(), _stream_ptr(self.device)))
+            if self.kind == "hash" and self.log2_bucket:
+                # pieces bounded by the scratch budget: two record buffers of 8 B per character
+                step = max(_lib.WORD_ALIGN, int(self.WORKSPACE_BUDGET // (2 * 8 * 32)) // _lib.WORD_ALIGN * _lib.WORD_ALIGN)
+                for w0 in range(word_begin, word_end, step):
+                    w1 = min(word_end, w0 + step)
+                    ws = self._workspace_for(w1 - w0)
+                    _lib.check(L.pg_kmer_count_bucketed(stream.codes.data_ptr(), stream.valid.data_ptr(), w0, w1, self.desc(),
+                                                        0 if self._empty else 1, ws.data_ptr(), ws.numel(),
+                                                        self.status.data_ptr(), _stream_ptr(self.device)))
+                    self._empty = False
+            else:
+                _lib.check(L.pg_kmer_count(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end,
+                                           self.desc(), self.status.data_ptr(), _stream_ptr(self.device)))
+                self._empty = False
         if check:
             self.check_status()
         return self
@@ -115,6 +163,9 @@ class KmerTable:
         if self.kind != "hash":
             raise ValueError("merge() is for hash tables; dense tables are summed with all_reduce")
         pairs = pairs.to(self.device, torch.int64).contiguous()
+        if self._empty and self.kind == "hash" and self.log2_bucket:
+            self.data.zero_()            # a reset() bucketed table is only logically empty
+        self._empty = False
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().pg_kmer_merge(pairs.data_ptr(), pairs.numel(), self.desc(), self.status.data_ptr(),
                                                  _stream_ptr(self.device)))
@@ -146,9 +197,10 @@ class KmerTable:
 
 
 def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hint: int | None = None,
-                max_log2_slots: int = 36) -> KmerTable:
+                max_log2_slots: int = 36, log2_bucket: int | None = None) -> KmerTable:
     """build the table of one stream; a full hash table is re-built with four times the slots"""
-    table = KmerTable.alloc(k, stream.device, kind, distinct_hint if distinct_hint else max(1 << 16, stream.n_chars // 8))
+    table = KmerTable.alloc(k, stream.device, kind, distinct_hint if distinct_hint else max(1 << 16, stream.n_chars // 8),
+                            log2_bucket=log2_bucket)
     while True:
         try:
             return table.count(stream)
@@ -156,8 +208,11 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
             if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
                 raise
             log2 = min(max_log2_slots, table.log2_slots + 2)
+            lb = None if log2_bucket is None else min(log2_bucket + 2, _lib.BUCKET_MAX_LOG2_SLOTS)
+            if lb is not None and log2 - lb > _lib.BUCKET_MAX_LOG2_BUCKETS:
+                lb = 0
             del table
-            table = KmerTable(k, "hash", torch.zeros(1 << log2, dtype=torch.int64, device=stream.device), log2)
+            table = KmerTable.with_slots(k, stream.device, log2, lb)
 
 
 # ---------------------------------------------------------------------------------------- TNF columns

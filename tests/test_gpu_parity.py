@@ -153,6 +153,45 @@ def test_counting_in_pieces_accumulates():
             assert np.array_equal(c1, c2) and np.array_equal(2 * n1, n2)
 
 
+@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 14), (18, 10), (19, 7), (20, 5), (20, 6), (18, 0)])
+def test_bucketed_counter_equals_direct_counter(log2_slots, log2_bucket):
+    """partition + LDS counting (one or two scatter passes, 2^4..2^15 buckets) builds the same multiset as one global
+    atomic per occurrence, fresh and accumulating, and the lookups see the same counts"""
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=20, n_genomes=3, genome_len=20_000, fragment=8_000, n_rate=0.05, seed=31)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    want = oracle.Table(21, threads=4).count(s.decode())
+    wc, wn = want.items()
+    t = kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket)
+    assert t.log2_bucket == log2_bucket
+    t.count(s)
+    gc, gn = t.items()
+    assert np.array_equal(gc, wc) and np.array_equal(gn, wn)
+    _, abd = kmer.features(s, rows, k_tnf=None, table=t, window=2, vsize=50)
+    _, _, oabd = _oracle_rows(s, rows, None, 21, 2, 50)
+    assert np.array_equal(abd.cpu().numpy(), oabd)
+    # accumulate: the same stream again in three pieces doubles every count; reset() forgets everything
+    a, b = s.n_words // 4 + 3, s.n_words // 2 + 11
+    t.count(s, 0, a).count(s, a, b).count(s, b, s.n_words)
+    gc, gn = t.items()
+    assert np.array_equal(gc, wc) and np.array_equal(gn, 2 * wn)
+    t.reset().count(s)
+    gc, gn = t.items()
+    assert np.array_equal(gc, wc) and np.array_equal(gn, wn)
+
+
+def test_bucket_overflow_is_reported():
+    cfg = synth.SynthConfig(n_pairs=4000, n_barcodes=16, n_genomes=2, genome_len=300_000, fragment=60_000, seed=77)
+    s = synth.generate(cfg, device=DEV)
+    t = kmer.KmerTable.with_slots(21, DEV, 14, 6)          # 16 k slots for ~1 M distinct 21-mers
+    with pytest.raises(_lib.PangaeaError) as e:
+        t.count(s)
+    assert e.value.code == _lib.PG_ETABLEFULL
+    grown = kmer.count_kmers(s, 21, kind="hash", distinct_hint=4096, log2_bucket=6)
+    want = oracle.Table(21, threads=4).count(s.decode())
+    assert all(np.array_equal(x, y) for x, y in zip(grown.items(), want.items()))
+
+
 def test_hash_table_full_is_reported_and_regrown():
     cfg = synth.SynthConfig(n_pairs=2048, n_barcodes=8, n_genomes=2, genome_len=200_000, fragment=50_000, seed=9)
     s = synth.generate(cfg, device=DEV)
