@@ -35,26 +35,14 @@ constexpr uint32_t HASH_CBITS = PG_HASH_COUNT_BITS;
 constexpr uint64_t HASH_CMASK = (1ull << HASH_CBITS) - 1;
 constexpr uint32_t HASH_SAT = PG_HASH_COUNT_SAT;
 constexpr uint32_t MAX_PROBE = 1u << 14;
+constexpr uint32_t PRIMARY_PROBES = 32;   // slots tried from the minimizer home before the k-mer's own hash takes over
+constexpr int MINI_W = 7;                 // m-mers per k-mer in the minimizer window: w = min(7, k), m = k - w + 1
+#ifndef PG_PLACEMENT_MINIMIZER
+#define PG_PLACEMENT_MINIMIZER 0
+#endif
+constexpr bool MINIMIZER = PG_PLACEMENT_MINIMIZER != 0;   // 0: home = uniform hash of the k-mer (no locality)
 
 enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2 };
-
-// hash table as the kernels see it: 2^log2_slots slots in buckets of 2^log2_bucket slots; a key's home
-// slot is the top log2_slots bits of its hash, probing wraps inside the bucket
-struct HashView {
-    uint64_t *slots;
-    int log2_slots;
-    int log2_bucket;
-    __device__ __forceinline__ uint64_t home(uint64_t h) const { return h >> (64 - log2_slots); }
-    __device__ __forceinline__ uint64_t next(uint64_t s) const
-    {
-        const uint64_t bm = (1ull << log2_bucket) - 1;
-        return (s & ~bm) | ((s + 1) & bm);
-    }
-    __device__ __forceinline__ uint32_t probe_limit() const
-    {
-        return log2_bucket < 14 ? (1u << log2_bucket) : MAX_PROBE;
-    }
-};
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -63,6 +51,48 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     x ^= x >> 33;
     return x;
 }
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x85ebca6bu;
+    x ^= x >> 13; x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
+}
+
+// Home slot (log2_slots bits) of a k-mer.  MINIMIZER placement: the 64-B line (8 slots) is chosen by the k-mer's
+// minimizer, the slot inside the line by the k-mer's own code, so the ~w consecutive k-mers of a read that share a
+// minimizer sit in ONE line and mostly in different slots of it.
+__device__ __forceinline__ uint64_t home_slot(uint32_t min_order, uint64_t code, int log2_slots)
+{
+    if (MINIMIZER)
+        return ((((uint64_t)min_order * 0x9E3779B97F4A7C15ull) >> (64 - log2_slots)) & ~7ull) | ((code * 0x9E3779B97F4A7C15ull) >> 61);
+    return mix64(code) >> (64 - log2_slots);
+}
+
+// Hash table as the kernels see it: 2^log2_slots slots in buckets of 2^log2_bucket slots.
+// PLACEMENT (shared by every kernel, the LDS tables included):
+//   home   = home_slot(min over the k-mer's w canonical m-mers of mix32(m-mer), code): line by minimizer, slot in
+//            the line by the code.  Consecutive k-mers of a read mostly share their minimizer, hence their line:
+//            a lookup stream walks the table supermer by supermer instead of touching one random line per k-mer.
+//   probe  = PRIMARY_PROBES consecutive slots from home (wrapping inside the bucket), then consecutive slots from
+//            (mix64(code) mod bucket) in the same bucket: crowded minimizers spill to uniformly hashed places.
+//   Slots are never freed, so a lookup may stop at the first empty slot of the sequence.
+struct HashView {
+    uint64_t *slots;
+    int log2_slots;
+    int log2_bucket;
+    __device__ __forceinline__ uint64_t bmask() const { return (1ull << log2_bucket) - 1; }
+    __device__ __forceinline__ uint32_t primary() const { return log2_bucket < 5 ? (1u << log2_bucket) : PRIMARY_PROBES; }
+    __device__ __forceinline__ uint32_t limit() const { return primary() + (log2_bucket < 14 ? (1u << log2_bucket) : MAX_PROBE); }
+    // slot after `s`, `i` = number of slots already tried (i >= 1)
+    __device__ __forceinline__ uint64_t next(uint64_t s, uint32_t i, uint64_t code) const
+    {
+        const uint64_t bm = bmask();
+        const uint64_t in = i == primary() ? (mix64(code) & bm) : ((s + 1) & bm);
+        return (s & ~bm) | in;
+    }
+};
 
 // bit p of the result is set iff bits p-k+1..p of m are all set (1 <= k <= 32): which positions of the
 // 64-character window [previous word | this word] end a run of >= k valid characters.
@@ -80,35 +110,71 @@ template <typename KT> __device__ __forceinline__ KT low_mask(int k)
     return (2 * k >= (int)(8 * sizeof(KT))) ? (KT)~(KT)0 : (KT)(((KT)1 << (2 * k)) - 1);
 }
 
-// One lane's walk over word w of the stream: calls f(canon) for every position of the word that ends a
-// valid k-mer (ascending position order).  Returns without calling when the word ends none.
-template <typename KT, typename F>
-__device__ __forceinline__ void for_each_kmer(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, int64_t w, int k, F &&f)
-{
-    const uint64_t cw = codes[w];
-    const uint32_t vw = valid[w];
-    const uint64_t pw = w > 0 ? codes[w - 1] : 0;
-    const uint32_t pv = w > 0 ? valid[w - 1] : 0;
-    const uint32_t ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
-    if (ok == 0) return;
-    const KT kmask = low_mask<KT>(k);
-    const int rc_shift = 2 * (k - 1);
-    KT fw = 0, rc = 0;
-    for (int i = 33 - k; i < 32; ++i) {                    // pre-roll the k-1 characters before the word
-        KT c = (KT)((pw >> (2 * i)) & 3);
-        fw = (KT)(fw << 2) | c;
-        rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
+// Rolling state of one lane: forward / reverse-complement code of the last k characters and, when MINI, the
+// order values of the last w canonical m-mers (a shift register: no dynamic register indexing).
+template <typename KT, bool MINI> struct Roller {
+    KT fw, rc, kmask;
+    uint32_t mmask, o0, o1, o2, o3, o4, o5, o6;
+    int rc_shift, rcm_shift, w;
+
+    __device__ __forceinline__ void init(int k)
+    {
+        fw = rc = 0;
+        kmask = low_mask<KT>(k);
+        rc_shift = 2 * (k - 1);
+        w = k < MINI_W ? k : MINI_W;
+        const int m = k - w + 1;
+        mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+        rcm_shift = 2 * (k - m);
+        o0 = o1 = o2 = o3 = o4 = o5 = o6 = 0xffffffffu;
     }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        KT c = (KT)((cw >> (2 * j)) & 3);
-        fw = (KT)(fw << 2) | c;
-        rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
-        if ((ok >> j) & 1) {
-            KT fm = fw & kmask;
-            f(fm < rc ? fm : rc);
+    __device__ __forceinline__ void push(uint32_t c)
+    {
+        fw = (KT)(fw << 2) | (KT)c;
+        rc = (KT)(rc >> 2) | (KT)((KT)(c ^ 2u) << rc_shift);
+        if (MINI) {
+            const uint32_t a = (uint32_t)fw & mmask;
+            const uint32_t b = (uint32_t)(rc >> rcm_shift);
+            o6 = o5; o5 = o4; o4 = o3; o3 = o2; o2 = o1; o1 = o0;
+            o0 = mix32(a < b ? a : b);
         }
     }
+    __device__ __forceinline__ KT canon() const
+    {
+        const KT f = fw & kmask;
+        return f < rc ? f : rc;
+    }
+    __device__ __forceinline__ uint64_t slot(int log2_slots) const { return home_slot(min_order(), (uint64_t)canon(), log2_slots); }
+    __device__ __forceinline__ uint32_t min_order() const
+    {
+        if (!MINI) return 0;
+        uint32_t mn = o0;
+        if (w > 1) mn = min(mn, o1);
+        if (w > 2) mn = min(mn, o2);
+        if (w > 3) mn = min(mn, o3);
+        if (w > 4) mn = min(mn, o4);
+        if (w > 5) mn = min(mn, o5);
+        if (w > 6) mn = min(mn, o6);
+        return mn;
+    }
+};
+
+// the same home slot from a canonical code alone (merge path; not hot)
+__device__ uint64_t slot_of_code(uint64_t code, int k, int log2_slots)
+{
+    if (!MINIMIZER) return home_slot(0, code, log2_slots);
+    const int w = k < MINI_W ? k : MINI_W;
+    const int m = k - w + 1;
+    const uint32_t mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+    uint64_t rck = 0, x = code;
+    for (int i = 0; i < k; ++i) { rck = (rck << 2) | ((x & 3) ^ 2); x >>= 2; }
+    uint32_t mn = 0xffffffffu;
+    for (int i = 0; i < w; ++i) {
+        const uint32_t a = (uint32_t)(code >> (2 * (w - 1 - i))) & mmask;
+        const uint32_t b = (uint32_t)(rck >> (2 * i)) & mmask;
+        mn = min(mn, mix32(a < b ? a : b));
+    }
+    return home_slot(mn, code, log2_slots);
 }
 
 // -------------------------------------------------------------------------------- table access
@@ -119,8 +185,8 @@ __device__ __forceinline__ void dense_add(uint32_t *table, uint32_t code) { atom
 // read can only show "empty", and the compare-and-swap then returns the real occupant.
 __device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, uint32_t *status)
 {
-    const uint32_t limit = t.probe_limit();
-    for (uint32_t probe = 0; probe < limit; ++probe) {
+    const uint32_t limit = t.limit();
+    for (uint32_t i = 1; i <= limit; ++i) {
         if (cur == 0) {
             cur = atomicCAS((unsigned long long *)&t.slots[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
             if (cur == 0) return;
@@ -130,7 +196,7 @@ __device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uin
             if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd((unsigned long long *)&t.slots[s], 1ull);
             return;
         }
-        s = t.next(s);
+        s = t.next(s, i, code);
         cur = t.slots[s];
     }
     atomicOr(status, 1u);
@@ -138,11 +204,11 @@ __device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uin
 
 __device__ __forceinline__ uint32_t hash_probe(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, bool *found)
 {
-    const uint32_t limit = t.probe_limit();
-    for (uint32_t probe = 0; probe < limit; ++probe) {
+    const uint32_t limit = t.limit();
+    for (uint32_t i = 1; i <= limit; ++i) {
         if (cur == 0) break;
         if ((cur >> HASH_CBITS) == code) { *found = true; return (uint32_t)(cur & HASH_CMASK); }
-        s = t.next(s);
+        s = t.next(s, i, code);
         cur = t.slots[s];
     }
     *found = false;
@@ -156,8 +222,6 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
                                                            int64_t word_begin, int64_t word_end, int k, uint32_t *dense,
                                                            HashView t, uint32_t *status)
 {
-    const KT kmask = low_mask<KT>(k);
-    const int rc_shift = 2 * (k - 1);
     for (int64_t w = word_begin + (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * BLOCK) {
         const uint64_t cw = codes[w];
         const uint32_t vw = valid[w];
@@ -165,12 +229,9 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
         const uint32_t pv = w > 0 ? valid[w - 1] : 0;
         const uint32_t ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
         if (ok == 0) continue;
-        KT fw = 0, rc = 0;
-        for (int i = 33 - k; i < 32; ++i) {
-            KT c = (KT)((pw >> (2 * i)) & 3);
-            fw = (KT)(fw << 2) | c;
-            rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
-        }
+        Roller<KT, TK == TK_HASH && MINIMIZER> r;
+        r.init(k);
+        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             KT canon[8];
@@ -179,16 +240,13 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = b * 8 + u;
-                KT c = (KT)((cw >> (2 * j)) & 3);
-                fw = (KT)(fw << 2) | c;
-                rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
-                KT fm = fw & kmask;
-                canon[u] = fm < rc ? fm : rc;
+                r.push((uint32_t)(cw >> (2 * j)) & 3u);
+                canon[u] = r.canon();
                 if ((ok >> j) & 1) {
                     if (TK == TK_DENSE) {
                         dense_add(dense, (uint32_t)canon[u]);
                     } else {                       // issue the first probe of the whole batch before resolving any
-                        hh[u] = t.home(mix64((uint64_t)canon[u]));
+                        hh[u] = r.slot(t.log2_slots);
                         cur[u] = t.slots[hh[u]];
                     }
                 }
@@ -203,18 +261,18 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
 }
 
 // merge (code,count) pairs of another table; counts saturate at SAT exactly (CAS loop; not a hot path)
-__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, HashView t, uint32_t *status)
+__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, int k, HashView t, uint32_t *status)
 {
-    const uint32_t limit = t.probe_limit();
+    const uint32_t limit = t.limit();
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         const uint64_t p = pairs[i];
         if (p == 0) continue;
         const uint64_t code = p >> HASH_CBITS;
         uint32_t add = (uint32_t)(p & HASH_CMASK);
         if (add > HASH_SAT) add = HASH_SAT;
-        uint64_t s = t.home(mix64(code));
+        uint64_t s = slot_of_code(code, k, t.log2_slots);
         bool done = false;
-        for (uint32_t probe = 0; probe < limit && !done; ++probe) {
+        for (uint32_t tries = 1; tries <= limit && !done; ++tries) {
             uint64_t cur = __hip_atomic_load(&t.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {
                 if (cur != 0 && (cur >> HASH_CBITS) != code) break;          // occupied by another key
@@ -225,31 +283,51 @@ __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__res
                 if (old == cur) { done = true; break; }
                 cur = old;
             }
-            s = t.next(s);
+            s = t.next(s, tries, code);
         }
         if (!done) atomicOr(status, 1u);
     }
 }
 
 // -------------------------------------------------------------------------------- K2 bucketed: partition + LDS counting
+//
+// record = canonical code (42 bits) | hfield << 42, hfield = the placement-hash bits that are still needed after the
+// first scatter pass: the (log2_slots - bits1) bits below the level-1 digit, i.e. [level-2 digit | slot in bucket].
+// The scatter-2 and bucket-count kernels therefore never hash: they read their digit / slot out of the record.
 
 constexpr int HIST_BLOCK = 1024;
-constexpr int TILE = 8192;            // records staged per scatter tile: 256 lanes x 32 characters
+constexpr int TILE0 = 8192;           // records per stream tile: 256 lanes x 32 characters
+constexpr int REC_PER_LANE = 16;      // scatter pass 2: records a lane keeps in registers
+constexpr int TILE1 = BLOCK * REC_PER_LANE;
 constexpr int MAX_FAN_BITS = 9;       // <= 512-way scatter per pass
-constexpr uint64_t REC_KEY_MASK = (1ull << 42) - 1;
+constexpr int REC_KEY_BITS = 42;
+constexpr uint64_t REC_KEY_MASK = (1ull << REC_KEY_BITS) - 1;
 
-// A0: histogram of final bucket ids (top `bits` bits of the hash) over every valid k-mer of the word range
+// A0: histogram of final bucket ids (top `bits` bits of the placement hash) over every valid k-mer of the word range
 __global__ __launch_bounds__(HIST_BLOCK) void bucket_hist_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                                 int64_t word_begin, int64_t word_end, int k, int bits,
+                                                                 int64_t word_begin, int64_t word_end, int k, int log2_slots, int bits,
                                                                  unsigned long long *__restrict__ hist)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int n_bins = 1 << bits;
     for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK) lds[i] = 0;
     __syncthreads();
-    const int sh = 64 - bits;
-    for (int64_t w = word_begin + (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * HIST_BLOCK)
-        for_each_kmer<uint64_t>(codes, valid, w, k, [&](uint64_t canon) { atomicAdd(&lds[mix64(canon) >> sh], 1u); });
+    for (int64_t w = word_begin + (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * HIST_BLOCK) {
+        const uint64_t cw = codes[w];
+        const uint32_t vw = valid[w];
+        const uint64_t pw = w > 0 ? codes[w - 1] : 0;
+        const uint32_t pv = w > 0 ? valid[w - 1] : 0;
+        const uint32_t ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
+        if (ok == 0) continue;
+        Roller<uint64_t, MINIMIZER> r;
+        r.init(k);
+        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            r.push((uint32_t)(cw >> (2 * j)) & 3u);
+            if ((ok >> j) & 1) atomicAdd(&lds[r.slot(log2_slots) >> (log2_slots - bits)], 1u);
+        }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK)
         if (lds[i]) atomicAdd(&hist[i], (unsigned long long)lds[i]);
@@ -275,130 +353,206 @@ __global__ __launch_bounds__(HIST_BLOCK) void bucket_scan_kernel(const unsigned 
     for (int i = a; i < b; ++i) { off[i] = run; run += hist[i]; }
 }
 
-// A1 / A2: one scatter pass.  SRC 0 reads k-mers from the stream (tile = 256 words), SRC 1 reads records of the
-// region blockIdx.y of a previous pass.  Records are split by digit = (hash >> shift) & (2^bits - 1): counted and
-// bucket-sorted inside LDS, then every digit's run is appended to its destination region (one global cursor add
-// per digit and tile), so HBM receives contiguous runs instead of single records.
-//   destination of digit d: out[off[base_index + (d << base_shift)] + cursor[base_index' + d] ...]
-template <int SRC>
-__global__ __launch_bounds__(BLOCK) void scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                        int64_t word_begin, int64_t word_end, int k,
-                                                        const uint64_t *__restrict__ rec_in, int in_region_shift,
-                                                        uint64_t *__restrict__ rec_out, const unsigned long long *__restrict__ off,
-                                                        unsigned long long *__restrict__ cursor, int shift, int bits, int base_shift)
-{
-    __shared__ uint64_t buf[TILE];
-    __shared__ uint32_t cnt[1 << MAX_FAN_BITS];
-    __shared__ uint32_t start[(1 << MAX_FAN_BITS) + 1];
-    __shared__ uint32_t fill[1 << MAX_FAN_BITS];
-    __shared__ unsigned long long gbase[1 << MAX_FAN_BITS];
-    __shared__ uint32_t wave_tot[WAVES];
-    const int n_dig = 1 << bits;
-    const uint64_t dmask = (uint64_t)n_dig - 1;
-    const int region = SRC == 1 ? blockIdx.y : 0;
-    const int64_t base_index = SRC == 1 ? ((int64_t)region << bits) : 0;      // first destination bucket of this region
-    int64_t r0 = 0, r1 = 0;
-    if (SRC == 1) {
-        r0 = (int64_t)off[(int64_t)region << in_region_shift];
-        r1 = (int64_t)off[((int64_t)region + 1) << in_region_shift];
-    }
-    const int64_t n_tiles = SRC == 0 ? (word_end - word_begin + BLOCK - 1) / BLOCK : (r1 - r0 + TILE - 1) / TILE;
+// LDS bookkeeping shared by both scatter passes
+struct ScatterLds {
+    uint32_t cnt[1 << MAX_FAN_BITS];
+    uint32_t start[(1 << MAX_FAN_BITS) + 1];
+    unsigned long long gbase[1 << MAX_FAN_BITS];
+    uint32_t wave_tot[WAVES];
+};
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        for (int i = threadIdx.x; i < n_dig; i += BLOCK) cnt[i] = 0;
-        __syncthreads();
-        // ---- phase 1: digit histogram of the tile
-        const int64_t w = word_begin + tile * BLOCK + threadIdx.x;
-        const int64_t t0 = r0 + tile * TILE;
-        const int64_t t1 = t0 + TILE < r1 ? t0 + TILE : r1;
-        if (SRC == 0) {
-            if (w < word_end)
-                for_each_kmer<uint64_t>(codes, valid, w, k, [&](uint64_t canon) { atomicAdd(&cnt[(mix64(canon) >> shift) & dmask], 1u); });
-        } else {
-            for (int64_t i = t0 + threadIdx.x; i < t1; i += BLOCK)
-                atomicAdd(&cnt[(mix64(rec_in[i] & REC_KEY_MASK) >> shift) & dmask], 1u);
-        }
-        __syncthreads();
-        // ---- exclusive scan of cnt -> start (n_dig <= 512: two entries per lane)
-        {
-            const int i0 = 2 * threadIdx.x, i1 = i0 + 1;
-            uint32_t a = i0 < n_dig ? cnt[i0] : 0, b = i1 < n_dig ? cnt[i1] : 0;
-            uint32_t v = a + b, incl = v;
+// exclusive scan of L.cnt[0..n_dig) into L.start[0..n_dig] (n_dig <= 512: two entries per lane); all lanes call
+__device__ __forceinline__ void scatter_scan(ScatterLds &L, int n_dig)
+{
+    const int i0 = 2 * threadIdx.x, i1 = i0 + 1;
+    const uint32_t a = i0 < n_dig ? L.cnt[i0] : 0, b = i1 < n_dig ? L.cnt[i1] : 0;
+    const uint32_t v = a + b;
+    uint32_t incl = v;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t o = __shfl_up(incl, d);
-                if ((threadIdx.x & 63) >= d) incl += o;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) L.wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += L.wave_tot[wv];
+    const uint32_t excl = before + incl - v;
+    if (i0 < n_dig) L.start[i0] = excl;
+    if (i1 < n_dig) L.start[i1] = excl + a;
+    if (threadIdx.x == BLOCK - 1) L.start[n_dig] = before + incl;
+    __syncthreads();
+}
+
+// A1: stream -> 2^bits1 regions.  A lane keeps the <= 32 records of its word in registers; one returning LDS atomic
+// per record yields its rank inside its digit, the tile is then laid out digit-sorted in LDS and every digit's run
+// is appended to its region with one global cursor add, so HBM receives contiguous runs.
+__global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                               int64_t word_begin, int64_t word_end, int k, int log2_slots, int bits1,
+                                                               uint64_t *__restrict__ rec_out, const unsigned long long *__restrict__ off,
+                                                               unsigned long long *__restrict__ cursor, int off_shift)
+{
+    __shared__ uint64_t buf[TILE0];
+    __shared__ ScatterLds L;
+    const int n_dig = 1 << bits1;
+    const int low_bits = log2_slots - bits1;                        // hfield width
+    const uint64_t low_mask64 = (1ull << low_bits) - 1;
+    const int64_t n_tiles = (word_end - word_begin + BLOCK - 1) / BLOCK;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt[i] = 0;
+        __syncthreads();
+        uint64_t rec[32];
+        uint32_t dr[32];                                            // digit << 16 | rank inside the digit
+        uint32_t ok = 0;
+        const int64_t w = word_begin + tile * BLOCK + threadIdx.x;
+        if (w < word_end) {
+            const uint64_t cw = codes[w];
+            const uint32_t vw = valid[w];
+            const uint64_t pw = w > 0 ? codes[w - 1] : 0;
+            const uint32_t pv = w > 0 ? valid[w - 1] : 0;
+            ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
+            if (ok) {
+                Roller<uint64_t, MINIMIZER> r;
+                r.init(k);
+                for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    r.push((uint32_t)(cw >> (2 * j)) & 3u);
+                    if ((ok >> j) & 1) {
+                        const uint64_t g = r.slot(log2_slots);
+                        const uint32_t d = (uint32_t)(g >> low_bits);
+                        rec[j] = r.canon() | ((g & low_mask64) << REC_KEY_BITS);
+                        dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
+                    }
+                }
             }
-            if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
-            __syncthreads();
-            uint32_t before = 0;
-            for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += wave_tot[wv];
-            const uint32_t excl = before + incl - v;
-            if (i0 < n_dig) { start[i0] = excl; fill[i0] = excl; }
-            if (i1 < n_dig) { start[i1] = excl + a; fill[i1] = excl + a; }
-            if (threadIdx.x == BLOCK - 1) start[n_dig] = before + incl;
         }
         __syncthreads();
-        // ---- reserve the destination runs (one cursor add per non-empty digit)
+        scatter_scan(L, n_dig);
         for (int d = threadIdx.x; d < n_dig; d += BLOCK)
-            if (cnt[d]) gbase[d] = off[base_index + ((int64_t)d << base_shift)] + atomicAdd(&cursor[base_index + d], (unsigned long long)cnt[d]);
-        // ---- phase 2: place the records bucket-sorted in LDS
-        if (SRC == 0) {
-            if (w < word_end)
-                for_each_kmer<uint64_t>(codes, valid, w, k, [&](uint64_t canon) {
-                    buf[atomicAdd(&fill[(mix64(canon) >> shift) & dmask], 1u)] = canon;
-                });
-        } else {
-            for (int64_t i = t0 + threadIdx.x; i < t1; i += BLOCK) {
-                const uint64_t r = rec_in[i];
-                buf[atomicAdd(&fill[(mix64(r & REC_KEY_MASK) >> shift) & dmask], 1u)] = r;
-            }
-        }
+            if (L.cnt[d]) L.gbase[d] = off[(int64_t)d << off_shift] + atomicAdd(&cursor[d], (unsigned long long)L.cnt[d]);
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if ((ok >> j) & 1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
         __syncthreads();
-        // ---- copy out: consecutive LDS entries of one digit go to consecutive addresses
-        const uint32_t total = start[n_dig];
-        for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {
-            const uint64_t r = buf[i];
-            const uint32_t d = (uint32_t)((mix64(r & REC_KEY_MASK) >> shift) & dmask);
-            rec_out[gbase[d] + (i - start[d])] = r;
+        // copy out run by run (a wave per digit): lanes write consecutive records of one digit to consecutive addresses
+        for (int d = threadIdx.x >> 6; d < n_dig; d += WAVES) {
+            const uint32_t a0 = L.start[d], c = L.start[d + 1] - a0;
+            const unsigned long long g0 = L.gbase[d];
+            for (uint32_t i = threadIdx.x & 63; i < c; i += 64) rec_out[g0 + i] = buf[a0 + i];
         }
         __syncthreads();
     }
 }
 
+// A2: region blockIdx.y of pass 1 -> its 2^bits2 final buckets.  Digit = top bits2 of the record's hfield.
+__global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const uint64_t *__restrict__ rec_in, uint64_t *__restrict__ rec_out,
+                                                                const unsigned long long *__restrict__ off,
+                                                                unsigned long long *__restrict__ cursor, int bits2, int log2_bucket)
+{
+    __shared__ uint64_t buf[TILE1];
+    __shared__ ScatterLds L;
+    const int n_dig = 1 << bits2;
+    const int region = blockIdx.y;
+    const int64_t base_index = (int64_t)region << bits2;
+    const int64_t r0 = (int64_t)off[base_index], r1 = (int64_t)off[base_index + n_dig];
+    const int64_t n_tiles = (r1 - r0 + TILE1 - 1) / TILE1;
+    const int dshift = REC_KEY_BITS + log2_bucket;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt[i] = 0;
+        __syncthreads();
+        const int64_t t0 = r0 + tile * TILE1;
+        uint64_t rec[REC_PER_LANE];
+        uint32_t dr[REC_PER_LANE];
+#pragma unroll
+        for (int j = 0; j < REC_PER_LANE; ++j) {                    // all loads of the lane in flight together
+            const int64_t i = t0 + j * BLOCK + threadIdx.x;
+            rec[j] = i < r1 ? rec_in[i] : ~0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < REC_PER_LANE; ++j) {
+            const int64_t i = t0 + j * BLOCK + threadIdx.x;
+            if (i < r1) {
+                const uint32_t d = (uint32_t)(rec[j] >> dshift);
+                dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
+            }
+        }
+        __syncthreads();
+        scatter_scan(L, n_dig);
+        for (int d = threadIdx.x; d < n_dig; d += BLOCK)
+            if (L.cnt[d]) L.gbase[d] = off[base_index + d] + atomicAdd(&cursor[base_index + d], (unsigned long long)L.cnt[d]);
+#pragma unroll
+        for (int j = 0; j < REC_PER_LANE; ++j) {
+            const int64_t i = t0 + j * BLOCK + threadIdx.x;
+            if (i < r1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
+        }
+        __syncthreads();
+        const uint32_t total = L.start[n_dig];
+        for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {
+            const uint64_t r = buf[i];
+            const uint32_t d = (uint32_t)(r >> dshift);
+            rec_out[L.gbase[d] + (i - L.start[d])] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// insert one record into the LDS table, starting from an already fetched first slot; false = table full
+__device__ __forceinline__ bool lds_insert(unsigned long long *tab, uint32_t smask, uint32_t primary, uint32_t limit,
+                                           uint64_t rec, uint32_t s, unsigned long long cur)
+{
+    if (rec == ~0ull) return true;                                  // padding lane of the last batch
+    const uint64_t code = rec & REC_KEY_MASK;
+    for (uint32_t i = 1; i <= limit; ++i) {
+        if (cur == 0) {
+            cur = atomicCAS(&tab[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
+            if (cur == 0) return true;
+        }
+        if ((cur >> HASH_CBITS) == code) {
+            if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
+            return true;
+        }
+        s = i == primary ? (uint32_t)(mix64(code) & smask) : ((s + 1) & smask);
+        cur = tab[s];
+    }
+    return false;
+}
+
 // B: one workgroup per final bucket.  The bucket's slice of the table (2^log2_bucket slots) lives in LDS while the
-// bucket's records stream through; the LDS image is then written back as the slice.
+// bucket's records stream through (8 loads per lane in flight); the LDS image is then written back as the slice.
+constexpr int CNT_BATCH = 8;               // PG_RESOLVE below is written for exactly 8
 __global__ __launch_bounds__(HIST_BLOCK) void bucket_count_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
                                                                   HashView t, int accumulate, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
+    const uint32_t primary = t.primary(), limit = t.limit();
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
     if (r0 == r1 && accumulate) return;                         // nothing to add, slice stays as it is
     for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) tab[i] = accumulate ? slice[i] : 0ull;
     __syncthreads();
-    const int hsh = 64 - t.log2_slots;
     bool full = false;
-    for (int64_t i = r0 + threadIdx.x; i < r1; i += HIST_BLOCK) {
-        const uint64_t code = rec[i] & REC_KEY_MASK;
-        uint32_t s = (uint32_t)(mix64(code) >> hsh) & smask;
-        bool done = false;
-        for (uint32_t probe = 0; probe < n_slots; ++probe) {
-            unsigned long long cur = tab[s];
-            if (cur == 0) {
-                cur = atomicCAS(&tab[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
-                if (cur == 0) { done = true; break; }
-            }
-            if ((cur >> HASH_CBITS) == code) {
-                if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
-                done = true;
-                break;
-            }
-            s = (s + 1) & smask;
+    for (int64_t base = r0; base < r1; base += (int64_t)HIST_BLOCK * CNT_BATCH) {
+        uint64_t rr[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            const int64_t i = base + (int64_t)j * HIST_BLOCK + threadIdx.x;
+            rr[j] = i < r1 ? rec[i] : ~0ull;
         }
-        full |= !done;
+        uint32_t ss[CNT_BATCH];
+        unsigned long long first[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {                       // first probes of the batch issued back to back
+            ss[j] = (uint32_t)(rr[j] >> REC_KEY_BITS) & smask;
+            first[j] = rr[j] == ~0ull ? 0ull : tab[ss[j]];
+        }
+        // resolved one by one, written out by hand: an unrolled loop around the probe loop is not unrolled by hipcc and
+        // would push the batch arrays into scratch
+#define PG_RESOLVE(J) full |= !lds_insert(tab, smask, primary, limit, rr[J], ss[J], first[J]);
+        PG_RESOLVE(0) PG_RESOLVE(1) PG_RESOLVE(2) PG_RESOLVE(3) PG_RESOLVE(4) PG_RESOLVE(5) PG_RESOLVE(6) PG_RESOLVE(7)
+#undef PG_RESOLVE
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
@@ -433,9 +587,8 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
     uint32_t *my_tnf = tnf_lds + (tnf_copies > 1 ? wave * n_raw : 0);
 
     const int64_t s0 = seg_start[blockIdx.x], s1 = seg_end[blockIdx.x];
+    const int kk = do_abd ? k : k_tnf;                                       // what the roller rolls
     const int kroll = do_abd ? (k > k_tnf || !do_tnf ? k : k_tnf) : k_tnf;   // characters to pre-roll + 1
-    const KT kmask = low_mask<KT>(do_abd ? k : 1);
-    const int rc_shift = do_abd ? 2 * (k - 1) : 0;
     const uint32_t tmask = do_tnf ? (uint32_t)n_raw - 1u : 0u;
 
     for (int64_t w = (s0 >> 5) + threadIdx.x; w <= ((s1 - 1) >> 5) && w < n_words; w += BLOCK) {
@@ -453,12 +606,9 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
         const uint32_t ok_a = do_abd ? (uint32_t)(runs_of(m, k) >> 32) & in_seg : 0u;
         if ((ok_t | ok_a) == 0) continue;
 
-        KT fw = 0, rc = 0;
-        for (int i = 33 - kroll; i < 32; ++i) {
-            KT c = (KT)((pw >> (2 * i)) & 3);
-            fw = (KT)(fw << 2) | c;
-            rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
-        }
+        Roller<KT, TK == TK_HASH && MINIMIZER> r;
+        r.init(kk);
+        for (int i = 33 - kroll; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
         // batches of 8 characters: roll, issue the table reads of the batch, then bin them
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -468,20 +618,18 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = b * 8 + u;
-                KT c = (KT)((cw >> (2 * j)) & 3);
-                fw = (KT)(fw << 2) | c;
-                if (do_abd) rc = (KT)(rc >> 2) | (KT)((c ^ 2) << rc_shift);
-                if (do_tnf && ((ok_t >> j) & 1)) atomicAdd(&my_tnf[(uint32_t)fw & tmask], 1u);
+                r.push((uint32_t)(cw >> (2 * j)) & 3u);
+                if (do_tnf && ((ok_t >> j) & 1)) atomicAdd(&my_tnf[(uint32_t)r.fw & tmask], 1u);
                 if (TK != TK_NONE) {
-                    KT fm = fw & kmask;
-                    canon[u] = fm < rc ? fm : rc;
+                    canon[u] = r.canon();
                     cur[u] = 0;
                     if ((ok_a >> j) & 1) {
                         if (TK == TK_DENSE) {
                             cur[u] = dense[(uint32_t)canon[u]];
                         } else {
-                            hh[u] = t.home(mix64((uint64_t)canon[u]));
-                            cur[u] = t.slots[hh[u]];
+                            hh[u] = r.slot(t.log2_slots);
+                            // each table line is used once per launch: keep it out of the way of the stream (measured -2 %)
+                            cur[u] = __builtin_nontemporal_load(&t.slots[hh[u]]);
                         }
                     }
                 }
@@ -589,6 +737,8 @@ int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
     p->bits1 = p->bits < 8 ? p->bits : 8;
     p->bits2 = p->bits - p->bits1;
     if (p->bits2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many buckets for two scatter passes");
+    if (t->log2_slots - p->bits1 > 64 - REC_KEY_BITS)
+        return pg_fail(PG_EINVAL, "bucketed counting needs log2_slots <= %d (got %d)", 64 - REC_KEY_BITS + p->bits1, t->log2_slots);
     p->cap = n_words * 32;
     const size_t nb = (size_t)1 << p->bits;
     size_t o = 0;
@@ -684,21 +834,20 @@ extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *val
     {
         int grid = (int)((n_words + HIST_BLOCK - 1) / HIST_BLOCK);
         if (grid > 512) grid = 512;
-        hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(HIST_BLOCK), (size_t)nb * 4, s, codes, valid, word_begin, word_end, t->k, p.bits, hist);
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(HIST_BLOCK), (size_t)nb * 4, s, codes, valid, word_begin, word_end, t->k, t->log2_slots, p.bits, hist);
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(HIST_BLOCK), 0, s, hist, nb, off);
     }
     // A1: stream -> 2^bits1 regions (region d1 = final buckets [d1 << bits2, (d1+1) << bits2))
     {
         int64_t tiles = (n_words + BLOCK - 1) / BLOCK;
         int grid = (int)(tiles > 8192 ? 8192 : tiles);
-        hipLaunchKernelGGL((scatter_kernel<0>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k,
-                           (const uint64_t *)nullptr, 0, bufa, off, cur1, 64 - p.bits1, p.bits1, p.bits2);
+        hipLaunchKernelGGL(scatter_stream_kernel, dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k,
+                           t->log2_slots, p.bits1, bufa, off, cur1, p.bits2);
     }
     // A2: every region -> its 2^bits2 final buckets
-    if (p.bits2) {
-        hipLaunchKernelGGL((scatter_kernel<1>), dim3(64, 1 << p.bits1), dim3(BLOCK), 0, s, (const uint64_t *)nullptr, (const uint32_t *)nullptr,
-                           (int64_t)0, (int64_t)0, t->k, bufa, p.bits2, bufb, off, cur2, 64 - p.bits, p.bits2, 0);
-    }
+    if (p.bits2)
+        hipLaunchKernelGGL(scatter_records_kernel, dim3(96, 1 << p.bits1), dim3(BLOCK), 0, s, bufa, bufb, off, cur2, p.bits2,
+                           t->log2_bucket_slots);
     // B: count every bucket inside LDS and write its slice of the table
     {
         const size_t lds = (size_t)8 << t->log2_bucket_slots;
@@ -714,7 +863,7 @@ extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t
     if (t->kind != PG_TABLE_HASH) return pg_fail(PG_EINVAL, "pg_kmer_merge: hash tables only (dense tables are summed with an all-reduce)");
     if (n < 0 || (n > 0 && !pairs) || !status) return pg_fail(PG_EINVAL, "pg_kmer_merge: bad arguments");
     if (n == 0) return PG_OK;
-    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, view_of(t), status);
+    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, t->k, view_of(t), status);
     return check_launch("pg_kmer_merge");
 }
 
