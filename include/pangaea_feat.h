@@ -176,6 +176,15 @@ int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,
  * ---------------------------------------------------------------------------------------------- */
 int pg_write_csv_gz(const char *path, const char *names, const int32_t *mat, int64_t n_rows, int64_t n_cols);
 
+/* ----------------------------------------------------------------------------------------------
+ * Bin writer (host): clusters.tsv -> <out_prefix>_bin<label>.fq and .barcode, the on-disk bin layout the
+ * unchanged reassembly stage reads.  Replaces the reference's extract_reads tool (extract_reads.cpp:57-190):
+ * same tsv grammar ("-1" labels skipped), same kept pairs, same rewritten headers
+ * ("<name>\tBX:Z:<barcode>-1").  r2 == NULL: interleaved input.  pairs_written may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int pg_extract_reads(const char *r1_or_interleaved, const char *r2_or_null, const char *clusters_tsv,
+                     const char *out_prefix, int64_t *pairs_written);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,7 @@ def load() -> C.CDLL:
         "pg_kmer_merge": (i32, [vp, i64, tp, vp, vp]),
         "pg_features": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp, vp, tp, i32, i32, vp, vp]),
         "pg_write_csv_gz": (i32, [cp, cp, vp, i64, i64]),
+        "pg_extract_reads": (i32, [cp, cp, cp, cp, C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)           # AttributeError here = header/library mismatch
@@ -94,7 +95,7 @@ EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fast
            "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
            "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_count_workspace_bytes",
            "pg_kmer_count_bucketed", "pg_kmer_merge",
-           "pg_features", "pg_write_csv_gz"]
+           "pg_features", "pg_write_csv_gz", "pg_extract_reads"]
 
 
 def check(rc: int) -> int:

@@ -1,0 +1,226 @@
+"""Clustering layer -- counterpart of /root/reference/src/clustering.py:14-129 with RPH-KMeans on the GPU.
+
+``clustering_rph_kmeans(embedding, k)`` keeps the reference's call (``RPHKMeans(n_init=20, n_clusters=k)``,
+clustering.py:14-19).  The algorithm is the vendored library's (third_parties/rph_kmeans):
+  * bucket width w = half the median of 1 000 random paired distances        (point_reducer_base.py:35-48)
+  * repeat until <= 2 000 points: 5 random projections N(0, 1/w) + U(0,1) offsets, truncate to int32, merge
+    the points that share all 5 integers into their weighted mean            (point_reducer_cy.py:47-76,
+                                                                               _point_reducer_cy_lib.cpp:5-28, .h:52-68)
+  * weighted k-means on the skeleton -> initial centres                        (rph_kmeans_.py:116-129)
+  * Lloyd iterations on ALL points from those centres, best inertia of n_init (rph_kmeans_.py:143-162)
+Where it runs: projections, bucketing (``torch.unique`` over the 5-integer rows), weighted merges and the Lloyd
+distance / assignment / update steps are torch-ROCm ops on the device (the [N,32]x[k,32] distance step is a GEMM +
+row argmin); the <= 2 000-point skeleton k-means stays sklearn on the host, as in the reference.  Random draws
+come from numpy's global generator in the reference's order (``init_all`` seeds it), but bucket numbering follows
+``torch.unique`` instead of ``unordered_map`` iteration, so labels are NOT bit-comparable with the reference
+ -- parity is by inertia and adjusted Rand index.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import warnings
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from .utils import run_cmd
+
+
+def _sq_dists(x: torch.Tensor, c: torch.Tensor, x2: torch.Tensor | None = None) -> torch.Tensor:
+    """squared euclidean distances [N, K] in the dtype of x (the distance step)"""
+    if x2 is None:
+        x2 = (x * x).sum(1, keepdim=True)
+    d = x2 - 2.0 * (x @ c.t()) + (c * c).sum(1)[None, :]
+    return d.clamp_(min=0)
+
+
+@torch.no_grad()
+def lloyd(x: torch.Tensor, centers: torch.Tensor, max_iter: int = 300, tol: float = 1e-4, sample_weight: torch.Tensor | None = None):
+    """sklearn ``KMeans(init=centers, n_init=1)`` semantics (algorithm "lloyd"): stop when the labels repeat or the
+    squared centre shift falls below tol * mean feature variance; an empty cluster takes the point farthest from its
+    centre.  Returns (labels int64 [N], centers [K,D], inertia float, n_iter)."""
+    n, dim = x.shape
+    k = centers.shape[0]
+    w = torch.ones(n, dtype=x.dtype, device=x.device) if sample_weight is None else sample_weight.to(x)
+    x2 = (x * x).sum(1, keepdim=True)
+    tol_abs = float(x.var(dim=0, unbiased=False).mean().item()) * tol
+    centers = centers.to(x).clone()
+    labels_old = None
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        d = _sq_dists(x, centers, x2)
+        mind, labels = d.min(dim=1)
+        sums = torch.zeros((k, dim), dtype=x.dtype, device=x.device).index_add_(0, labels, x * w[:, None])
+        cnt = torch.zeros(k, dtype=x.dtype, device=x.device).index_add_(0, labels, w)
+        empty = torch.nonzero(cnt == 0).flatten()
+        if empty.numel():                                   # relocate empty clusters to the farthest points
+            far = torch.argsort(mind, descending=True)[:empty.numel()]
+            for e, f in zip(empty.tolist(), far.tolist()):
+                old = int(labels[f])
+                sums[old] -= x[f] * w[f]; cnt[old] -= w[f]
+                sums[e] = x[f] * w[f]; cnt[e] = w[f]
+                labels[f] = e
+        new_centers = sums / cnt.clamp(min=1e-30)[:, None]
+        shift = float(((new_centers - centers) ** 2).sum().item())
+        centers = new_centers
+        if labels_old is not None and torch.equal(labels, labels_old):
+            break
+        labels_old = labels
+        if shift <= tol_abs:
+            break
+    d = _sq_dists(x, centers, x2)
+    mind, labels = d.min(dim=1)
+    inertia = float((mind * w).sum().item())
+    return labels, centers, inertia, n_iter
+
+
+class RPHKMeans:
+    """device-resident ``rph_kmeans.RPHKMeans`` (constructor arguments and fitted attributes as the library's)"""
+
+    def __init__(self, n_clusters=8, n_init=1, w=None, max_point=2000, proj_num=5, max_iter=1000, sample_dist_num=1000,
+                 verbose=0, device=None):
+        self.n_clusters, self.n_init, self.w = n_clusters, n_init, w
+        self.max_point, self.proj_num, self.max_iter, self.sample_dist_num = max_point, proj_num, max_iter, int(sample_dist_num)
+        self.verbose = verbose
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("RPHKMeans runs on the GPU; pass device='cpu' explicitly to run the same torch ops on the host")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.inertia_ = self.cluster_centers_ = self.labels_ = self.n_iter_ = None
+        self.reduced_X_ = self.reduced_X_weight_ = self.rp_labels_ = self.rp_iter_ = self.init_centers_ = None
+
+    # -------------------------------------------------------------- point reduction
+
+    def _get_w(self, x: torch.Tensor) -> float:
+        if self.w is not None:
+            return self.w
+        n = x.shape[0]
+        a = torch.from_numpy(np.random.choice(n, self.sample_dist_num)).to(x.device)
+        b = torch.from_numpy(np.random.choice(n, self.sample_dist_num)).to(x.device)
+        dist = (x[a].double() - x[b].double()).pow(2).sum(1).sqrt()
+        self.w = float(np.median(dist.cpu().numpy()) * 0.5)
+        return self.w
+
+    @torch.no_grad()
+    def reduce_points(self, x: torch.Tensor):
+        """(reduced_X [G,D], weight [G], labels int64 [N] -> row of reduced_X, iterations)"""
+        n, dim = x.shape
+        w = self._get_w(x)
+        if not (w > 0):
+            raise RuntimeError("RPH bucket width is zero: the sampled points are all identical")
+        labels = torch.arange(n, device=x.device)
+        weight = torch.ones(n, dtype=x.dtype, device=x.device)
+        red = x
+        it = 0
+        while it < self.max_iter and red.shape[0] > self.max_point:
+            b = np.random.uniform(0, 1, size=(self.proj_num,))
+            proj = np.random.normal(0, 1.0 / w, size=(dim, self.proj_num))
+            pj = (red.double() @ torch.from_numpy(proj).to(x.device) + torch.from_numpy(b).to(x.device)).to(torch.int32)   # trunc toward 0
+            _, bucket = torch.unique(pj, dim=0, return_inverse=True)
+            g = int(bucket.max().item()) + 1
+            new_w = torch.zeros(g, dtype=x.dtype, device=x.device).index_add_(0, bucket, weight)
+            new_x = torch.zeros((g, dim), dtype=x.dtype, device=x.device).index_add_(0, bucket, red * weight[:, None])
+            red = new_x / new_w[:, None]
+            weight = new_w
+            labels = bucket[labels]
+            it += 1
+        return red, weight, labels, it
+
+    def init_centers(self, x: torch.Tensor):
+        from sklearn.cluster import KMeans
+        red, weight, labels, it = self.reduce_points(x)
+        if red.shape[0] < self.n_clusters:
+            raise RuntimeError("Number of reduced points is too small, please try smaller w or larger proj_num")
+        skeleton = KMeans(n_clusters=self.n_clusters)
+        pred = skeleton.fit_predict(red.cpu().numpy(), sample_weight=weight.cpu().numpy())
+        return skeleton.cluster_centers_, red, weight, labels, it, skeleton.inertia_, pred
+
+    # -------------------------------------------------------------- fit
+
+    def fit(self, X):
+        x = torch.as_tensor(np.ascontiguousarray(X) if isinstance(X, np.ndarray) else X).to(self.device)
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.float()
+        self.inertia_ = np.inf
+        for _ in range(self.n_init):
+            centers0, red, weight, rp_labels, rp_iter, _, _ = self.init_centers(x)
+            labels, centers, inertia, n_iter = lloyd(x, torch.from_numpy(np.asarray(centers0)).to(x))
+            if inertia < self.inertia_:
+                self.inertia_ = inertia
+                self.labels_, self.cluster_centers_, self.n_iter_ = labels.cpu().numpy().astype(np.int32), centers.cpu().numpy(), n_iter
+                self.init_centers_, self.reduced_X_, self.reduced_X_weight_ = np.asarray(centers0), red.cpu().numpy(), weight.cpu().numpy()
+                self.rp_labels_, self.rp_iter_ = rp_labels.cpu().numpy(), rp_iter
+        return self
+
+    def fit_predict(self, X):
+        return self.fit(X).labels_
+
+    def predict(self, X):
+        x = torch.as_tensor(X).to(self.device)
+        c = torch.from_numpy(self.cluster_centers_).to(x)
+        return _sq_dists(x, c).argmin(1).cpu().numpy().astype(np.int32)
+
+
+def clustering_rph_kmeans(embedding, k):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clt = RPHKMeans(n_init=20, n_clusters=k, verbose=0)
+        return clt.fit_predict(embedding)
+
+
+def write_clusters_tsv(path: str, clusters, barcodes) -> None:
+    """``<label>\\t<bc1>,<bc2>,...`` per label in first-seen order (clustering.py:107-112)"""
+    cluster2barcodes = defaultdict(list)
+    for lab, bc in zip(clusters, barcodes):
+        cluster2barcodes[lab].append(str(bc))
+    with open(path, "w") as tsv:
+        for cluster_id in cluster2barcodes:
+            tsv.write("{}\t{}\n".format(cluster_id, ",".join(cluster2barcodes[cluster_id])))
+
+
+def cluster_barcode_reads(args, model_path, cluster_path, script_path):
+    """step 3 of pangaea.py: latent.npz/barcodes.npz -> clusters.npz, clusters.tsv, cluster_bin<label>.{fq,barcode},
+    clustering_finished -- the on-disk bin layout the unchanged reassembly stage reads (bin_assembly.sh:18)."""
+    from .binwriter import extract_reads
+    output_npz = os.path.join(cluster_path, "clusters.npz")
+    output_tsv = os.path.join(cluster_path, "clusters.tsv")
+    embedding_path = os.path.join(model_path, "latent.npz")
+    barcodes_path = os.path.join(model_path, "barcodes.npz")
+    if not os.path.isfile(embedding_path) or not os.path.isfile(barcodes_path):
+        raise FileNotFoundError(f"{embedding_path} or {barcodes_path} not found")
+    if not os.path.isfile(output_tsv):
+        embedding = np.load(embedding_path)["arr_0"]
+        barcodes = np.load(barcodes_path)["arr_0"]
+        if args.clusters:
+            num_classes = args.clusters
+        else:
+            # the reference estimates 8 x Shannon diversity with metaphlan (clustering.py:92-102): an external tool,
+            # outside this path -- run the reference's own script when it is installed next to us
+            diversity = os.path.join(script_path, "scripts", "calculate_diversity.sh")
+            if not os.path.isfile(diversity):
+                raise FileNotFoundError("number of clusters (-c) not given and scripts/calculate_diversity.sh not found")
+            reads = args.reads1 if (args.reads1 and args.reads2) else args.interleaved_reads
+            run_cmd([diversity, reads, args.metaphlan_db, cluster_path])
+            shannon = np.loadtxt(os.path.join(cluster_path, "metaphlan_tmp/diversity_analysis/profiles_table_shannon.txt"))
+            num_classes = int(8 * shannon)
+            logging.info(f"estimated num_classes: {num_classes}")
+            run_cmd(["rm", "-rf", os.path.join(cluster_path, "metaphlan_tmp")])
+        clusters = clustering_rph_kmeans(embedding, num_classes)
+        np.savez(output_npz, clusters)
+        logging.info("saving clustering tsv")
+        write_clusters_tsv(output_tsv, clusters, barcodes)
+    else:
+        logging.info("existing clustering result found")
+    prefix = os.path.join(cluster_path, "cluster")
+    if args.reads1 and args.reads2:
+        extract_reads(args.reads1, args.reads2, output_tsv, prefix)
+    elif args.interleaved_reads:
+        extract_reads(args.interleaved_reads, None, output_tsv, prefix)
+    else:
+        logging.error("no reads provided")
+        raise FileNotFoundError("no reads provided")
+    with open(os.path.join(cluster_path, "clustering_finished"), "w") as f:
+        f.write("finished")

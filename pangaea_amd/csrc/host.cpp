@@ -16,6 +16,7 @@
 #include <zlib.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pg_internal.h"
@@ -418,5 +419,150 @@ extern "C" int pg_write_csv_gz(const char *path, const char *names, const int32_
         }
     }
     if (gzclose(f) != Z_OK) return pg_fail(PG_EIO, "close error on %s", path);
+    return PG_OK;
+}
+
+// ------------------------------------------------------------------------------------ bin writer
+//
+// clusters.tsv -> <prefix>_bin<label>.fq / .barcode, as the reference's extract_reads.cpp:57-190 writes them:
+//   * every tsv line "<label>\t<bc>,<bc>,..." opens both files of its label ("-1" lines are skipped entirely) and
+//     maps its barcodes to it (a barcode listed twice belongs to the later line);
+//   * interleaved input: a pair is kept when the barcode of mate 1's header is mapped; mate 1's header is rewritten to
+//     "<name>\tBX:Z:<barcode>-1", the other seven lines are copied as they are (extract_reads.cpp:98-125);
+//   * paired input: additionally both headers must agree in name and barcode, both are rewritten, and the pair goes to
+//     the .fq as mate 1 record + mate 2 record (extract_reads.cpp:141-176);
+//   * the .barcode file receives the barcode once per kept pair.
+
+namespace {
+
+struct BinFiles {
+    FILE *fq = nullptr, *bc = nullptr;
+    std::string fq_buf, bc_buf;
+    void flush()
+    {
+        if (fq && !fq_buf.empty()) { fwrite(fq_buf.data(), 1, fq_buf.size(), fq); fq_buf.clear(); }
+        if (bc && !bc_buf.empty()) { fwrite(bc_buf.data(), 1, bc_buf.size(), bc); bc_buf.clear(); }
+    }
+};
+
+}  // namespace
+
+extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clusters_tsv, const char *out_prefix, int64_t *pairs_written)
+{
+    if (!r1 || !clusters_tsv || !out_prefix) return pg_fail(PG_EINVAL, "pg_extract_reads: null argument");
+    std::string tsv;
+    {
+        FILE *f = fopen(clusters_tsv, "rb");
+        if (!f) return pg_fail(PG_EIO, "cannot open %s", clusters_tsv);
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) tsv.append(buf, got);
+        fclose(f);
+    }
+    std::unordered_map<std::string, uint32_t> cluster_of;
+    std::vector<BinFiles> bins;
+    auto close_all = [&]() {
+        for (auto &b : bins) { b.flush(); if (b.fq) fclose(b.fq); if (b.bc) fclose(b.bc); }
+    };
+    {
+        Lines L(tsv);
+        const char *b; size_t len;
+        while (L.next(b, len)) {
+            size_t pos = find_chr(b, len, '\t', 0);
+            const std::string label(b, pos == NPOS ? len : pos);
+            if (label == "-1") continue;
+            BinFiles files;
+            const std::string stem = std::string(out_prefix) + "_bin" + label;
+            files.bc = fopen((stem + ".barcode").c_str(), "wb");
+            files.fq = fopen((stem + ".fq").c_str(), "wb");
+            if (!files.bc || !files.fq) {
+                if (files.bc) fclose(files.bc);
+                if (files.fq) fclose(files.fq);
+                close_all();
+                return pg_fail(PG_EIO, "cannot create %s.{fq,barcode}", stem.c_str());
+            }
+            bins.push_back(std::move(files));
+            const uint32_t id = (uint32_t)bins.size() - 1;
+            // the reference walks `pos` with wrap-around when the line has no TAB (then the whole line is a barcode list)
+            std::string bc;
+            while (pos != len) {
+                while (++pos < len && b[pos] != ',') bc.push_back(b[pos]);
+                cluster_of[bc] = id;
+                bc.clear();
+            }
+        }
+    }
+    std::string f1, f2;
+    int rc = slurp(r1, f1);
+    if (!rc && r2) rc = slurp(r2, f2);
+    if (rc) { close_all(); return rc; }
+    int64_t written = 0;
+    int mode = MODE_UNSET;
+    const char *b; size_t len;
+    auto emit = [&](uint32_t id, const std::string &barcode, const std::string &rec1, const std::string &rec2) {
+        BinFiles &o = bins[id];
+        o.bc_buf.append(barcode).push_back('\n');
+        o.fq_buf.append(rec1).append(rec2);
+        if (o.fq_buf.size() > (1u << 20)) o.flush();
+        ++written;
+    };
+    if (!r2) {
+        Lines L(f1);
+        uint64_t line_no = 0;
+        bool keep = false;
+        uint32_t id = 0;
+        std::string rec, barcode;
+        const std::string none;
+        while (L.next(b, len)) {
+            const int ph = (int)(++line_no % 8);
+            if (ph == 1) {
+                Span nm, bc;
+                if (!header_fields(b, len, mode, nm, bc)) { close_all(); return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag", r1, (unsigned long long)line_no); }
+                barcode.assign(b + bc.b, bc.n);
+                auto it = cluster_of.find(barcode);
+                keep = it != cluster_of.end();
+                if (keep) {
+                    id = it->second;
+                    rec.append(b + nm.b, nm.n).append("\tBX:Z:").append(barcode).append("-1\n");
+                }
+            } else if (keep) {
+                rec.append(b, len).push_back('\n');
+                if (ph == 0) { emit(id, barcode, rec, none); rec.clear(); }
+            }
+        }
+    } else {
+        Lines L1(f1), L2(f2);
+        uint64_t line_no = 0;
+        bool keep = false;
+        uint32_t id = 0;
+        std::string rec1, rec2, barcode;
+        const char *c; size_t clen;
+        while (L1.next(b, len)) {
+            if (!L2.next(c, clen)) { c = ""; clen = 0; }
+            const int ph = (int)(++line_no % 4);
+            if (ph == 1) {
+                Span n1, b1, n2, b2;
+                if (!header_fields(b, len, mode, n1, b1) || !header_fields(c, clen, mode, n2, b2)) {
+                    close_all();
+                    return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag", r1, (unsigned long long)line_no);
+                }
+                barcode.assign(b + b1.b, b1.n);
+                auto it = cluster_of.find(barcode);
+                keep = it != cluster_of.end() && n1.n == n2.n && memcmp(b + n1.b, c + n2.b, n1.n) == 0 &&
+                       b1.n == b2.n && memcmp(b + b1.b, c + b2.b, b1.n) == 0;
+                if (keep) {
+                    id = it->second;
+                    rec1.append(b + n1.b, n1.n).append("\tBX:Z:").append(barcode).append("-1\n");
+                    rec2.append(c + n2.b, n2.n).append("\tBX:Z:").append(barcode).append("-1\n");
+                }
+            } else if (keep) {
+                rec1.append(b, len).push_back('\n');
+                rec2.append(c, clen).push_back('\n');
+                if (ph == 0) { emit(id, barcode, rec1, rec2); rec1.clear(); rec2.clear(); }
+            }
+        }
+    }
+    close_all();
+    if (pairs_written) *pairs_written = written;
     return PG_OK;
 }

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""``pangaea.py`` -- the reference orchestrator (/root/reference/src/pangaea.py) with steps 1-3 on the GPU.
+
+Same command line (every flag of pangaea.py:130-171), same four resumable steps and marker files
+(``1.features/feature_finished``, ``2.vae/model_finished``, ``3.clustering/clustering_finished``; pangaea.py:23-35),
+same output tree.  Step 4 (sub-assembly + ensemble; clustering.py:132-164) belongs to the unchanged reassembly stage:
+it is delegated to the reference's own ``final_assemble`` when a Pangaea checkout is given with ``--reference_src``
+(or PANGAEA_SRC), and skipped with a log line otherwise.
+
+    python -m pangaea_amd.pangaea -i interleaved.sorted.fastq -o out -c 30 -st 1,2,3
+Multi-GPU: ``torchrun --nproc-per-node N -m pangaea_amd.pangaea ...`` shards step 1 (see pangaea_amd/dist.py).
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+
+import numpy as np
+import torch
+
+
+def check_steps_finish(args, step):
+    marks = {"1": ("1.features", "feature_finished"), "2": ("2.vae", "model_finished"),
+             "3": ("3.clustering", "clustering_finished"), "4": ("4.assembly", "assemble_finished")}
+    if step not in marks:
+        return False
+    d, f = marks[step]
+    return os.path.exists(os.path.join(args.output, d, f))
+
+
+def check_steps_required(args_steps, step):
+    return step in ("1", "2", "3", "4") and step in args_steps
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    p.add_argument("-1", "--reads1", default="", help="path to reads1 file (linked-reads)")
+    p.add_argument("-2", "--reads2", default="", help="path to reads2 file (linked-reads)")
+    p.add_argument("-i", "--interleaved_reads", default="", help="path to reads file (long-reads)")
+    p.add_argument("-o", "--output", required=True, help="output directory")
+    p.add_argument("-l", "--min_length", type=int, default=2000, help="min barcode length (default 2000)")
+    p.add_argument("-k", "--kmer", type=int, default=15, help="kmer for abundance (default 15)")
+    p.add_argument("-tnf_k", "--tnf_kmer", type=int, default=4, help="kmer for TNF (default 4, long reads should use 3)")
+    p.add_argument("-s", "--window_size", type=int, default=10, help="window size for abundance (default 10)")
+    p.add_argument("-v", "--vector_size", type=int, default=400, help="vector size for abundance (default 400)")
+    p.add_argument("-r", "--lr", type=float, default=0.005, help="learning rate (default 0.005)")
+    p.add_argument("-w", "--weight_decay", type=float, default=0.0001, help="weight decay (default 0.0001)")
+    p.add_argument("-e", "--epochs", type=int, default=100, help="number of epochs (default 100)")
+    p.add_argument("-b", "--batch_size", type=int, default=2048, help="batch size (defult 2048)")
+    p.add_argument("-d", "--dropout", type=float, default=0.2, help="dropout (default 0.2)")
+    p.add_argument("-p", "--patience", type=int, default=20, help="early stop patience (default 20)")
+    p.add_argument("-wa", "--weight_alpha", type=float, default=0.1, help="training weight for abundance and tnf (default 0.1)")
+    p.add_argument("-wk", "--weight_kl", type=float, default=0.015, help="training weight for KL (default 0.015)")
+    p.add_argument("-ld", "--latent_dim", type=int, default=32, help="latent dimension (default 32)")
+    p.add_argument("-c", "--clusters", type=int, required=False, help="number of clusters")
+    p.add_argument("-m", "--metaphlan_db", type=str, default="metaphlan_db", help="path to metaphlan db (default metaphlan_db)")
+    p.add_argument("-t", "--threads", type=int, default=100, help="number of threads (default 100)")
+    p.add_argument("-g", "--use_cuda", type=bool, default=True, help="use the GPU (default True; the feature path has no CPU form)")
+    p.add_argument("-n", "--num_gpus", type=int, default=1, help="use gpu in parallel (if use cuda)")
+    p.add_argument("-sp", "--spades", type=str, help="path to original contigs")
+    p.add_argument("-lc", "--local_assembly", type=str, help="path to local assembly contigs")
+    p.add_argument("-at", "--athena", type=str, help="path to athena contigs")
+    p.add_argument("-lt", "--low_abd_cut", type=str, default="10,30", help="coverage for low abundance contigs")
+    p.add_argument("-la", "--low_assembler", type=str, default="megahit", help="local assembly method (spades or megahit)")
+    p.add_argument("-md", "--model", type=str, default="vae", help="model ( vae)")
+    p.add_argument("-ls", "--loss_type", type=str, default="ce", help="reconstruction loss type (default ce)")
+    p.add_argument("-st", "--steps", type=str, default="1,2,3,4", help="steps to run (default 1:feature extraction, 2:vae trainning, 3:clutsering, 4:sub-assembly and final assembly)")
+    # additive option (not in the reference)
+    p.add_argument("--reference_src", type=str, default=os.environ.get("PANGAEA_SRC", ""),
+                   help="src/ directory of a Pangaea checkout: where step 4 and the metaphlan helper scripts live")
+    return p
+
+
+def run(args, script_path):
+    from .clustering import cluster_barcode_reads
+    from .data import Data
+    from .feature import Feature
+    from .loader import shuffled_batches, weighted_batches
+    from .models.VAENET import VAENET
+    from .utils import init_all
+
+    init_all(seed=2021, threads=min(args.threads, os.cpu_count() or 1), logfile="log", level=logging.INFO, outdir=args.output)
+    logging.info("command: " + " ".join(sys.argv))
+    logging.info(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.distributed.init_process_group("nccl")
+    rank0 = not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0
+
+    model_path = os.path.join(args.output, "2.vae")
+    cluster_path = os.path.join(args.output, "3.clustering")
+    assembly_path = os.path.join(args.output, "4.assembly")
+    have_reads = (args.reads1 and args.reads2) or args.interleaved_reads
+    read_specify = abundance = tnf = None
+
+    # step 1: feature extraction (every rank takes part; the rest of the steps run on rank 0)
+    if not check_steps_required(args.steps, "1"):
+        logging.info("skip step 1: feature extraction")
+    elif check_steps_finish(args, "1"):
+        logging.info("step 1: feature extraction finished")
+    elif have_reads:
+        read_specify, abundance, tnf = Feature(args, script_path).extract_features()
+    else:
+        print("Please provide one or two input file(s):-1 and -2 for pair-end linked reads; -lr as long reads; -i for interleaved linked reads.")
+        sys.exit()
+    if not rank0:
+        return
+
+    # step 2: training
+    if not check_steps_required(args.steps, "2"):
+        logging.info("skip step 2: training")
+    elif check_steps_finish(args, "2"):
+        logging.info("step 2: training finished")
+    else:
+        if not all(isinstance(a, np.ndarray) for a in (read_specify, abundance, tnf)):
+            read_specify, abundance, tnf = Feature(args, script_path).load_features()
+        dataset = Data(read_specify, abundance, tnf)
+        test_size = min(int(len(dataset) * 0.7), 1000000)
+        train = weighted_batches(dataset, args.batch_size)
+        test = weighted_batches(dataset, args.batch_size, num_samples=test_size, replacement=False)
+        original = shuffled_batches(dataset, args.batch_size)
+        os.makedirs(model_path, exist_ok=True)
+        vae = VAENET(abd_dim=abundance.shape[1], tnf_dim=tnf.shape[1], latent_size=args.latent_dim, num_classes=args.clusters,
+                     epochs=args.epochs, cuda=True, num_gpus=args.num_gpus, lr=args.lr, dropout=args.dropout,
+                     alpha=args.weight_alpha, w_kl=args.weight_kl, weight_decay=args.weight_decay)
+        vae.train(train, test, original, model_path, args.patience)
+
+    # step 3: clustering
+    if not check_steps_required(args.steps, "3"):
+        logging.info("skip step 3: clustering")
+    elif check_steps_finish(args, "3"):
+        logging.info("step 3: clustering finished")
+    else:
+        logging.info("start clustering")
+        os.makedirs(cluster_path, exist_ok=True)
+        if have_reads:
+            cluster_barcode_reads(args, model_path, cluster_path, args.reference_src or script_path)
+        else:
+            logging.info("Please provide one or two input file(s):-1 and -2 for pair-end linked reads; -lr as long reads; -i for interleaved linked reads.")
+            sys.exit()
+
+    # step 4: the unchanged reassembly / ensemble stage of the reference
+    if not check_steps_required(args.steps, "4"):
+        logging.info("skip step 4: assembly")
+    elif check_steps_finish(args, "4"):
+        logging.info("step 4: assembly finished")
+    elif args.reference_src and os.path.isfile(os.path.join(args.reference_src, "clustering.py")):
+        logging.info("start assembly (reference final_assemble)")
+        sys.path.insert(0, args.reference_src)
+        sys.path.insert(0, os.path.join(os.path.dirname(args.reference_src), "third_parties", "rph_kmeans"))
+        from clustering import final_assemble              # the reference's own step 4
+        final_assemble(args, cluster_path, assembly_path, args.reference_src)
+    else:
+        logging.info("step 4 (multi-threshold reassembly + ensemble) is the reference's unchanged stage: "
+                     "give --reference_src <Pangaea>/src to run it on " + cluster_path)
+    logging.info("program finished successfully")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    run(args, os.path.dirname(os.path.abspath(__file__)))
+
+
+if __name__ == "__main__":
+    main()

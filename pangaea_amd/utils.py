@@ -1,5 +1,5 @@
 """Counterparts of /root/reference/src/utils.py used on the hot path: the weighted sampler (utils.py:9-21), early
-stopping with checkpoint-on-improve (utils.py:24-50) and ``init_all`` (utils.py:82-103)."""
+stopping with checkpoint-on-improve (utils.py:24-50), ``run_cmd`` (utils.py:67-79) and ``init_all`` (utils.py:82-103)."""
 from __future__ import annotations
 
 import logging
@@ -41,6 +41,19 @@ class EarlyStopping:
     def save_checkpoint(self, val_loss, model):
         torch.save(model.state_dict(), self.path)
         self.val_loss_min = val_loss
+
+
+def run_cmd(command, log_file=None):
+    """run an external tool, exit the program on failure (utils.py:67-79)"""
+    import subprocess
+    import sys
+    log_pipe = subprocess.DEVNULL if not log_file else open(log_file, "a")
+    logging.info("command started: " + " ".join(command))
+    ret = subprocess.run(command, stdout=subprocess.PIPE, stderr=log_pipe, stdin=subprocess.PIPE, text=True)
+    if ret.returncode:
+        logging.error("command failed: " + " ".join(command))
+        sys.exit(1)
+    logging.info("command completed: " + " ".join(command))
 
 
 def init_all(seed, threads, logfile, level, outdir):

@@ -10,6 +10,10 @@ Runs only in the build container (needs /root/reference):
   * part B -- ``/root/reference/src/data.py`` and ``src/models/VAENET.py`` are imported (two harness-side
     shims: a stub ``kneed`` module and ``np.Inf``) and evaluated on seeded inputs -> ``data_g4.npz``,
     ``vae_g5.npz``.
+  * part C -- the reference's ``extract_reads`` binary (same build) on three inputs + clusters.tsv files ->
+    ``bins_*/cluster_bin<label>.{fq,barcode}``.
+  * part D -- the vendored ``third_parties/rph_kmeans`` library (its pure-python reducer; the Cython extension is
+    not built) on seeded separable latents -> ``rph_g6.npz`` (labels, inertia).
 
 Everything written is data (inputs + expected outputs); no reference source text is stored.
 Usage:  python tests/golden/make_goldens.py
@@ -284,6 +288,62 @@ def part_b():
     print("part B: data_g4.npz vae_g5.npz")
 
 
+def part_c():
+    """bin writer: the reference's extract_reads binary on three inputs -> every file it writes"""
+    ref = oracle.ref_tool("extract_reads")
+    assert ref, "run `make -C oracle ref` first"
+    import shutil
+    import tempfile
+    jobs = [("bins_tenx", {"i": "tenx_mixed.fq"}, "3\tAAACCCGG,ACGTACGT\n-1\tAACGTTTC\n0\tCCGGTTAA,GGTTAACC,AAACCCGG\n7\t\n"),
+            ("bins_stlfr", {"i": "stlfr.fq"}, "1\t1_2_3,7_8_9\n2\t10_11_12\n"),
+            ("bins_pair", {"1": "pair_R1.fq", "2": "pair_R2.fq"}, "5\tAAAA\n6\tCCCC,GGGG\n")]
+    man = []
+    for name, spec, tsv in jobs:
+        out = os.path.join(HERE, name)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        with open(os.path.join(out, "clusters.tsv"), "w") as f:
+            f.write(tsv)
+        args = []
+        for flag, fn in spec.items():
+            args += [f"-{flag}", os.path.join(HERE, fn)]
+        run([ref] + args + ["-c", os.path.join(out, "clusters.tsv"), "-o", os.path.join(out, "cluster")])
+        man.append({"dir": name, "input": spec, "files": sorted(f for f in os.listdir(out) if f.startswith("cluster_"))})
+    with open(os.path.join(HERE, "manifest.json")) as f:
+        m = json.load(f)
+    m["bin_writer"] = man
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(m, f, indent=1)
+    print(f"part C: {len(man)} bin-writer cases")
+
+
+def part_d():
+    """rph_kmeans (vendored library, python reducer: the Cython extension is not built) on separable latents:
+    labels are not bit-reproducible across hash-map orders, so the fixture pins inertia and the partition"""
+    sys.path[:0] = [os.path.join(REF, "third_parties", "rph_kmeans")]
+    kneed = types.ModuleType("kneed"); kneed.KneeLocator = object
+    sys.modules["kneed"] = kneed
+    import warnings
+    from rph_kmeans import RPHKMeans
+    rs = np.random.RandomState(6)
+    sizes = [700, 300, 150, 60, 40, 350]
+    centers = rs.randn(len(sizes), 32) * 0.6
+    X = np.concatenate([c + 0.05 * rs.randn(n, 32) for c, n in zip(centers, sizes)]).astype(np.float32)
+    truth = np.concatenate([np.full(n, i) for i, n in enumerate(sizes)])
+    perm = rs.permutation(len(X))
+    X, truth = X[perm], truth[perm]
+    np.random.seed(2021)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clt = RPHKMeans(n_init=20, n_clusters=len(sizes), verbose=0, max_point=200)
+        labels = clt.fit_predict(X)
+    np.savez_compressed(os.path.join(HERE, "rph_g6.npz"), X=X, truth=truth, labels=labels.astype(np.int32),
+                        inertia=np.float64(clt.inertia_), n_clusters=np.int32(len(sizes)), max_point=np.int32(200))
+    print("part D: rph_g6.npz inertia", clt.inertia_)
+
+
 if __name__ == "__main__":
     part_a()
     part_b()
+    part_c()
+    part_d()

@@ -1,0 +1,69 @@
+"""Bin writer (pg_extract_reads) against the files the reference's extract_reads binary wrote (tests/golden/bins_*)
+and, where oracle/_ref exists, against that binary live on randomised cluster assignments."""
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import oracle
+from pangaea_amd import _lib
+from pangaea_amd.binwriter import extract_reads
+from pangaea_amd.clustering import write_clusters_tsv
+
+from .conftest import GOLDEN
+
+
+def _inputs(spec):
+    if "i" in spec:
+        return os.path.join(GOLDEN, spec["i"]), None
+    return os.path.join(GOLDEN, spec["1"]), os.path.join(GOLDEN, spec["2"])
+
+
+def test_golden_bins(manifest, tmp_path):
+    for case in manifest["bin_writer"]:
+        src = os.path.join(GOLDEN, case["dir"])
+        out = tmp_path / case["dir"]
+        out.mkdir()
+        r1, r2 = _inputs(case["input"])
+        n = extract_reads(r1, r2, os.path.join(src, "clusters.tsv"), str(out / "cluster"))
+        assert sorted(os.listdir(out)) == case["files"]
+        total = 0
+        for fn in case["files"]:
+            with open(os.path.join(src, fn), "rb") as f, open(out / fn, "rb") as g:
+                want = f.read()
+                assert g.read() == want, fn
+            if fn.endswith(".barcode"):
+                total += want.count(b"\n")
+        assert n == total
+
+
+def test_errors_are_reported(tmp_path):
+    with pytest.raises(_lib.PangaeaError):
+        extract_reads(os.path.join(GOLDEN, "stlfr.fq"), None, str(tmp_path / "missing.tsv"), str(tmp_path / "c"))
+    tsv = tmp_path / "c.tsv"
+    tsv.write_text("0\tAAAA\n")
+    with pytest.raises(_lib.PangaeaError):
+        extract_reads("/nonexistent.fq", None, str(tsv), str(tmp_path / "c"))
+    with pytest.raises(_lib.PangaeaError):
+        extract_reads(os.path.join(GOLDEN, "stlfr.fq"), None, str(tsv), str(tmp_path / "no_such_dir" / "c"))
+
+
+@pytest.mark.skipif(oracle.ref_tool("extract_reads") is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("name", ["tenx_mixed.fq", "tenx_clean.fq.gz", "stlfr.fq", "tenx_crlf.fq", "pair"])
+def test_live_against_reference_binary(name, tmp_path):
+    rng = random.Random(len(name))
+    spec = {"1": "pair_R1.fq", "2": "pair_R2.fq"} if name == "pair" else {"i": name}
+    r1, r2 = _inputs(spec)
+    barcodes = sorted({n for n in oracle.Reads(r1, r2).names if n})
+    labels = [rng.choice([-1, 0, 1, 2, 5]) for _ in barcodes]
+    tsv = str(tmp_path / "clusters.tsv")
+    write_clusters_tsv(tsv, labels, barcodes)
+    a, b = tmp_path / "ref", tmp_path / "mine"
+    a.mkdir(); b.mkdir()
+    flags = ["-i", r1] if r2 is None else ["-1", r1, "-2", r2]
+    subprocess.run([oracle.ref_tool("extract_reads")] + flags + ["-c", tsv, "-o", str(a / "cluster")], check=True, stdout=subprocess.DEVNULL)
+    extract_reads(r1, r2, tsv, str(b / "cluster"))
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b))
+    for fn in os.listdir(a):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
