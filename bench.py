@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--barcodes", type=int, default=0, help="barcodes per GPU (default pairs/200)")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="pairs in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     return ap.parse_args()
 
 
@@ -111,11 +112,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the feature path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from pangaea_amd import dist as pdist
     from pangaea_amd import kmer, synth
@@ -206,7 +211,7 @@ def main():
             "config": {"workload": f"synthetic {args.pairs} x 150 bp read pairs and {n_bc} barcodes per GPU, k=21 hash table "
                                    f"(2^{table.log2_slots} slots), TNF k=4 + abundance V=400 W=10, L1-normalise, VAE 536-512-512-32 encode",
                        "pairs_per_gpu": args.pairs, "barcodes_per_gpu": n_bc, "rows_per_gpu": len(rows),
-                       "parallelism": f"run-sharded x{world}, table all-gather+merge" if world > 1 else "single GPU",
+                       "parallelism": f"run-sharded x{world}, table all-gather + LDS bucket merge ({args.backend})" if world > 1 else "single GPU",
                        "input": "packed reads resident in HBM"},
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -122,7 +122,7 @@ enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2 };
 #define PG_HASH_COUNT_BITS 22
 #define PG_HASH_COUNT_SAT (1u << 21)
 #define PG_BUCKET_MAX_LOG2_SLOTS 14   /* 2^14 slots x 8 B = 128 KiB of the CU's 160 KiB LDS */
-#define PG_BUCKET_MAX_LOG2_BUCKETS 15
+#define PG_BUCKET_MAX_LOG2_BUCKETS 17  /* two scatter passes of <= 9 bits; the histogram takes 2^15 bins per launch */
 
 typedef struct {
     int32_t kind;       /* PG_TABLE_DENSE or PG_TABLE_HASH */
@@ -154,6 +154,13 @@ int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t
 /* Add n (code,count) pairs -- `pairs[i] = (code << 22) | count`, the slot format -- into a hash table:
  * the merge step after tables of other GPUs have been gathered. */
 int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t, uint32_t *status, void *stream);
+
+/* The same merge for a bucketed table whose foreign entries arrive in bucket order (a table's slots are laid out
+ * bucket by bucket, so the occupied slots of another rank's table, in slot order, already are): one workgroup per
+ * bucket merges inside LDS, no global atomics.  `pairs` = n_parts vectors concatenated; seg[p * (n_buckets + 1) + b]
+ * .. seg[p * (n_buckets + 1) + b + 1] delimit part p's entries of bucket b (absolute offsets into pairs, device). */
+int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
+                           uint32_t *status, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Per-run feature rows (device).  One launch fills both matrices.

@@ -21,7 +21,7 @@ HASH_COUNT_BITS = 22
 HASH_COUNT_SAT = 1 << 21
 TNF_MAX_K = 6
 WORD_ALIGN = 256
-BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 15
+BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
 
 
 class PangaeaError(RuntimeError):
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
         "pg_kmer_count_workspace_bytes": (i64, [i64, tp]),
         "pg_kmer_count_bucketed": (i32, [vp, vp, i64, i64, tp, i32, vp, i64, vp, vp]),
         "pg_kmer_merge": (i32, [vp, i64, tp, vp, vp]),
+        "pg_kmer_merge_bucketed": (i32, [vp, vp, i32, tp, vp, vp]),
         "pg_features": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp, vp, tp, i32, i32, vp, vp]),
         "pg_write_csv_gz": (i32, [cp, cp, vp, i64, i64]),
         "pg_extract_reads": (i32, [cp, cp, cp, cp, C.POINTER(i64)]),
@@ -94,7 +95,7 @@ EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fast
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
            "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
            "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_count_workspace_bytes",
-           "pg_kmer_count_bucketed", "pg_kmer_merge",
+           "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed",
            "pg_features", "pg_write_csv_gz", "pg_extract_reads"]
 
 

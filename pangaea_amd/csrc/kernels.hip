@@ -306,10 +306,11 @@ constexpr uint64_t REC_KEY_MASK = (1ull << REC_KEY_BITS) - 1;
 // A0: histogram of final bucket ids (top `bits` bits of the placement hash) over every valid k-mer of the word range
 __global__ __launch_bounds__(HIST_BLOCK) void bucket_hist_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                                  int64_t word_begin, int64_t word_end, int k, int log2_slots, int bits,
-                                                                 unsigned long long *__restrict__ hist)
+                                                                 uint32_t bin_base, int n_bins, unsigned long long *__restrict__ hist)
 {
+    // one launch covers the bins [bin_base, bin_base + n_bins) (n_bins <= 2^15: 128 KiB of LDS counters); tables
+    // with more buckets take several launches over the stream
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int n_bins = 1 << bits;
     for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK) lds[i] = 0;
     __syncthreads();
     for (int64_t w = word_begin + (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * HIST_BLOCK) {
@@ -325,12 +326,15 @@ __global__ __launch_bounds__(HIST_BLOCK) void bucket_hist_kernel(const uint64_t 
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             r.push((uint32_t)(cw >> (2 * j)) & 3u);
-            if ((ok >> j) & 1) atomicAdd(&lds[r.slot(log2_slots) >> (log2_slots - bits)], 1u);
+            if ((ok >> j) & 1) {
+                const uint32_t bin = (uint32_t)(r.slot(log2_slots) >> (log2_slots - bits)) - bin_base;
+                if (bin < (uint32_t)n_bins) atomicAdd(&lds[bin], 1u);
+            }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK)
-        if (lds[i]) atomicAdd(&hist[i], (unsigned long long)lds[i]);
+        if (lds[i]) atomicAdd(&hist[bin_base + i], (unsigned long long)lds[i]);
 }
 
 // exclusive prefix sum of hist[n] -> off[n+1] (one workgroup; n <= 2^17)
@@ -559,6 +563,56 @@ __global__ __launch_bounds__(HIST_BLOCK) void bucket_count_kernel(const uint64_t
     for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) slice[i] = tab[i];
 }
 
+// Bucket-wise merge of other tables into this one: the compacted tables of the other ranks arrive bucket by bucket
+// (a table's slots are laid out by bucket, so compaction keeps bucket order).  One workgroup per bucket loads its slice
+// into LDS, adds every foreign entry of that bucket (counts saturate exactly) and writes the slice back.
+//   pairs  : the foreign tables' occupied slots, concatenated part after part
+//   seg    : [n_parts][n_buckets + 1] offsets into `pairs` (absolute)
+__global__ __launch_bounds__(HIST_BLOCK) void bucket_merge_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
+                                                                  int n_parts, int k, HashView t, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t primary = t.primary(), limit = t.limit();
+    const int64_t n_buckets = (int64_t)1 << (t.log2_slots - t.log2_bucket);
+    uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    int64_t total = 0;
+    for (int p = 0; p < n_parts; ++p) total += seg[p * (n_buckets + 1) + blockIdx.x + 1] - seg[p * (n_buckets + 1) + blockIdx.x];
+    if (total == 0) return;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) tab[i] = slice[i];
+    __syncthreads();
+    bool full = false;
+    for (int p = 0; p < n_parts; ++p) {
+        const int64_t a = seg[p * (n_buckets + 1) + blockIdx.x], b = seg[p * (n_buckets + 1) + blockIdx.x + 1];
+        for (int64_t i = a + threadIdx.x; i < b; i += HIST_BLOCK) {
+            const uint64_t e = pairs[i];
+            const uint64_t code = e >> HASH_CBITS;
+            uint32_t add = (uint32_t)(e & HASH_CMASK);
+            if (add > HASH_SAT) add = HASH_SAT;
+            uint32_t s = (uint32_t)slot_of_code(code, k, t.log2_slots) & smask;
+            bool done = false;
+            for (uint32_t tries = 1; tries <= limit && !done; ++tries) {
+                unsigned long long cur = tab[s];
+                for (;;) {
+                    if (cur != 0 && (cur >> HASH_CBITS) != code) break;
+                    const uint32_t have = (uint32_t)(cur & HASH_CMASK);
+                    const uint32_t sum = have + add > HASH_SAT ? HASH_SAT : have + add;
+                    const unsigned long long want = (code << HASH_CBITS) | sum;
+                    const unsigned long long old = atomicCAS(&tab[s], cur, want);
+                    if (old == cur) { done = true; break; }
+                    cur = old;
+                }
+                s = tries == primary ? (uint32_t)(mix64(code) & smask) : ((s + 1) & smask);
+            }
+            full |= !done;
+        }
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) slice[i] = tab[i];
+}
+
 // -------------------------------------------------------------------------------- K1 + K3: per-run rows
 
 // LDS: abd_copies x [vsize] abundance bins, then tnf_copies x [4^k_tnf] raw k_tnf-mer bins
@@ -734,7 +788,9 @@ int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
     p->bits = t->log2_slots - t->log2_bucket_slots;
     if (p->bits < 1 || p->bits > PG_BUCKET_MAX_LOG2_BUCKETS)
         return pg_fail(PG_EINVAL, "bucketed counting needs 1 <= log2_slots - log2_bucket_slots <= %d (got %d)", PG_BUCKET_MAX_LOG2_BUCKETS, p->bits);
-    p->bits1 = p->bits < 8 ? p->bits : 8;
+    // first-level fan-out: 8 bits, 9 when the record's 22 spare bits could not hold the rest of the slot index
+    p->bits1 = p->bits < 8 ? p->bits : (t->log2_slots - 8 > 64 - REC_KEY_BITS ? 9 : 8);
+    if (p->bits1 > p->bits) p->bits1 = p->bits;
     p->bits2 = p->bits - p->bits1;
     if (p->bits2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many buckets for two scatter passes");
     if (t->log2_slots - p->bits1 > 64 - REC_KEY_BITS)
@@ -825,7 +881,7 @@ extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *val
     const int64_t n_words = word_end - word_begin;
 
     // both LDS-heavy kernels may need more than the default 64 KiB of dynamic LDS
-    if (((size_t)nb * 4 > 64 * 1024 || ((size_t)8 << t->log2_bucket_slots) > 64 * 1024)) {
+    if (nb > (1 << 14) || ((size_t)8 << t->log2_bucket_slots) > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)bucket_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)bucket_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
             return pg_fail(PG_EHIP, "pg_kmer_count_bucketed: cannot raise the dynamic LDS limit");
@@ -834,7 +890,10 @@ extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *val
     {
         int grid = (int)((n_words + HIST_BLOCK - 1) / HIST_BLOCK);
         if (grid > 512) grid = 512;
-        hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(HIST_BLOCK), (size_t)nb * 4, s, codes, valid, word_begin, word_end, t->k, t->log2_slots, p.bits, hist);
+        const int per = nb < (1 << 15) ? nb : (1 << 15);
+        for (int base = 0; base < nb; base += per)
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(HIST_BLOCK), (size_t)per * 4, s, codes, valid, word_begin, word_end,
+                               t->k, t->log2_slots, p.bits, (uint32_t)base, per, hist);
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(HIST_BLOCK), 0, s, hist, nb, off);
     }
     // A1: stream -> 2^bits1 regions (region d1 = final buckets [d1 << bits2, (d1+1) << bits2))
@@ -865,6 +924,25 @@ extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t
     if (n == 0) return PG_OK;
     hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, t->k, view_of(t), status);
     return check_launch("pg_kmer_merge");
+}
+
+extern "C" int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t, uint32_t *status, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_HASH || t->log2_bucket_slots == 0 || t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS)
+        return pg_fail(PG_EINVAL, "pg_kmer_merge_bucketed: needs a bucketed hash table with LDS-sized buckets");
+    if (n_parts < 0 || (n_parts > 0 && (!pairs || !seg)) || !status) return pg_fail(PG_EINVAL, "pg_kmer_merge_bucketed: bad arguments");
+    if (n_parts == 0) return PG_OK;
+    const int bits = t->log2_slots - t->log2_bucket_slots;
+    if (bits < 0 || bits > 30) return pg_fail(PG_EINVAL, "pg_kmer_merge_bucketed: bad bucket geometry");
+    const size_t lds = (size_t)8 << t->log2_bucket_slots;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)bucket_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+        return pg_fail(PG_EHIP, "pg_kmer_merge_bucketed: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(HIST_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
+                       n_parts, t->k, view_of(t), status);
+    return check_launch("pg_kmer_merge_bucketed");
 }
 
 extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,

@@ -4,8 +4,9 @@ The reference is single-process; the decomposition is the build's own (SURVEY 8e
   * rows (barcode runs) are independent -> every rank takes a contiguous range of runs, balanced by characters,
     and produces its own block of the count matrices: no data-path collective for K1/K3 or the VAE encode;
   * the k-mer multiplicity table is a global sum -> ONE exchange after counting: dense tables (k <= 16) are
-    summed with an all-reduce; hash tables are compacted, all-gathered and merged, after which every rank holds
-    the full table and looks up locally.
+    summed with an all-reduce; hash tables are compacted, all-gathered and merged -- bucket by bucket inside LDS,
+    because every rank uses the same bucket geometry and a compacted table is already in bucket order -- after
+    which every rank holds the full table and looks up locally.
 """
 from __future__ import annotations
 
@@ -98,10 +99,19 @@ def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTabl
             table.data.copy_(data)
         return table
     me = dist.get_rank(group)
+    world = dist.get_world_size(group)
     parts = gather_pairs(table.compact(), group)
-    for r, pairs in enumerate(parts):
-        if r != me and pairs.numel():
-            table.merge(pairs, check=False)
+    if table.log2_bucket:
+        # every rank built its table with the same geometry, so compacted tables are bucket-ordered: exchange the
+        # per-bucket counts too and merge bucket by bucket inside LDS (no global atomics)
+        mine = _staged(table.bucket_counts(), group)
+        counts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(counts, mine, group=group)
+        table.merge_parts([(parts[r], counts[r]) for r in range(world) if r != me], check=False)
+    else:
+        for r, pairs in enumerate(parts):
+            if r != me and pairs.numel():
+                table.merge(pairs, check=False)
     if check:
         table.check_status()
     return table

@@ -173,6 +173,44 @@ class KmerTable:
             self.check_status()
         return self
 
+    @property
+    def n_buckets(self) -> int:
+        return 1 << (self.log2_slots - self.log2_bucket) if self.kind == "hash" and self.log2_bucket else 1
+
+    def bucket_counts(self) -> torch.Tensor:
+        """occupied slots per bucket, int64 [n_buckets] -- the segment lengths of ``compact()`` (slot order = bucket order)"""
+        if self.kind != "hash":
+            raise ValueError("bucket_counts() is for hash tables")
+        return (self.data.view(self.n_buckets, -1) != 0).sum(dim=1)
+
+    def merge_parts(self, parts, check: bool = True) -> "KmerTable":
+        """add other tables of the SAME geometry, each given as (compact(), bucket_counts()); bucket by bucket inside
+        LDS when the buckets are LDS-sized, else with global atomics"""
+        parts = [(p.to(self.device, torch.int64), c.to(self.device, torch.int64)) for p, c in parts if p.numel()]
+        if not parts:
+            return self
+        if not (self.kind == "hash" and 0 < self.log2_bucket <= _lib.BUCKET_MAX_LOG2_SLOTS):
+            for p, _ in parts:
+                self.merge(p, check=False)
+        else:
+            if self._empty:
+                self.data.zero_()
+            self._empty = False
+            pairs = torch.cat([p for p, _ in parts]).contiguous()
+            seg, base = [], 0
+            for p, c in parts:
+                if c.numel() != self.n_buckets or int(c.sum().item()) != p.numel():
+                    raise ValueError("merge_parts: bucket counts do not describe the pairs (different table geometry?)")
+                seg.append(torch.cat([c.new_zeros(1), torch.cumsum(c, 0)]) + base)
+                base += p.numel()
+            seg = torch.stack(seg).contiguous()
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().pg_kmer_merge_bucketed(pairs.data_ptr(), seg.data_ptr(), len(parts), self.desc(),
+                                                              self.status.data_ptr(), _stream_ptr(self.device)))
+        if check:
+            self.check_status()
+        return self
+
     def compact(self) -> torch.Tensor:
         """occupied slots of a hash table as an int64 vector (slot format)"""
         if self.kind != "hash":

@@ -153,7 +153,7 @@ def test_counting_in_pieces_accumulates():
             assert np.array_equal(c1, c2) and np.array_equal(2 * n1, n2)
 
 
-@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 14), (18, 10), (19, 7), (20, 5), (20, 6), (18, 0)])
+@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 14), (18, 10), (19, 7), (20, 5), (20, 6), (22, 5), (23, 7), (18, 0)])
 def test_bucketed_counter_equals_direct_counter(log2_slots, log2_bucket):
     """partition + LDS counting (one or two scatter passes, 2^4..2^15 buckets) builds the same multiset as one global
     atomic per occurrence, fresh and accumulating, and the lookups see the same counts"""
@@ -178,6 +178,26 @@ def test_bucketed_counter_equals_direct_counter(log2_slots, log2_bucket):
     t.reset().count(s)
     gc, gn = t.items()
     assert np.array_equal(gc, wc) and np.array_equal(gn, wn)
+
+
+@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 10), (20, 6), (18, 14), (18, 0)])
+def test_merging_tables_bucket_by_bucket(log2_slots, log2_bucket):
+    """tables of two halves of a stream (same geometry) merge into the table of the whole, through the LDS bucket merge
+    (or global atomics for the unbucketed form) -- what the multi-GPU exchange does after its all-gather"""
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=20, n_genomes=3, genome_len=20_000, fragment=8_000, seed=41)
+    s = synth.generate(cfg, device=DEV)
+    cut = s.n_words // 2 + 5
+    a = kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket).count(s, 0, cut)
+    b = kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket).count(s, cut, s.n_words)
+    c = kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket).count(s, cut, s.n_words)
+    assert int(b.bucket_counts().sum()) == b.compact().numel() and b.bucket_counts().numel() == b.n_buckets
+    a.merge_parts([(b.compact(), b.bucket_counts()), (c.compact(), c.bucket_counts())])
+    want = oracle.Table(21, threads=4).count(s.decode())
+    gc, gn = a.items()
+    # a + 2 x b: every k-mer of the second half counted twice more
+    wb = kmer.KmerTable.with_slots(21, DEV, log2_slots, 0).count(s).count(s, cut, s.n_words)
+    assert all(np.array_equal(x, y) for x, y in zip((gc, gn), wb.items()))
+    assert len(gc) == len(want.items()[0])
 
 
 def test_bucket_overflow_is_reported():
