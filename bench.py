@@ -184,6 +184,7 @@ def main():
     assert tuple(mu.shape) == (len(rows), 32) and bool(torch.isfinite(mu).all())
 
     kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    table_load = table.occupancy() if table.kind == "hash" else None
     dominant = max(kern_ms, key=kern_ms.get)
     achieved = ALG_BYTES[dominant] * args.pairs / (kern_ms[dominant] * 1e-3) / 1e9
     traffic = None
@@ -212,7 +213,8 @@ def main():
                                    f"(2^{table.log2_slots} slots), TNF k=4 + abundance V=400 W=10, L1-normalise, VAE 536-512-512-32 encode",
                        "pairs_per_gpu": args.pairs, "barcodes_per_gpu": n_bc, "rows_per_gpu": len(rows),
                        "parallelism": f"run-sharded x{world}, table all-gather + LDS bucket merge ({args.backend})" if world > 1 else "single GPU",
-                       "input": "packed reads resident in HBM"},
+                       "input": "packed reads resident in HBM", "table_load": table_load,
+                       "table_buckets": table.n_buckets, "bucket_slots": 1 << table.log2_bucket if table.log2_bucket else None},
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
