@@ -149,7 +149,7 @@ def main():
         e[0].record()
         table.reset()                   # bucketed tables are overwritten slice by slice: no 4 GB clear
 
-        table.count(stream, check=False)
+        table.count(stream, check=False, rows=plan)
         e[1].record()
         pdist.exchange_table(table, check=False)
         e[2].record()

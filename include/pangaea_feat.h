@@ -138,17 +138,26 @@ typedef struct {
 int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
                   const pg_table *t, uint32_t *status, void *stream);
 
+/* Rows = barcode runs that yield an output row: sorted, disjoint character ranges of the stream (device arrays). */
+typedef struct {
+    const int64_t *row_start; /* device [n_rows] */
+    const int64_t *row_end;   /* device [n_rows] */
+    int64_t n_rows;           /* < 2^22 - 1 per launch */
+} pg_rows;
+
 /* The same result as pg_kmer_count for a bucketed hash table, without random HBM traffic: the k-mer
  * occurrences of the word range are hash-partitioned into the table's buckets by two streaming scatter
  * passes, each bucket is counted inside LDS by one workgroup and written back as its slice of the table.
  *   accumulate = 0: the table is taken to be empty and every slice is overwritten (no clearing needed);
  *   accumulate = 1: slices are loaded first, so counts add to what the table holds.
+ * rows (may be NULL): when given, every partition record also carries the index of the row its k-mer ends in,
+ * and the bucket-ordered records stay in the workspace for pg_abundance_from_records.
  * workspace: device scratch of pg_kmer_count_workspace_bytes(word_end - word_begin, t) bytes, 256-B aligned
  * (two record buffers of 8 B per character of the range + counters).  status as for pg_kmer_count:
  * [0] != 0 after synchronising means a bucket overflowed (PG_ETABLEFULL condition). */
 int64_t pg_kmer_count_workspace_bytes(int64_t n_words, const pg_table *t);
 int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
-                           const pg_table *t, int accumulate, void *workspace, int64_t workspace_bytes,
+                           const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
                            uint32_t *status, void *stream);
 
 /* Add n (code,count) pairs -- `pairs[i] = (code << 22) | count`, the slot format -- into a hash table:
@@ -175,6 +184,18 @@ int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,
                 const int32_t *seg_row, const int64_t *seg_start, const int64_t *seg_end, int64_t n_segs,
                 int k_tnf, const uint16_t *colmap, int32_t *tnf_out,
                 const pg_table *t, int window, int vsize, int32_t *abd_out, void *stream);
+
+/* The abundance matrix of pg_features WITHOUT random table reads (count_kmer.cpp:55-108 again): the records left in
+ * `count_workspace` by pg_kmer_count_bucketed(..., rows, ...) are looked up bucket by bucket in LDS copies of the
+ * table's slices (so `t` may meanwhile have been merged with other ranks' tables), turned into (row, bin) words,
+ * scattered back by groups of 64 rows and histogrammed in LDS.  abd_out [n_rows, vsize] is overwritten (no zero
+ * fill needed).  Requirements: the same `t` geometry, `rows` and word count as the counting call, one counting
+ * call since the table was last reset, vsize <= PG_SHUFFLE_MAX_VSIZE.  workspace: pg_abundance_workspace_bytes. */
+#define PG_SHUFFLE_MAX_VSIZE 512
+int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize);
+int pg_abundance_from_records(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
+                              const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                              void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Cache files.  Rows as the reference binaries print them: "<name>,v1,...,vD\n", numbers through

@@ -22,6 +22,8 @@ HASH_COUNT_SAT = 1 << 21
 TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
+SHUFFLE_MAX_VSIZE = 512
+MAX_ROWS = (1 << 22) - 2
 
 
 class PangaeaError(RuntimeError):
@@ -33,6 +35,10 @@ class PangaeaError(RuntimeError):
 class pg_table(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("log2_slots", C.c_int32), ("log2_bucket_slots", C.c_int32),
                 ("data", C.c_void_p)]
+
+
+class pg_rows(C.Structure):
+    _fields_ = [("row_start", C.c_void_p), ("row_end", C.c_void_p), ("n_rows", C.c_int64)]
 
 
 def build() -> None:
@@ -51,6 +57,7 @@ def load() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, cp = C.c_void_p, C.c_int64, C.c_int, C.c_char_p
     tp = C.POINTER(pg_table)
+    rp = C.POINTER(pg_rows)
     sig = {
         "pg_abi_version": (i32, []),
         "pg_last_error": (cp, []),
@@ -75,7 +82,9 @@ def load() -> C.CDLL:
         "pg_tnf_colmap": (i32, [i32, vp, vp]),
         "pg_kmer_count": (i32, [vp, vp, i64, i64, tp, vp, vp]),
         "pg_kmer_count_workspace_bytes": (i64, [i64, tp]),
-        "pg_kmer_count_bucketed": (i32, [vp, vp, i64, i64, tp, i32, vp, i64, vp, vp]),
+        "pg_kmer_count_bucketed": (i32, [vp, vp, i64, i64, tp, i32, rp, vp, i64, vp, vp]),
+        "pg_abundance_workspace_bytes": (i64, [i64, i64, i32]),
+        "pg_abundance_from_records": (i32, [tp, rp, i32, i32, vp, vp, i64, i64, vp, i64, vp]),
         "pg_kmer_merge": (i32, [vp, i64, tp, vp, vp]),
         "pg_kmer_merge_bucketed": (i32, [vp, vp, i32, tp, vp, vp]),
         "pg_features": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp, vp, tp, i32, i32, vp, vp]),
@@ -95,7 +104,8 @@ EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fast
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
            "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
            "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_count_workspace_bytes",
-           "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed",
+           "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed", "pg_abundance_workspace_bytes",
+           "pg_abundance_from_records",
            "pg_features", "pg_write_csv_gz", "pg_extract_reads"]
 
 

@@ -1,9 +1,10 @@
 // kernels.hip -- gfx950 kernels of the barcode k-mer feature path + their C-ABI launchers.
 //
 // Replaces (reference file:line, /root/reference/src):
-//   K2  pg_kmer_count*  jellyfish count -C (feature.py:94) + dump reload (cpptools/count_kmer.cpp:139-170)
-//   K1  pg_features/tnf cpptools/count_tnf.cpp:78-113  (per-run canonical k_tnf-mer counts)
-//   K3  pg_features/abd cpptools/count_kmer.cpp:55-108 (per-run histogram of global multiplicities)
+//   K2  pg_kmer_count*            jellyfish count -C (feature.py:94) + dump reload (cpptools/count_kmer.cpp:139-170)
+//   K1  pg_features / tnf         cpptools/count_tnf.cpp:78-113  (per-run canonical k_tnf-mer counts)
+//   K3  pg_features / abd         cpptools/count_kmer.cpp:55-108 (per-run histogram of global multiplicities), by table lookups
+//       pg_abundance_from_records the same rows without random HBM reads, from the partitioned occurrence records
 //
 // Work decomposition (wave64):
 //   * the read stream is 2-bit codes + 1-bit validity, 32 characters per word (include/pangaea_feat.h);
@@ -15,12 +16,16 @@
 //   * integer counting only: LDS histograms / LDS hash tables, global atomics only where unavoidable.
 //     No MFMA -- there is no contraction on this path.
 //
-// Two ways to build the hash table:
-//   direct    (kmer_count_kernel)   one random 64-B line + one memory-side atomic per k-mer occurrence;
-//   bucketed  (pg_kmer_count_bucketed) occurrences are hash-partitioned with two streaming scatter passes
-//             (<= 256-way then <= 512-way, LDS-staged so HBM sees whole runs), every final bucket is then
-//             counted inside LDS by one workgroup and its LDS image is written back as that bucket's slice
-//             of the table.  HBM only sees streaming traffic; all counting atomics are LDS atomics.
+// Hash table building, two ways:
+//   direct    (kmer_count_kernel)      one random 64-B line + one memory-side atomic per k-mer occurrence;
+//   bucketed  (pg_kmer_count_bucketed) occurrences are hash-partitioned by two streaming scatter passes (LDS-staged so
+//             HBM sees whole runs), every bucket is then counted inside LDS by one workgroup and its LDS image is
+//             written back as that bucket's slice of the table.  HBM only sees streams; counting atomics are LDS atomics.
+// Abundance rows, two ways:
+//   lookups   (features_kernel)        one random 64-B line per k-mer occurrence;
+//   shuffle   (pg_abundance_from_records) the partition records carry their row id; every bucket's slice is loaded into
+//             LDS, each record's count becomes a (row, bin) word, the words are scattered back by row group (two passes)
+//             and histogrammed in LDS.  Again only streams.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,16 +36,11 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
+constexpr int BIG_BLOCK = 1024;           // one workgroup per CU kernels (LDS-resident tables / histograms)
 constexpr uint32_t HASH_CBITS = PG_HASH_COUNT_BITS;
 constexpr uint64_t HASH_CMASK = (1ull << HASH_CBITS) - 1;
 constexpr uint32_t HASH_SAT = PG_HASH_COUNT_SAT;
 constexpr uint32_t MAX_PROBE = 1u << 14;
-constexpr uint32_t PRIMARY_PROBES = 32;   // slots tried from the minimizer home before the k-mer's own hash takes over
-constexpr int MINI_W = 7;                 // m-mers per k-mer in the minimizer window: w = min(7, k), m = k - w + 1
-#ifndef PG_PLACEMENT_MINIMIZER
-#define PG_PLACEMENT_MINIMIZER 0
-#endif
-constexpr bool MINIMIZER = PG_PLACEMENT_MINIMIZER != 0;   // 0: home = uniform hash of the k-mer (no locality)
 
 enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2 };
 
@@ -52,46 +52,20 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     return x;
 }
 
-__device__ __forceinline__ uint32_t mix32(uint32_t x)
-{
-    x ^= x >> 16; x *= 0x85ebca6bu;
-    x ^= x >> 13; x *= 0xc2b2ae35u;
-    x ^= x >> 16;
-    return x;
-}
-
-// Home slot (log2_slots bits) of a k-mer.  MINIMIZER placement: the 64-B line (8 slots) is chosen by the k-mer's
-// minimizer, the slot inside the line by the k-mer's own code, so the ~w consecutive k-mers of a read that share a
-// minimizer sit in ONE line and mostly in different slots of it.
-__device__ __forceinline__ uint64_t home_slot(uint32_t min_order, uint64_t code, int log2_slots)
-{
-    if (MINIMIZER)
-        return ((((uint64_t)min_order * 0x9E3779B97F4A7C15ull) >> (64 - log2_slots)) & ~7ull) | ((code * 0x9E3779B97F4A7C15ull) >> 61);
-    return mix64(code) >> (64 - log2_slots);
-}
-
-// Hash table as the kernels see it: 2^log2_slots slots in buckets of 2^log2_bucket slots.
-// PLACEMENT (shared by every kernel, the LDS tables included):
-//   home   = home_slot(min over the k-mer's w canonical m-mers of mix32(m-mer), code): line by minimizer, slot in
-//            the line by the code.  Consecutive k-mers of a read mostly share their minimizer, hence their line:
-//            a lookup stream walks the table supermer by supermer instead of touching one random line per k-mer.
-//   probe  = PRIMARY_PROBES consecutive slots from home (wrapping inside the bucket), then consecutive slots from
-//            (mix64(code) mod bucket) in the same bucket: crowded minimizers spill to uniformly hashed places.
-//   Slots are never freed, so a lookup may stop at the first empty slot of the sequence.
+// hash table as the kernels see it: 2^log2_slots slots in buckets of 2^log2_bucket slots; a key's home slot is the
+// top log2_slots bits of mix64(code), probing is linear and wraps inside the bucket.  Slots are never freed, so a
+// lookup may stop at the first empty slot.
 struct HashView {
     uint64_t *slots;
     int log2_slots;
     int log2_bucket;
-    __device__ __forceinline__ uint64_t bmask() const { return (1ull << log2_bucket) - 1; }
-    __device__ __forceinline__ uint32_t primary() const { return log2_bucket < 5 ? (1u << log2_bucket) : PRIMARY_PROBES; }
-    __device__ __forceinline__ uint32_t limit() const { return primary() + (log2_bucket < 14 ? (1u << log2_bucket) : MAX_PROBE); }
-    // slot after `s`, `i` = number of slots already tried (i >= 1)
-    __device__ __forceinline__ uint64_t next(uint64_t s, uint32_t i, uint64_t code) const
+    __device__ __forceinline__ uint64_t home(uint64_t code) const { return mix64(code) >> (64 - log2_slots); }
+    __device__ __forceinline__ uint64_t next(uint64_t s) const
     {
-        const uint64_t bm = bmask();
-        const uint64_t in = i == primary() ? (mix64(code) & bm) : ((s + 1) & bm);
-        return (s & ~bm) | in;
+        const uint64_t bm = (1ull << log2_bucket) - 1;
+        return (s & ~bm) | ((s + 1) & bm);
     }
+    __device__ __forceinline__ uint32_t limit() const { return log2_bucket < 14 ? (1u << log2_bucket) : MAX_PROBE; }
 };
 
 // bit p of the result is set iff bits p-k+1..p of m are all set (1 <= k <= 32): which positions of the
@@ -110,71 +84,42 @@ template <typename KT> __device__ __forceinline__ KT low_mask(int k)
     return (2 * k >= (int)(8 * sizeof(KT))) ? (KT)~(KT)0 : (KT)(((KT)1 << (2 * k)) - 1);
 }
 
-// Rolling state of one lane: forward / reverse-complement code of the last k characters and, when MINI, the
-// order values of the last w canonical m-mers (a shift register: no dynamic register indexing).
-template <typename KT, bool MINI> struct Roller {
+// rolling state of one lane: forward / reverse-complement code of the last k characters
+template <typename KT> struct Roller {
     KT fw, rc, kmask;
-    uint32_t mmask, o0, o1, o2, o3, o4, o5, o6;
-    int rc_shift, rcm_shift, w;
-
+    int rc_shift;
     __device__ __forceinline__ void init(int k)
     {
         fw = rc = 0;
         kmask = low_mask<KT>(k);
         rc_shift = 2 * (k - 1);
-        w = k < MINI_W ? k : MINI_W;
-        const int m = k - w + 1;
-        mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
-        rcm_shift = 2 * (k - m);
-        o0 = o1 = o2 = o3 = o4 = o5 = o6 = 0xffffffffu;
     }
     __device__ __forceinline__ void push(uint32_t c)
     {
         fw = (KT)(fw << 2) | (KT)c;
         rc = (KT)(rc >> 2) | (KT)((KT)(c ^ 2u) << rc_shift);
-        if (MINI) {
-            const uint32_t a = (uint32_t)fw & mmask;
-            const uint32_t b = (uint32_t)(rc >> rcm_shift);
-            o6 = o5; o5 = o4; o4 = o3; o3 = o2; o2 = o1; o1 = o0;
-            o0 = mix32(a < b ? a : b);
-        }
     }
     __device__ __forceinline__ KT canon() const
     {
         const KT f = fw & kmask;
         return f < rc ? f : rc;
     }
-    __device__ __forceinline__ uint64_t slot(int log2_slots) const { return home_slot(min_order(), (uint64_t)canon(), log2_slots); }
-    __device__ __forceinline__ uint32_t min_order() const
-    {
-        if (!MINI) return 0;
-        uint32_t mn = o0;
-        if (w > 1) mn = min(mn, o1);
-        if (w > 2) mn = min(mn, o2);
-        if (w > 3) mn = min(mn, o3);
-        if (w > 4) mn = min(mn, o4);
-        if (w > 5) mn = min(mn, o5);
-        if (w > 6) mn = min(mn, o6);
-        return mn;
-    }
 };
 
-// the same home slot from a canonical code alone (merge path; not hot)
-__device__ uint64_t slot_of_code(uint64_t code, int k, int log2_slots)
+// word w of the stream, the word before it, and the mask of its positions that end a valid k-mer
+struct Word {
+    uint64_t cw, pw;
+    uint32_t ok;
+};
+__device__ __forceinline__ Word load_word(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, int64_t w, int k)
 {
-    if (!MINIMIZER) return home_slot(0, code, log2_slots);
-    const int w = k < MINI_W ? k : MINI_W;
-    const int m = k - w + 1;
-    const uint32_t mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
-    uint64_t rck = 0, x = code;
-    for (int i = 0; i < k; ++i) { rck = (rck << 2) | ((x & 3) ^ 2); x >>= 2; }
-    uint32_t mn = 0xffffffffu;
-    for (int i = 0; i < w; ++i) {
-        const uint32_t a = (uint32_t)(code >> (2 * (w - 1 - i))) & mmask;
-        const uint32_t b = (uint32_t)(rck >> (2 * i)) & mmask;
-        mn = min(mn, mix32(a < b ? a : b));
-    }
-    return home_slot(mn, code, log2_slots);
+    Word x;
+    x.cw = codes[w];
+    const uint32_t vw = valid[w];
+    x.pw = w > 0 ? codes[w - 1] : 0;
+    const uint32_t pv = w > 0 ? valid[w - 1] : 0;
+    x.ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
+    return x;
 }
 
 // -------------------------------------------------------------------------------- table access
@@ -186,7 +131,7 @@ __device__ __forceinline__ void dense_add(uint32_t *table, uint32_t code) { atom
 __device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, uint32_t *status)
 {
     const uint32_t limit = t.limit();
-    for (uint32_t i = 1; i <= limit; ++i) {
+    for (uint32_t i = 0; i < limit; ++i) {
         if (cur == 0) {
             cur = atomicCAS((unsigned long long *)&t.slots[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
             if (cur == 0) return;
@@ -196,7 +141,7 @@ __device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uin
             if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd((unsigned long long *)&t.slots[s], 1ull);
             return;
         }
-        s = t.next(s, i, code);
+        s = t.next(s);
         cur = t.slots[s];
     }
     atomicOr(status, 1u);
@@ -205,10 +150,10 @@ __device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uin
 __device__ __forceinline__ uint32_t hash_probe(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, bool *found)
 {
     const uint32_t limit = t.limit();
-    for (uint32_t i = 1; i <= limit; ++i) {
+    for (uint32_t i = 0; i < limit; ++i) {
         if (cur == 0) break;
         if ((cur >> HASH_CBITS) == code) { *found = true; return (uint32_t)(cur & HASH_CMASK); }
-        s = t.next(s, i, code);
+        s = t.next(s);
         cur = t.slots[s];
     }
     *found = false;
@@ -223,15 +168,11 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
                                                            HashView t, uint32_t *status)
 {
     for (int64_t w = word_begin + (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * BLOCK) {
-        const uint64_t cw = codes[w];
-        const uint32_t vw = valid[w];
-        const uint64_t pw = w > 0 ? codes[w - 1] : 0;
-        const uint32_t pv = w > 0 ? valid[w - 1] : 0;
-        const uint32_t ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
-        if (ok == 0) continue;
-        Roller<KT, TK == TK_HASH && MINIMIZER> r;
+        const Word x = load_word(codes, valid, w, k);
+        if (x.ok == 0) continue;
+        Roller<KT> r;
         r.init(k);
-        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
+        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(x.pw >> (2 * i)) & 3u);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             KT canon[8];
@@ -240,13 +181,13 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = b * 8 + u;
-                r.push((uint32_t)(cw >> (2 * j)) & 3u);
+                r.push((uint32_t)(x.cw >> (2 * j)) & 3u);
                 canon[u] = r.canon();
-                if ((ok >> j) & 1) {
+                if ((x.ok >> j) & 1) {
                     if (TK == TK_DENSE) {
                         dense_add(dense, (uint32_t)canon[u]);
                     } else {                       // issue the first probe of the whole batch before resolving any
-                        hh[u] = r.slot(t.log2_slots);
+                        hh[u] = t.home((uint64_t)canon[u]);
                         cur[u] = t.slots[hh[u]];
                     }
                 }
@@ -254,14 +195,14 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
             if (TK == TK_HASH) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if ((ok >> (b * 8 + u)) & 1) hash_add_from(t, hh[u], cur[u], (uint64_t)canon[u], status);
+                    if ((x.ok >> (b * 8 + u)) & 1) hash_add_from(t, hh[u], cur[u], (uint64_t)canon[u], status);
             }
         }
     }
 }
 
 // merge (code,count) pairs of another table; counts saturate at SAT exactly (CAS loop; not a hot path)
-__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, int k, HashView t, uint32_t *status)
+__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, HashView t, uint32_t *status)
 {
     const uint32_t limit = t.limit();
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
@@ -270,9 +211,9 @@ __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__res
         const uint64_t code = p >> HASH_CBITS;
         uint32_t add = (uint32_t)(p & HASH_CMASK);
         if (add > HASH_SAT) add = HASH_SAT;
-        uint64_t s = slot_of_code(code, k, t.log2_slots);
+        uint64_t s = t.home(code);
         bool done = false;
-        for (uint32_t tries = 1; tries <= limit && !done; ++tries) {
+        for (uint32_t tries = 0; tries < limit && !done; ++tries) {
             uint64_t cur = __hip_atomic_load(&t.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {
                 if (cur != 0 && (cur >> HASH_CBITS) != code) break;          // occupied by another key
@@ -283,81 +224,91 @@ __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__res
                 if (old == cur) { done = true; break; }
                 cur = old;
             }
-            s = t.next(s, tries, code);
+            s = t.next(s);
         }
         if (!done) atomicOr(status, 1u);
     }
 }
 
-// -------------------------------------------------------------------------------- K2 bucketed: partition + LDS counting
+// -------------------------------------------------------------------------------- partition machinery
 //
-// record = canonical code (42 bits) | hfield << 42, hfield = the placement-hash bits that are still needed after the
-// first scatter pass: the (log2_slots - bits1) bits below the level-1 digit, i.e. [level-2 digit | slot in bucket].
-// The scatter-2 and bucket-count kernels therefore never hash: they read their digit / slot out of the record.
+// occurrence record = canonical code (low 42 bits) | row id << 42 (22 bits, ROW_NONE = not inside any row)
 
-constexpr int HIST_BLOCK = 1024;
 constexpr int TILE0 = 8192;           // records per stream tile: 256 lanes x 32 characters
-constexpr int REC_PER_LANE = 16;      // scatter pass 2: records a lane keeps in registers
+constexpr int REC_PER_LANE = 16;      // record scatter passes: records a lane keeps in registers
 constexpr int TILE1 = BLOCK * REC_PER_LANE;
 constexpr int MAX_FAN_BITS = 9;       // <= 512-way scatter per pass
 constexpr int REC_KEY_BITS = 42;
 constexpr uint64_t REC_KEY_MASK = (1ull << REC_KEY_BITS) - 1;
+constexpr uint32_t ROW_NONE = (1u << (64 - REC_KEY_BITS)) - 1;
+constexpr int GROUP_ROWS_LOG2 = 6;    // rows per LDS row-histogram group (64 x 512 bins x 4 B = 128 KiB at most)
 
-// A0: histogram of final bucket ids (top `bits` bits of the placement hash) over every valid k-mer of the word range
-__global__ __launch_bounds__(HIST_BLOCK) void bucket_hist_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                                 int64_t word_begin, int64_t word_end, int k, int log2_slots, int bits,
-                                                                 uint32_t bin_base, int n_bins, unsigned long long *__restrict__ hist)
+// first row whose end lies beyond the first character of each 256-word tile (rows sorted, disjoint)
+__global__ __launch_bounds__(BLOCK) void tile_rows_kernel(const int64_t *__restrict__ row_end, int64_t n_rows, int64_t word_begin,
+                                                          int64_t n_tiles, int32_t *__restrict__ tile_row)
 {
-    // one launch covers the bins [bin_base, bin_base + n_bins) (n_bins <= 2^15: 128 KiB of LDS counters); tables
-    // with more buckets take several launches over the stream
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t c0 = (word_begin + t * BLOCK) * 32;
+    int64_t lo = 0, hi = n_rows;                                    // first r with row_end[r] > c0
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (row_end[mid] > c0) hi = mid; else lo = mid + 1;
+    }
+    tile_row[t] = (int32_t)lo;
+}
+
+// A0: histogram of final bucket ids (top `bits` bits of the hash) over every valid k-mer of the word range; one launch
+// covers the bins [bin_base, bin_base + n_bins) (n_bins <= 2^15: 128 KiB of LDS counters)
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_hist_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                                int64_t word_begin, int64_t word_end, int k, int bits,
+                                                                uint32_t bin_base, int n_bins, unsigned long long *__restrict__ hist)
+{
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK) lds[i] = 0;
+    for (int i = threadIdx.x; i < n_bins; i += BIG_BLOCK) lds[i] = 0;
     __syncthreads();
-    for (int64_t w = word_begin + (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * HIST_BLOCK) {
-        const uint64_t cw = codes[w];
-        const uint32_t vw = valid[w];
-        const uint64_t pw = w > 0 ? codes[w - 1] : 0;
-        const uint32_t pv = w > 0 ? valid[w - 1] : 0;
-        const uint32_t ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
-        if (ok == 0) continue;
-        Roller<uint64_t, MINIMIZER> r;
+    const int sh = 64 - bits;
+    for (int64_t w = word_begin + (int64_t)blockIdx.x * BIG_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * BIG_BLOCK) {
+        const Word x = load_word(codes, valid, w, k);
+        if (x.ok == 0) continue;
+        Roller<uint64_t> r;
         r.init(k);
-        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
+        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(x.pw >> (2 * i)) & 3u);
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            r.push((uint32_t)(cw >> (2 * j)) & 3u);
-            if ((ok >> j) & 1) {
-                const uint32_t bin = (uint32_t)(r.slot(log2_slots) >> (log2_slots - bits)) - bin_base;
+            r.push((uint32_t)(x.cw >> (2 * j)) & 3u);
+            if ((x.ok >> j) & 1) {
+                const uint32_t bin = (uint32_t)(mix64(r.canon()) >> sh) - bin_base;
                 if (bin < (uint32_t)n_bins) atomicAdd(&lds[bin], 1u);
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_bins; i += HIST_BLOCK)
+    for (int i = threadIdx.x; i < n_bins; i += BIG_BLOCK)
         if (lds[i]) atomicAdd(&hist[bin_base + i], (unsigned long long)lds[i]);
 }
 
-// exclusive prefix sum of hist[n] -> off[n+1] (one workgroup; n <= 2^17)
-__global__ __launch_bounds__(HIST_BLOCK) void bucket_scan_kernel(const unsigned long long *__restrict__ hist, int n, unsigned long long *__restrict__ off)
+// exclusive prefix sum of hist[n] -> off[n+1] (one workgroup)
+__global__ __launch_bounds__(BIG_BLOCK) void scan_kernel(const unsigned long long *__restrict__ hist, int64_t n, unsigned long long *__restrict__ off)
 {
-    __shared__ unsigned long long part[HIST_BLOCK];
-    const int per = (n + HIST_BLOCK - 1) / HIST_BLOCK;
-    const int a = threadIdx.x * per, b = min(n, a + per);
+    __shared__ unsigned long long part[BIG_BLOCK];
+    const int64_t per = (n + BIG_BLOCK - 1) / BIG_BLOCK;
+    const int64_t a = threadIdx.x * per, b = a + per < n ? a + per : n;
     unsigned long long s = 0;
-    for (int i = a; i < b; ++i) s += hist[i];
+    for (int64_t i = a; i < b; ++i) s += hist[i];
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long run = 0;
-        for (int i = 0; i < HIST_BLOCK; ++i) { unsigned long long v = part[i]; part[i] = run; run += v; }
+        for (int i = 0; i < BIG_BLOCK; ++i) { unsigned long long v = part[i]; part[i] = run; run += v; }
         off[n] = run;
     }
     __syncthreads();
     unsigned long long run = part[threadIdx.x];
-    for (int i = a; i < b; ++i) { off[i] = run; run += hist[i]; }
+    for (int64_t i = a; i < b; ++i) { off[i] = run; run += hist[i]; }
 }
 
-// LDS bookkeeping shared by both scatter passes
+// LDS bookkeeping shared by the scatter passes
 struct ScatterLds {
     uint32_t cnt[1 << MAX_FAN_BITS];
     uint32_t start[(1 << MAX_FAN_BITS) + 1];
@@ -391,16 +342,18 @@ __device__ __forceinline__ void scatter_scan(ScatterLds &L, int n_dig)
 // A1: stream -> 2^bits1 regions.  A lane keeps the <= 32 records of its word in registers; one returning LDS atomic
 // per record yields its rank inside its digit, the tile is then laid out digit-sorted in LDS and every digit's run
 // is appended to its region with one global cursor add, so HBM receives contiguous runs.
+// With rows given, every record also carries the index of the row its k-mer ends in (ROW_NONE outside all rows).
 __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                               int64_t word_begin, int64_t word_end, int k, int log2_slots, int bits1,
+                                                               int64_t word_begin, int64_t word_end, int k, int bits1,
+                                                               const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end,
+                                                               int64_t n_rows, const int32_t *__restrict__ tile_row,
                                                                uint64_t *__restrict__ rec_out, const unsigned long long *__restrict__ off,
                                                                unsigned long long *__restrict__ cursor, int off_shift)
 {
     __shared__ uint64_t buf[TILE0];
     __shared__ ScatterLds L;
     const int n_dig = 1 << bits1;
-    const int low_bits = log2_slots - bits1;                        // hfield width
-    const uint64_t low_mask64 = (1ull << low_bits) - 1;
+    const int dsh = 64 - bits1;
     const int64_t n_tiles = (word_end - word_begin + BLOCK - 1) / BLOCK;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt[i] = 0;
@@ -410,22 +363,34 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
         uint32_t ok = 0;
         const int64_t w = word_begin + tile * BLOCK + threadIdx.x;
         if (w < word_end) {
-            const uint64_t cw = codes[w];
-            const uint32_t vw = valid[w];
-            const uint64_t pw = w > 0 ? codes[w - 1] : 0;
-            const uint32_t pv = w > 0 ? valid[w - 1] : 0;
-            ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
+            const Word x = load_word(codes, valid, w, k);
+            ok = x.ok;
             if (ok) {
-                Roller<uint64_t, MINIMIZER> r;
-                r.init(k);
-                for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
+                // row bookkeeping: r = first row that can still contain a position >= the current one
+                int64_t r = n_rows, rs = INT64_MAX, re = INT64_MAX;
+                const int64_t pos0 = w << 5;
+                if (row_start) {
+                    r = tile_row[tile];
+                    while (r < n_rows && row_end[r] <= pos0) ++r;
+                    if (r < n_rows) { rs = row_start[r]; re = row_end[r]; }
+                }
+                Roller<uint64_t> rl;
+                rl.init(k);
+                for (int i = 33 - k; i < 32; ++i) rl.push((uint32_t)(x.pw >> (2 * i)) & 3u);
 #pragma unroll
                 for (int j = 0; j < 32; ++j) {
-                    r.push((uint32_t)(cw >> (2 * j)) & 3u);
+                    rl.push((uint32_t)(x.cw >> (2 * j)) & 3u);
                     if ((ok >> j) & 1) {
-                        const uint64_t g = r.slot(log2_slots);
-                        const uint32_t d = (uint32_t)(g >> low_bits);
-                        rec[j] = r.canon() | ((g & low_mask64) << REC_KEY_BITS);
+                        const int64_t pos = pos0 + j;
+                        while (pos >= re) {                         // rows are at least one character long: terminates
+                            ++r;
+                            rs = r < n_rows ? row_start[r] : INT64_MAX;
+                            re = r < n_rows ? row_end[r] : INT64_MAX;
+                        }
+                        const uint64_t row = pos >= rs ? (uint64_t)r : (uint64_t)ROW_NONE;
+                        const uint64_t code = rl.canon();
+                        const uint32_t d = (uint32_t)(mix64(code) >> dsh);
+                        rec[j] = code | (row << REC_KEY_BITS);
                         dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
                     }
                 }
@@ -449,65 +414,77 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
     }
 }
 
-// A2: region blockIdx.y of pass 1 -> its 2^bits2 final buckets.  Digit = top bits2 of the record's hfield.
-__global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const uint64_t *__restrict__ rec_in, uint64_t *__restrict__ rec_out,
-                                                                const unsigned long long *__restrict__ off,
-                                                                unsigned long long *__restrict__ cursor, int bits2, int log2_bucket)
+// Generic record scatter pass (A2, S2a, S2b).  Region = blockIdx.x / tiles_x; its input records are
+//   [in_begin[region << in_shift], in_cnt ? begin + in_cnt[region] : in_end[region << in_shift]).
+// Digit: DIG_HASH -> (mix64(key) >> dshift) & mask;  DIG_ROW -> (word >> dshift) & mask of a 32-bit (row, bin) word.
+// Destination of digit d: out[obase[(base + d) << oshift] + cursor[base + d] ...], base = flat ? 0 : region << dbits.
+enum { DIG_HASH = 0, DIG_ROW = 1 };
+template <typename REC, int DIG>
+__global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__restrict__ rec_in,
+                                                                const unsigned long long *__restrict__ in_begin,
+                                                                const unsigned long long *__restrict__ in_end, int in_shift,
+                                                                const unsigned long long *__restrict__ in_cnt, int tiles_x,
+                                                                REC *__restrict__ rec_out, const unsigned long long *__restrict__ obase,
+                                                                unsigned long long *__restrict__ cursor, int oshift, int flat,
+                                                                int dbits, int dshift)
 {
-    __shared__ uint64_t buf[TILE1];
+    __shared__ REC buf[TILE1];
     __shared__ ScatterLds L;
-    const int n_dig = 1 << bits2;
-    const int region = blockIdx.y;
-    const int64_t base_index = (int64_t)region << bits2;
-    const int64_t r0 = (int64_t)off[base_index], r1 = (int64_t)off[base_index + n_dig];
+    const int n_dig = 1 << dbits;
+    const uint32_t dmask = (uint32_t)n_dig - 1u;
+    const int64_t region = blockIdx.x / tiles_x;
+    const int64_t base_index = flat ? 0 : (region << dbits);
+    const int64_t r0 = (int64_t)in_begin[region << in_shift];
+    const int64_t r1 = in_cnt ? r0 + (int64_t)in_cnt[region] : (int64_t)in_end[region << in_shift];
     const int64_t n_tiles = (r1 - r0 + TILE1 - 1) / TILE1;
-    const int dshift = REC_KEY_BITS + log2_bucket;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    auto digit_of = [&](REC r) -> uint32_t {
+        if (DIG == DIG_HASH) return (uint32_t)(mix64((uint64_t)r & REC_KEY_MASK) >> dshift) & dmask;
+        return ((uint32_t)r >> dshift) & dmask;
+    };
+    for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
         for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt[i] = 0;
         __syncthreads();
         const int64_t t0 = r0 + tile * TILE1;
-        uint64_t rec[REC_PER_LANE];
+        REC rec[REC_PER_LANE];
         uint32_t dr[REC_PER_LANE];
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {                    // all loads of the lane in flight together
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
-            rec[j] = i < r1 ? rec_in[i] : ~0ull;
+            rec[j] = i < r1 ? rec_in[i] : (REC)0;
         }
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) {
-                const uint32_t d = (uint32_t)(rec[j] >> dshift);
+                const uint32_t d = digit_of(rec[j]);
                 dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
             }
         }
         __syncthreads();
         scatter_scan(L, n_dig);
         for (int d = threadIdx.x; d < n_dig; d += BLOCK)
-            if (L.cnt[d]) L.gbase[d] = off[base_index + d] + atomicAdd(&cursor[base_index + d], (unsigned long long)L.cnt[d]);
+            if (L.cnt[d]) L.gbase[d] = obase[(base_index + d) << oshift] + atomicAdd(&cursor[base_index + d], (unsigned long long)L.cnt[d]);
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
         }
         __syncthreads();
-        const uint32_t total = L.start[n_dig];
-        for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {
-            const uint64_t r = buf[i];
-            const uint32_t d = (uint32_t)(r >> dshift);
-            rec_out[L.gbase[d] + (i - L.start[d])] = r;
+        for (int d = threadIdx.x >> 6; d < n_dig; d += WAVES) {
+            const uint32_t a0 = L.start[d], c = L.start[d + 1] - a0;
+            const unsigned long long g0 = L.gbase[d];
+            for (uint32_t i = threadIdx.x & 63; i < c; i += 64) rec_out[g0 + i] = buf[a0 + i];
         }
         __syncthreads();
     }
 }
 
 // insert one record into the LDS table, starting from an already fetched first slot; false = table full
-__device__ __forceinline__ bool lds_insert(unsigned long long *tab, uint32_t smask, uint32_t primary, uint32_t limit,
-                                           uint64_t rec, uint32_t s, unsigned long long cur)
+__device__ __forceinline__ bool lds_insert(unsigned long long *tab, uint32_t smask, uint32_t limit,
+                                           uint64_t code, bool live, uint32_t s, unsigned long long cur)
 {
-    if (rec == ~0ull) return true;                                  // padding lane of the last batch
-    const uint64_t code = rec & REC_KEY_MASK;
-    for (uint32_t i = 1; i <= limit; ++i) {
+    if (!live) return true;                                         // padding lane of the last batch
+    for (uint32_t i = 0; i < limit; ++i) {
         if (cur == 0) {
             cur = atomicCAS(&tab[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
             if (cur == 0) return true;
@@ -516,51 +493,55 @@ __device__ __forceinline__ bool lds_insert(unsigned long long *tab, uint32_t sma
             if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
             return true;
         }
-        s = i == primary ? (uint32_t)(mix64(code) & smask) : ((s + 1) & smask);
+        s = (s + 1) & smask;
         cur = tab[s];
     }
     return false;
 }
 
 // B: one workgroup per final bucket.  The bucket's slice of the table (2^log2_bucket slots) lives in LDS while the
-// bucket's records stream through (8 loads per lane in flight); the LDS image is then written back as the slice.
-constexpr int CNT_BATCH = 8;               // PG_RESOLVE below is written for exactly 8
-__global__ __launch_bounds__(HIST_BLOCK) void bucket_count_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
-                                                                  HashView t, int accumulate, uint32_t *status)
+// bucket's records stream through (8 loads per lane in flight, first LDS probes of a batch issued back to back);
+// the LDS image is then written back as the slice.
+constexpr int CNT_BATCH = 8;               // the resolve macros below are written for exactly 8
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                 HashView t, int accumulate, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
-    const uint32_t primary = t.primary(), limit = t.limit();
+    const uint32_t limit = t.limit();
+    const int hsh = 64 - t.log2_slots;
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
     if (r0 == r1 && accumulate) return;                         // nothing to add, slice stays as it is
-    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) tab[i] = accumulate ? slice[i] : 0ull;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = accumulate ? slice[i] : 0ull;
     __syncthreads();
     bool full = false;
-    for (int64_t base = r0; base < r1; base += (int64_t)HIST_BLOCK * CNT_BATCH) {
+    for (int64_t base = r0; base < r1; base += (int64_t)BIG_BLOCK * CNT_BATCH) {
         uint64_t rr[CNT_BATCH];
+        bool live[CNT_BATCH];
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
-            const int64_t i = base + (int64_t)j * HIST_BLOCK + threadIdx.x;
-            rr[j] = i < r1 ? rec[i] : ~0ull;
+            const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            live[j] = i < r1;
+            rr[j] = live[j] ? rec[i] & REC_KEY_MASK : 0ull;
         }
         uint32_t ss[CNT_BATCH];
         unsigned long long first[CNT_BATCH];
 #pragma unroll
-        for (int j = 0; j < CNT_BATCH; ++j) {                       // first probes of the batch issued back to back
-            ss[j] = (uint32_t)(rr[j] >> REC_KEY_BITS) & smask;
-            first[j] = rr[j] == ~0ull ? 0ull : tab[ss[j]];
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            ss[j] = (uint32_t)(mix64(rr[j]) >> hsh) & smask;
+            first[j] = live[j] ? tab[ss[j]] : 0ull;
         }
         // resolved one by one, written out by hand: an unrolled loop around the probe loop is not unrolled by hipcc and
         // would push the batch arrays into scratch
-#define PG_RESOLVE(J) full |= !lds_insert(tab, smask, primary, limit, rr[J], ss[J], first[J]);
+#define PG_RESOLVE(J) full |= !lds_insert(tab, smask, limit, rr[J], live[J], ss[J], first[J]);
         PG_RESOLVE(0) PG_RESOLVE(1) PG_RESOLVE(2) PG_RESOLVE(3) PG_RESOLVE(4) PG_RESOLVE(5) PG_RESOLVE(6) PG_RESOLVE(7)
 #undef PG_RESOLVE
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) slice[i] = tab[i];
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
 }
 
 // Bucket-wise merge of other tables into this one: the compacted tables of the other ranks arrive bucket by bucket
@@ -568,31 +549,32 @@ __global__ __launch_bounds__(HIST_BLOCK) void bucket_count_kernel(const uint64_t
 // into LDS, adds every foreign entry of that bucket (counts saturate exactly) and writes the slice back.
 //   pairs  : the foreign tables' occupied slots, concatenated part after part
 //   seg    : [n_parts][n_buckets + 1] offsets into `pairs` (absolute)
-__global__ __launch_bounds__(HIST_BLOCK) void bucket_merge_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
-                                                                  int n_parts, int k, HashView t, uint32_t *status)
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
+                                                                 int n_parts, HashView t, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
-    const uint32_t primary = t.primary(), limit = t.limit();
+    const uint32_t limit = t.limit();
+    const int hsh = 64 - t.log2_slots;
     const int64_t n_buckets = (int64_t)1 << (t.log2_slots - t.log2_bucket);
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     int64_t total = 0;
     for (int p = 0; p < n_parts; ++p) total += seg[p * (n_buckets + 1) + blockIdx.x + 1] - seg[p * (n_buckets + 1) + blockIdx.x];
     if (total == 0) return;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) tab[i] = slice[i];
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = slice[i];
     __syncthreads();
     bool full = false;
     for (int p = 0; p < n_parts; ++p) {
         const int64_t a = seg[p * (n_buckets + 1) + blockIdx.x], b = seg[p * (n_buckets + 1) + blockIdx.x + 1];
-        for (int64_t i = a + threadIdx.x; i < b; i += HIST_BLOCK) {
+        for (int64_t i = a + threadIdx.x; i < b; i += BIG_BLOCK) {
             const uint64_t e = pairs[i];
             const uint64_t code = e >> HASH_CBITS;
             uint32_t add = (uint32_t)(e & HASH_CMASK);
             if (add > HASH_SAT) add = HASH_SAT;
-            uint32_t s = (uint32_t)slot_of_code(code, k, t.log2_slots) & smask;
+            uint32_t s = (uint32_t)(mix64(code) >> hsh) & smask;
             bool done = false;
-            for (uint32_t tries = 1; tries <= limit && !done; ++tries) {
+            for (uint32_t tries = 0; tries < limit && !done; ++tries) {
                 unsigned long long cur = tab[s];
                 for (;;) {
                     if (cur != 0 && (cur >> HASH_CBITS) != code) break;
@@ -603,17 +585,127 @@ __global__ __launch_bounds__(HIST_BLOCK) void bucket_merge_kernel(const uint64_t
                     if (old == cur) { done = true; break; }
                     cur = old;
                 }
-                s = tries == primary ? (uint32_t)(mix64(code) & smask) : ((s + 1) & smask);
+                s = (s + 1) & smask;
             }
             full |= !done;
         }
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_slots; i += HIST_BLOCK) slice[i] = tab[i];
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
 }
 
-// -------------------------------------------------------------------------------- K1 + K3: per-run rows
+// -------------------------------------------------------------------------------- K3 by shuffle
+
+// count of one record's code in the LDS copy of its bucket slice, starting from an already fetched first slot
+__device__ __forceinline__ uint32_t lds_lookup(const unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code,
+                                               uint32_t s, unsigned long long cur, bool *found)
+{
+    for (uint32_t i = 0; i < limit; ++i) {
+        if (cur == 0) break;
+        if ((cur >> HASH_CBITS) == code) { *found = true; return (uint32_t)(cur & HASH_CMASK); }
+        s = (s + 1) & smask;
+        cur = tab[s];
+    }
+    *found = false;
+    return 0;
+}
+
+// S1: one workgroup per bucket: the (final, possibly merged) slice is loaded into LDS and every record of the bucket
+// that lies inside a row becomes the 32-bit word (row << vbits | count / window) if that bin is < vsize.  Words are
+// packed at the front of the bucket's record range (order irrelevant); emit_end[b] = one past the last word.
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                  HashView t, uint32_t window, uint32_t vsize, int vbits,
+                                                                  uint32_t *__restrict__ words, unsigned long long *__restrict__ emit_end)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ uint32_t emitted;
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = 64 - t.log2_slots;
+    const uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    if (threadIdx.x == 0) emitted = 0;
+    if (r0 == r1) { if (threadIdx.x == 0) emit_end[blockIdx.x] = (unsigned long long)r0; return; }
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = slice[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    for (int64_t base = r0; base < r1; base += (int64_t)BIG_BLOCK * CNT_BATCH) {
+        uint64_t rr[CNT_BATCH];
+        bool live[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            live[j] = i < r1;
+            rr[j] = live[j] ? rec[i] : ~0ull;                       // a padding lane carries ROW_NONE
+        }
+        uint32_t ss[CNT_BATCH];
+        unsigned long long first[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            live[j] = live[j] && (uint32_t)(rr[j] >> REC_KEY_BITS) != ROW_NONE;
+            ss[j] = (uint32_t)(mix64(rr[j] & REC_KEY_MASK) >> hsh) & smask;
+            first[j] = live[j] ? tab[ss[j]] : 0ull;
+        }
+#define PG_EMIT(J)                                                                                                          \
+        {                                                                                                                   \
+            bool found = false;                                                                                             \
+            uint32_t cnt = live[J] ? lds_lookup(tab, smask, limit, rr[J] & REC_KEY_MASK, ss[J], first[J], &found) : 0u;     \
+            const uint32_t bin = cnt / window;                                                                              \
+            const bool put = found && bin < vsize;                                                                          \
+            const unsigned long long m = __ballot(put);                                                                     \
+            if (m) {                                                                                                        \
+                const int leader = __ffsll((long long)m) - 1;                                                               \
+                uint32_t at = 0;                                                                                            \
+                if ((int)lane == leader) at = atomicAdd(&emitted, (uint32_t)__popcll(m));                                   \
+                at = __shfl(at, leader);                                                                                    \
+                if (put) words[r0 + at + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(rr[J] >> REC_KEY_BITS) << vbits) | bin; \
+            }                                                                                                               \
+        }
+        PG_EMIT(0) PG_EMIT(1) PG_EMIT(2) PG_EMIT(3) PG_EMIT(4) PG_EMIT(5) PG_EMIT(6) PG_EMIT(7)
+#undef PG_EMIT
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) emit_end[blockIdx.x] = (unsigned long long)r0 + emitted;
+}
+
+// capacity of every row group (64 rows): the rows' character counts bound their k-mer counts
+__global__ __launch_bounds__(BLOCK) void group_caps_kernel(const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end,
+                                                           int64_t n_rows, int64_t n_groups_padded, unsigned long long *__restrict__ caps)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= n_groups_padded) return;
+    unsigned long long c = 0;
+    for (int64_t r = g << GROUP_ROWS_LOG2; r < ((g + 1) << GROUP_ROWS_LOG2) && r < n_rows; ++r) c += (unsigned long long)(row_end[r] - row_start[r]);
+    caps[g] = c;
+}
+
+// S3: one workgroup per row group: LDS histogram [64 rows][vsize] of the group's (row, bin) words, written out as the
+// rows of the abundance matrix (plain stores: every row belongs to exactly one group)
+__global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const uint32_t *__restrict__ words, const unsigned long long *__restrict__ goff,
+                                                             const unsigned long long *__restrict__ gcnt, int vbits, uint32_t vsize,
+                                                             int64_t n_rows, int32_t *__restrict__ abd_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const int64_t g = blockIdx.x;
+    const int64_t row0 = g << GROUP_ROWS_LOG2;
+    const int64_t rows_here = n_rows - row0 < (1 << GROUP_ROWS_LOG2) ? n_rows - row0 : (1 << GROUP_ROWS_LOG2);
+    const uint32_t n_bins = (uint32_t)rows_here * vsize;
+    for (uint32_t i = threadIdx.x; i < n_bins; i += BIG_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const int64_t a = (int64_t)goff[g], b = a + (int64_t)gcnt[g];
+    const uint32_t bmask = (1u << vbits) - 1u;
+    for (int64_t i = a + threadIdx.x; i < b; i += BIG_BLOCK) {
+        const uint32_t e = words[i];
+        atomicAdd(&hist[((e >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e & bmask)], 1u);
+    }
+    __syncthreads();
+    int32_t *dst = abd_out + row0 * (int64_t)vsize;
+    for (uint32_t i = threadIdx.x; i < n_bins; i += BIG_BLOCK) dst[i] = (int32_t)hist[i];
+}
+
+// -------------------------------------------------------------------------------- K1 + K3 by lookups: per-run rows
 
 // LDS: abd_copies x [vsize] abundance bins, then tnf_copies x [4^k_tnf] raw k_tnf-mer bins
 // (one copy per wavefront while that fits comfortably, else one shared copy).
@@ -660,7 +752,7 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
         const uint32_t ok_a = do_abd ? (uint32_t)(runs_of(m, k) >> 32) & in_seg : 0u;
         if ((ok_t | ok_a) == 0) continue;
 
-        Roller<KT, TK == TK_HASH && MINIMIZER> r;
+        Roller<KT> r;
         r.init(kk);
         for (int i = 33 - kroll; i < 32; ++i) r.push((uint32_t)(pw >> (2 * i)) & 3u);
         // batches of 8 characters: roll, issue the table reads of the batch, then bin them
@@ -681,7 +773,7 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                         if (TK == TK_DENSE) {
                             cur[u] = dense[(uint32_t)canon[u]];
                         } else {
-                            hh[u] = r.slot(t.log2_slots);
+                            hh[u] = t.home((uint64_t)canon[u]);
                             // each table line is used once per launch: keep it out of the way of the stream (measured -2 %)
                             cur[u] = __builtin_nontemporal_load(&t.slots[hh[u]]);
                         }
@@ -772,11 +864,20 @@ HashView view_of(const pg_table *t)
     return v;
 }
 
+int raise_lds_limit(const void *kernel, size_t bytes, const char *who)
+{
+    if (bytes <= 64 * 1024) return PG_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+        return pg_fail(PG_EHIP, "%s: cannot raise the dynamic LDS limit", who);
+    return PG_OK;
+}
+
 // workspace carving of the bucketed counter
 struct BucketPlan {
     int bits, bits1, bits2;           // bucket id bits, split over the two scatter passes
-    int64_t cap;                      // record capacity of each of the two record buffers
-    size_t hist_off, off_off, cur1_off, cur2_off, bufa_off, bufb_off, total;
+    int64_t cap, n_tiles;             // record capacity of each record buffer; 256-word tiles of the range
+    size_t hist_off, off_off, cur1_off, cur2_off, tile_off, bufa_off, bufb_off, total;
+    size_t final_off() const { return bits2 ? bufb_off : bufa_off; }
 };
 
 int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
@@ -788,14 +889,11 @@ int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
     p->bits = t->log2_slots - t->log2_bucket_slots;
     if (p->bits < 1 || p->bits > PG_BUCKET_MAX_LOG2_BUCKETS)
         return pg_fail(PG_EINVAL, "bucketed counting needs 1 <= log2_slots - log2_bucket_slots <= %d (got %d)", PG_BUCKET_MAX_LOG2_BUCKETS, p->bits);
-    // first-level fan-out: 8 bits, 9 when the record's 22 spare bits could not hold the rest of the slot index
-    p->bits1 = p->bits < 8 ? p->bits : (t->log2_slots - 8 > 64 - REC_KEY_BITS ? 9 : 8);
-    if (p->bits1 > p->bits) p->bits1 = p->bits;
+    p->bits1 = p->bits < 8 ? p->bits : 8;
     p->bits2 = p->bits - p->bits1;
     if (p->bits2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many buckets for two scatter passes");
-    if (t->log2_slots - p->bits1 > 64 - REC_KEY_BITS)
-        return pg_fail(PG_EINVAL, "bucketed counting needs log2_slots <= %d (got %d)", 64 - REC_KEY_BITS + p->bits1, t->log2_slots);
     p->cap = n_words * 32;
+    p->n_tiles = (n_words + BLOCK - 1) / BLOCK;
     const size_t nb = (size_t)1 << p->bits;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
@@ -803,8 +901,53 @@ int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
     p->off_off = take((nb + 1) * 8);
     p->cur1_off = take(((size_t)1 << p->bits1) * 8);
     p->cur2_off = take(nb * 8);
+    p->tile_off = take((size_t)(p->n_tiles + 1) * 4);
     p->bufa_off = take((size_t)p->cap * 8);
     p->bufb_off = p->bits2 ? take((size_t)p->cap * 8) : p->bufa_off;
+    p->total = o;
+    return PG_OK;
+}
+
+int check_rows(const pg_rows *rows, const char *who)
+{
+    if (!rows) return PG_OK;
+    if (rows->n_rows < 0 || rows->n_rows >= (int64_t)ROW_NONE)
+        return pg_fail(PG_EINVAL, "%s: %lld rows (at most %u per launch)", who, (long long)rows->n_rows, ROW_NONE - 1);
+    if (rows->n_rows > 0 && (!rows->row_start || !rows->row_end)) return pg_fail(PG_EINVAL, "%s: null row arrays", who);
+    return PG_OK;
+}
+
+// carving of the shuffle workspace
+struct ShufflePlan {
+    int vbits, gbits, gb1, gb2;
+    int64_t n_groups, n_groups_padded;
+    size_t emit_off, caps_off, goff_off, gcur1_off, gcur2_off, words_e_off, words_a_off, words_b_off, total;
+};
+
+int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, ShufflePlan *p)
+{
+    if (vsize < 1 || vsize > PG_SHUFFLE_MAX_VSIZE)
+        return pg_fail(PG_EINVAL, "the shuffle path needs 1 <= vector size <= %d (got %d)", PG_SHUFFLE_MAX_VSIZE, vsize);
+    p->vbits = 1;
+    while ((1 << p->vbits) < vsize) ++p->vbits;
+    p->n_groups = (n_rows + (1 << GROUP_ROWS_LOG2) - 1) >> GROUP_ROWS_LOG2;
+    if (p->n_groups < 1) p->n_groups = 1;
+    p->gbits = 0;
+    while (((int64_t)1 << p->gbits) < p->n_groups) ++p->gbits;
+    p->gb1 = p->gbits < 8 ? p->gbits : 8;
+    p->gb2 = p->gbits - p->gb1;
+    if (p->gb2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many rows for two scatter passes");
+    p->n_groups_padded = (int64_t)1 << p->gbits;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    p->emit_off = take(((size_t)1 << PG_BUCKET_MAX_LOG2_BUCKETS) * 8);
+    p->caps_off = take((size_t)p->n_groups_padded * 8);
+    p->goff_off = take((size_t)(p->n_groups_padded + 1) * 8);
+    p->gcur1_off = take(((size_t)1 << p->gb1) * 8);
+    p->gcur2_off = take((size_t)p->n_groups_padded * 8);
+    p->words_e_off = take((size_t)cap * 4);                              // emitted by the lookup pass, bucket order
+    p->words_a_off = take((size_t)cap * 4);                              // after the first row pass
+    p->words_b_off = p->gb2 ? p->words_e_off : p->words_a_off;           // the second row pass reuses the first buffer
     p->total = o;
     return PG_OK;
 }
@@ -853,13 +996,14 @@ extern "C" int64_t pg_kmer_count_workspace_bytes(int64_t n_words, const pg_table
 }
 
 extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
-                                      const pg_table *t, int accumulate, void *workspace, int64_t workspace_bytes,
+                                      const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
                                       uint32_t *status, void *stream)
 {
     if (!codes || !valid || !workspace || !status) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: null argument");
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: bad word range");
     int rc = check_table(t);
     if (rc) return rc;
+    if ((rc = check_rows(rows, "pg_kmer_count_bucketed"))) return rc;
     BucketPlan p;
     rc = plan_buckets(t, word_end - word_begin, &p);
     if (rc) return rc;
@@ -873,45 +1017,49 @@ extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *val
     auto *off = (unsigned long long *)(ws + p.off_off);
     auto *cur1 = (unsigned long long *)(ws + p.cur1_off);
     auto *cur2 = (unsigned long long *)(ws + p.cur2_off);
+    auto *tile_row = (int32_t *)(ws + p.tile_off);
     auto *bufa = (uint64_t *)(ws + p.bufa_off);
     auto *bufb = (uint64_t *)(ws + p.bufb_off);
     const int nb = 1 << p.bits;
     // counters are contiguous at the front of the workspace: one clear
-    if (hipMemsetAsync(ws, 0, p.bufa_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_kmer_count_bucketed: memset failed");
+    if (hipMemsetAsync(ws, 0, p.tile_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_kmer_count_bucketed: memset failed");
     const int64_t n_words = word_end - word_begin;
+    const size_t slice_lds = (size_t)8 << t->log2_bucket_slots;
+    if ((rc = raise_lds_limit((const void *)bucket_hist_kernel, (size_t)(nb < (1 << 15) ? nb : (1 << 15)) * 4, "pg_kmer_count_bucketed"))) return rc;
+    if ((rc = raise_lds_limit((const void *)bucket_count_kernel, slice_lds, "pg_kmer_count_bucketed"))) return rc;
 
-    // both LDS-heavy kernels may need more than the default 64 KiB of dynamic LDS
-    if (nb > (1 << 14) || ((size_t)8 << t->log2_bucket_slots) > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)bucket_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)bucket_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-            return pg_fail(PG_EHIP, "pg_kmer_count_bucketed: cannot raise the dynamic LDS limit");
-    }
+    const bool with_rows = rows && rows->n_rows > 0;
+    if (with_rows)
+        hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((p.n_tiles + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_end, rows->n_rows,
+                           word_begin, p.n_tiles, tile_row);
     // A0 histogram of final bucket ids, then offsets
     {
-        int grid = (int)((n_words + HIST_BLOCK - 1) / HIST_BLOCK);
+        int grid = (int)((n_words + BIG_BLOCK - 1) / BIG_BLOCK);
         if (grid > 512) grid = 512;
         const int per = nb < (1 << 15) ? nb : (1 << 15);
         for (int base = 0; base < nb; base += per)
-            hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(HIST_BLOCK), (size_t)per * 4, s, codes, valid, word_begin, word_end,
-                               t->k, t->log2_slots, p.bits, (uint32_t)base, per, hist);
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(HIST_BLOCK), 0, s, hist, nb, off);
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(BIG_BLOCK), (size_t)per * 4, s, codes, valid, word_begin, word_end,
+                               t->k, p.bits, (uint32_t)base, per, hist);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, hist, (int64_t)nb, off);
     }
     // A1: stream -> 2^bits1 regions (region d1 = final buckets [d1 << bits2, (d1+1) << bits2))
     {
-        int64_t tiles = (n_words + BLOCK - 1) / BLOCK;
-        int grid = (int)(tiles > 8192 ? 8192 : tiles);
-        hipLaunchKernelGGL(scatter_stream_kernel, dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k,
-                           t->log2_slots, p.bits1, bufa, off, cur1, p.bits2);
+        int grid = (int)(p.n_tiles > 8192 ? 8192 : p.n_tiles);
+        hipLaunchKernelGGL(scatter_stream_kernel, dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k, p.bits1,
+                           with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
+                           with_rows ? rows->n_rows : (int64_t)0, (const int32_t *)tile_row, bufa, (const unsigned long long *)off, cur1, p.bits2);
     }
     // A2: every region -> its 2^bits2 final buckets
-    if (p.bits2)
-        hipLaunchKernelGGL(scatter_records_kernel, dim3(96, 1 << p.bits1), dim3(BLOCK), 0, s, bufa, bufb, off, cur2, p.bits2,
-                           t->log2_bucket_slots);
-    // B: count every bucket inside LDS and write its slice of the table
-    {
-        const size_t lds = (size_t)8 << t->log2_bucket_slots;
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(HIST_BLOCK), lds, s, p.bits2 ? bufb : bufa, off, view_of(t), accumulate ? 1 : 0, status);
+    if (p.bits2) {
+        const int tiles_x = 96;
+        hipLaunchKernelGGL((scatter_records_kernel<uint64_t, DIG_HASH>), dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s,
+                           (const uint64_t *)bufa, (const unsigned long long *)off, (const unsigned long long *)(off + ((size_t)1 << p.bits2)),
+                           p.bits2, (const unsigned long long *)nullptr, tiles_x, bufb, (const unsigned long long *)off, cur2, 0, 0,
+                           p.bits2, 64 - p.bits);
     }
+    // B: count every bucket inside LDS and write its slice of the table
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)(p.bits2 ? bufb : bufa),
+                       (const unsigned long long *)off, view_of(t), accumulate ? 1 : 0, status);
     return check_launch("pg_kmer_count_bucketed");
 }
 
@@ -922,7 +1070,7 @@ extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t
     if (t->kind != PG_TABLE_HASH) return pg_fail(PG_EINVAL, "pg_kmer_merge: hash tables only (dense tables are summed with an all-reduce)");
     if (n < 0 || (n > 0 && !pairs) || !status) return pg_fail(PG_EINVAL, "pg_kmer_merge: bad arguments");
     if (n == 0) return PG_OK;
-    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, t->k, view_of(t), status);
+    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, view_of(t), status);
     return check_launch("pg_kmer_merge");
 }
 
@@ -937,12 +1085,91 @@ extern "C" int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg,
     const int bits = t->log2_slots - t->log2_bucket_slots;
     if (bits < 0 || bits > 30) return pg_fail(PG_EINVAL, "pg_kmer_merge_bucketed: bad bucket geometry");
     const size_t lds = (size_t)8 << t->log2_bucket_slots;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)bucket_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-        return pg_fail(PG_EHIP, "pg_kmer_merge_bucketed: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(HIST_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
-                       n_parts, t->k, view_of(t), status);
+    if ((rc = raise_lds_limit((const void *)bucket_merge_kernel, lds, "pg_kmer_merge_bucketed"))) return rc;
+    hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
+                       n_parts, view_of(t), status);
     return check_launch("pg_kmer_merge_bucketed");
+}
+
+extern "C" int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize)
+{
+    if (n_words_counted < 0 || n_rows < 0) return pg_fail(PG_EINVAL, "negative size");
+    ShufflePlan sp;
+    int rc = plan_shuffle(n_words_counted * 32, n_rows, vsize, &sp);
+    if (rc) return rc;
+    return (int64_t)sp.total;
+}
+
+extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
+                                         const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                                         void *workspace, int64_t workspace_bytes, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!rows || !abd_out || !count_workspace || !workspace) return pg_fail(PG_EINVAL, "pg_abundance_from_records: null argument");
+    if ((rc = check_rows(rows, "pg_abundance_from_records"))) return rc;
+    if (window < 1) return pg_fail(PG_EINVAL, "pg_abundance_from_records: window %d", window);
+    if ((int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
+        return pg_fail(PG_EINVAL, "pg_abundance_from_records: window*vector_size %lld exceeds the exact range of the hash table (%u)",
+                       (long long)window * vsize, PG_HASH_COUNT_SAT);
+    BucketPlan p;
+    if ((rc = plan_buckets(t, n_words_counted, &p))) return rc;
+    if ((int64_t)p.total > count_workspace_bytes) return pg_fail(PG_EINVAL, "pg_abundance_from_records: count workspace does not match n_words_counted");
+    ShufflePlan sp;
+    if ((rc = plan_shuffle(p.cap, rows->n_rows, vsize, &sp))) return rc;
+    if ((int64_t)sp.total > workspace_bytes)
+        return pg_fail(PG_EINVAL, "pg_abundance_from_records: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return pg_fail(PG_EINVAL, "pg_abundance_from_records: workspace must be 256-byte aligned");
+    if (rows->n_rows == 0) return PG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const char *cws = (const char *)count_workspace;
+    const auto *off = (const unsigned long long *)(cws + p.off_off);
+    const auto *recs = (const uint64_t *)(cws + p.final_off());
+    char *ws = (char *)workspace;
+    auto *emit_end = (unsigned long long *)(ws + sp.emit_off);
+    auto *caps = (unsigned long long *)(ws + sp.caps_off);
+    auto *goff = (unsigned long long *)(ws + sp.goff_off);
+    auto *gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
+    auto *gcur2 = (unsigned long long *)(ws + sp.gcur2_off);
+    auto *words_e = (uint32_t *)(ws + sp.words_e_off);
+    auto *words_a = (uint32_t *)(ws + sp.words_a_off);
+    auto *words_b = (uint32_t *)(ws + sp.words_b_off);
+    const int nb = 1 << p.bits;
+    const size_t slice_lds = (size_t)8 << t->log2_bucket_slots;
+    const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
+    if ((rc = raise_lds_limit((const void *)bucket_lookup_kernel, slice_lds, "pg_abundance_from_records"))) return rc;
+    if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
+    if (hipMemsetAsync(ws, 0, sp.words_e_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
+
+    // row-group capacities -> offsets of the group regions
+    hipLaunchKernelGGL(group_caps_kernel, dim3((unsigned)((sp.n_groups_padded + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_start, rows->row_end,
+                       rows->n_rows, sp.n_groups_padded, caps);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)caps, sp.n_groups_padded, goff);
+    // S1: counts out of the LDS copies of the slices -> (row, bin) words, packed per bucket
+    hipLaunchKernelGGL(bucket_lookup_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, recs, off, view_of(t), (uint32_t)window, (uint32_t)vsize, sp.vbits,
+                       words_e, emit_end);
+    // S2: scatter the words by row group: first gb1 bits, then the remaining gb2 bits
+    const int gshift = sp.vbits + GROUP_ROWS_LOG2;
+    {
+        const int tiles_x = 4;
+        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW>), dim3((unsigned)(tiles_x * nb)), dim3(BLOCK), 0, s,
+                           (const uint32_t *)words_e, off, (const unsigned long long *)emit_end, 0, (const unsigned long long *)nullptr, tiles_x,
+                           words_a, (const unsigned long long *)goff, gcur1, sp.gb2, 1, sp.gb1, gshift + sp.gb2);
+    }
+    const unsigned long long *gcnt = gcur1;
+    const uint32_t *final_words = words_a;
+    if (sp.gb2) {
+        const int tiles_x = 64;
+        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW>), dim3((unsigned)(tiles_x << sp.gb1)), dim3(BLOCK), 0, s,
+                           (const uint32_t *)words_a, (const unsigned long long *)goff, (const unsigned long long *)nullptr, sp.gb2,
+                           (const unsigned long long *)gcur1, tiles_x, words_b, (const unsigned long long *)goff, gcur2, 0, 0, sp.gb2, gshift);
+        gcnt = gcur2;
+        final_words = words_b;
+    }
+    // S3: LDS row histograms -> rows of the matrix
+    hipLaunchKernelGGL(row_hist_kernel, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, final_words, (const unsigned long long *)goff, gcnt,
+                       sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
+    return check_launch("pg_abundance_from_records");
 }
 
 extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,

@@ -26,7 +26,7 @@ import pandas as pd
 import torch
 
 from . import _lib, dist as pdist
-from .kmer import KmerTable, count_kmers, features, tnf_ncols
+from .kmer import KmerTable, Plan, count_kmers, features, tnf_ncols
 from .reads import ReadStream
 
 
@@ -79,10 +79,11 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     part = pdist.shard_stream(host, rank, world) if world > 1 else host
     stream = part.to(device)
     rows = stream.rows(min_len)
+    plan = Plan(rows, device)
     if want_abd and table is None:
-        table = count_kmers(stream, k)
+        table = count_kmers(stream, k, rows=plan)
         pdist.exchange_table(table)
-    tnf, abd = features(stream, rows, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
+    tnf, abd = features(stream, plan, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
                         window=window, vsize=vsize)
     names = list(rows.names)
     if world > 1:

@@ -46,6 +46,8 @@ class KmerTable:
                                    self.log2_bucket, data.data_ptr())
         self._empty = True               # nothing counted since allocation / reset()
         self._workspace = None
+        self._shuffle_ws = None
+        self._records = None             # (plan, n_words) while the workspace holds the row-tagged records of ONE count
 
     # ------------------------------------------------------------------ construction
 
@@ -119,6 +121,7 @@ class KmerTable:
             self.data.zero_()
         self.status.zero_()
         self._empty = True
+        self._records = None
         return self
 
     def _workspace_for(self, n_words: int) -> torch.Tensor:
@@ -128,8 +131,11 @@ class KmerTable:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def count(self, stream: ReadStream, word_begin: int = 0, word_end: int | None = None, check: bool = True) -> "KmerTable":
-        """add the k-mers ending in words [word_begin, word_end) of the stream (asynchronous unless ``check``)"""
+    def count(self, stream: ReadStream, word_begin: int = 0, word_end: int | None = None, check: bool = True,
+              rows: "Plan | None" = None) -> "KmerTable":
+        """add the k-mers ending in words [word_begin, word_end) of the stream (asynchronous unless ``check``).
+        With ``rows`` (a Plan of this stream's rows) a bucketed table also keeps the row-tagged partition records, which
+        lets ``features`` build the abundance rows by shuffle instead of by table lookups."""
         _require_gpu(stream.codes, "the read stream")
         if stream.device != self.device:
             raise ValueError("stream and table are on different devices")
@@ -139,13 +145,18 @@ class KmerTable:
             if self.kind == "hash" and self.log2_bucket:
                 # pieces bounded by the scratch budget: two record buffers of 8 B per character
                 step = max(_lib.WORD_ALIGN, int(self.WORKSPACE_BUDGET // (2 * 8 * 32)) // _lib.WORD_ALIGN * _lib.WORD_ALIGN)
+                single = self._empty and word_end - word_begin <= step
+                keep = rows if (single and rows is not None and rows.shuffle_ok) else None
+                self._records = None
                 for w0 in range(word_begin, word_end, step):
                     w1 = min(word_end, w0 + step)
                     ws = self._workspace_for(w1 - w0)
                     _lib.check(L.pg_kmer_count_bucketed(stream.codes.data_ptr(), stream.valid.data_ptr(), w0, w1, self.desc(),
-                                                        0 if self._empty else 1, ws.data_ptr(), ws.numel(),
-                                                        self.status.data_ptr(), _stream_ptr(self.device)))
+                                                        0 if self._empty else 1, C.byref(keep.rows_desc) if keep is not None else None,
+                                                        ws.data_ptr(), ws.numel(), self.status.data_ptr(), _stream_ptr(self.device)))
                     self._empty = False
+                if keep is not None:
+                    self._records = (keep, word_end - word_begin)
             else:
                 _lib.check(L.pg_kmer_count(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end,
                                            self.desc(), self.status.data_ptr(), _stream_ptr(self.device)))
@@ -153,6 +164,26 @@ class KmerTable:
         if check:
             self.check_status()
         return self
+
+    def has_records_for(self, plan: "Plan", vsize: int) -> bool:
+        return (self._records is not None and self._records[0] is plan and vsize <= _lib.SHUFFLE_MAX_VSIZE
+                and self.kind == "hash" and bool(self.log2_bucket))
+
+    def abundance_from_records(self, plan: "Plan", window: int, vsize: int, out: torch.Tensor) -> torch.Tensor:
+        """abundance rows by shuffle: bucket-wise LDS lookups of the kept records + row-group scatter + LDS row histograms"""
+        if not self.has_records_for(plan, vsize):
+            raise RuntimeError("no partition records for these rows: count(stream, rows=plan) first")
+        n_words = self._records[1]
+        L = _lib.load()
+        need = _lib.check(L.pg_abundance_workspace_bytes(n_words, plan.n_rows, vsize))
+        if self._shuffle_ws is None or self._shuffle_ws.numel() < need:
+            self._shuffle_ws = None
+            self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.pg_abundance_from_records(self.desc(), C.byref(plan.rows_desc), window, vsize, out.data_ptr(),
+                                                   self._workspace.data_ptr(), self._workspace.numel(), n_words,
+                                                   self._shuffle_ws.data_ptr(), self._shuffle_ws.numel(), _stream_ptr(self.device)))
+        return out
 
     def check_status(self) -> None:
         if self.kind == "hash" and int(self.status[0].item()) != 0:
@@ -235,13 +266,13 @@ class KmerTable:
 
 
 def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hint: int | None = None,
-                max_log2_slots: int = 36, log2_bucket: int | None = None) -> KmerTable:
+                max_log2_slots: int = 36, log2_bucket: int | None = None, rows: "Plan | None" = None) -> KmerTable:
     """build the table of one stream; a full hash table is re-built with four times the slots"""
     table = KmerTable.alloc(k, stream.device, kind, distinct_hint if distinct_hint else max(1 << 16, stream.n_chars // 8),
                             log2_bucket=log2_bucket)
     while True:
         try:
-            return table.count(stream)
+            return table.count(stream, rows=rows)
         except _lib.PangaeaError as e:
             if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
                 raise
@@ -292,7 +323,8 @@ def plan_segments(rows: Rows, seg_chars: int = DEFAULT_SEG_CHARS):
 
 
 class Plan:
-    """device copy of the work segments of a row set (re-usable across launches)"""
+    """device copy of a row set: its work segments (lookup kernels) and its row ranges (row ids in the partition
+    records of the shuffle path); re-usable across launches"""
 
     def __init__(self, rows: Rows, device, seg_chars: int = DEFAULT_SEG_CHARS):
         r, s, e = plan_segments(rows, seg_chars)
@@ -300,6 +332,14 @@ class Plan:
         self.seg_row = torch.from_numpy(r).to(device)
         self.seg_start = torch.from_numpy(s).to(device)
         self.seg_end = torch.from_numpy(e).to(device)
+        start = np.ascontiguousarray(rows.start, dtype=np.int64)
+        end = np.ascontiguousarray(rows.end, dtype=np.int64)
+        # the shuffle path needs sorted, disjoint, non-empty rows (barcode runs are) and at most 2^22 - 2 of them
+        self.shuffle_ok = bool(len(start) and len(start) <= _lib.MAX_ROWS and (end > start).all()
+                               and (start[1:] >= end[:-1]).all())
+        self.row_start = torch.from_numpy(start).to(device)
+        self.row_end = torch.from_numpy(end).to(device)
+        self.rows_desc = _lib.pg_rows(self.row_start.data_ptr(), self.row_end.data_ptr(), self.n_rows)
 
 
 def features(stream: ReadStream, rows: Rows | Plan, k_tnf: int | None = 4, table: KmerTable | None = None,
@@ -321,19 +361,28 @@ def features(stream: ReadStream, rows: Rows | Plan, k_tnf: int | None = 4, table
         colmap, _ = tnf_colmap(k_tnf, dev)
         colmap_ptr = colmap.data_ptr()
         tnf = out_tnf.zero_() if out_tnf is not None else torch.zeros((n, tnf_ncols(k_tnf)), dtype=torch.int32, device=dev)
+    shuffle = table is not None and table.has_records_for(plan, vsize)
     if table is not None:
         if table.device != dev:
             raise ValueError("stream and table are on different devices")
-        abd = out_abd.zero_() if out_abd is not None else torch.zeros((n, vsize), dtype=torch.int32, device=dev)
+        if shuffle:                 # every row is overwritten: no zero fill
+            abd = out_abd if out_abd is not None else torch.empty((n, vsize), dtype=torch.int32, device=dev)
+        else:
+            abd = out_abd.zero_() if out_abd is not None else torch.zeros((n, vsize), dtype=torch.int32, device=dev)
     if tnf is None and abd is None:
         raise ValueError("nothing to compute: give k_tnf and/or a table")
     if plan.n_segs == 0:            # no rows (or only empty ones): the zero-filled matrices are the answer
         return tnf, abd
+    if shuffle:
+        table.abundance_from_records(plan, window, vsize, abd)
+        if tnf is None:
+            return tnf, abd
+        table = None                         # the lookup kernel below only counts TNF
     with torch.cuda.device(dev):
         _lib.check(_lib.load().pg_features(
             stream.codes.data_ptr(), stream.valid.data_ptr(), stream.n_words,
             plan.seg_row.data_ptr(), plan.seg_start.data_ptr(), plan.seg_end.data_ptr(), plan.n_segs,
             k_tnf or 0, colmap_ptr, tnf.data_ptr() if tnf is not None else None,
             table.desc() if table is not None else None, window, vsize,
-            abd.data_ptr() if abd is not None else None, _stream_ptr(dev)))
+            abd.data_ptr() if (abd is not None and table is not None) else None, _stream_ptr(dev)))
     return tnf, abd

@@ -117,6 +117,67 @@ def test_synthetic_against_oracle(k, kind, k_tnf, window, vsize, seg):
     assert np.array_equal(abd.cpu().numpy(), oabd)
 
 
+@pytest.mark.parametrize("k,k_tnf,window,vsize,log2_slots,log2_bucket", [
+    (21, 4, 10, 400, None, None), (21, 4, 1, 6, 19, 7), (17, 3, 2, 512, 18, 14), (9, 5, 3, 33, 20, 5), (21, None, 10, 400, 18, 10)])
+def test_abundance_by_shuffle_equals_lookups_and_oracle(k, k_tnf, window, vsize, log2_slots, log2_bucket):
+    """count(stream, rows=plan) keeps row-tagged records; features() then answers from LDS and shuffles (row, bin) words
+    back by row group -- same matrices as the lookup kernel and the oracle"""
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=37, n_genomes=3, genome_len=30_000, fragment=8_000,
+                            sub_rate=0.01, n_rate=0.2, seed=200 + k)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV, seg_chars=1024)
+    if log2_slots is None:
+        table = kmer.count_kmers(s, k, kind="hash", rows=plan)
+    else:
+        table = kmer.KmerTable.with_slots(k, DEV, log2_slots, log2_bucket).count(s, rows=plan)
+    assert table.has_records_for(plan, vsize)
+    tnf, abd = kmer.features(s, plan, k_tnf=k_tnf, table=table, window=window, vsize=vsize)
+    _, otnf, oabd = _oracle_rows(s, rows, k_tnf, k, window, vsize)
+    assert np.array_equal(abd.cpu().numpy(), oabd)
+    if k_tnf:
+        assert np.array_equal(tnf.cpu().numpy(), otnf)
+    # the lookup kernel on the same table (a Rows argument has no records attached)
+    _, abd2 = kmer.features(s, rows, k_tnf=None, table=table, window=window, vsize=vsize)
+    assert torch.equal(abd, abd2)
+    # beyond the shuffle's bin range the lookup kernel takes over transparently
+    assert not table.has_records_for(plan, 1024)
+    _, abd3 = kmer.features(s, plan, k_tnf=None, table=table, window=1, vsize=1024)
+    _, _, oabd3 = _oracle_rows(s, rows, None, k, 1, 1024)
+    assert np.array_equal(abd3.cpu().numpy(), oabd3)
+    # a second count invalidates the records (they describe one pass only)
+    table.count(s, rows=plan)
+    assert not table.has_records_for(plan, vsize)
+
+
+def test_shuffle_with_many_small_rows_and_ragged_rows():
+    # > 16 384 rows: the (row, bin) words take two scatter passes; rows of 2 pairs, some not word aligned
+    cfg = synth.SynthConfig(n_pairs=36_000, n_barcodes=18_000, n_genomes=2, genome_len=40_000, fragment=2_000, unbarcoded=0.0, seed=8)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(300)
+    assert len(rows) > 16_384 + 64
+    plan = kmer.Plan(rows, DEV)
+    table = kmer.count_kmers(s, 15, kind="hash", rows=plan)
+    _, abd = kmer.features(s, plan, k_tnf=None, table=table, window=2, vsize=40)
+    _, abd2 = kmer.features(s, rows, k_tnf=None, table=table, window=2, vsize=40)
+    assert torch.equal(abd, abd2)
+    otab = oracle.Table(15, threads=4).count(s.decode())
+    for r in (0, 1, 63, 64, 16_383, 16_384, len(rows) - 1):
+        txt = s.decode(int(rows.start[r]), int(rows.end[r]))
+        assert np.array_equal(abd[r].cpu().numpy(), oracle.abd_row(txt, 15, otab, 2, 40))
+    # ragged runs: empty, 1-character and unaligned rows, rows without any k-mer
+    runs = [("", b"ACGTACGTN"), ("b", b"N"), ("c", b"ACGN"), ("d", b"ACGTN" * 3), ("e", b"A" * 5000 + b"N"),
+            ("f", b"NNNNACGTACGTACGTACGTACGTACGTNNNN"), ("h", (b"ACGT" * 9 + b"N") * 40), ("i", b"ACGTTGCAN" * 7),
+            ("j", b"G" * 31 + b"N"), ("k", b"C" * 32 + b"N"), ("l", b"T" * 33 + b"N")]
+    s = ReadStream.from_runs(runs, device=DEV)
+    rows = s.rows(0)
+    plan = kmer.Plan(rows, DEV, seg_chars=32)
+    table = kmer.KmerTable.with_slots(9, DEV, 14, 8).count(s, rows=plan)
+    tnf, abd = kmer.features(s, plan, k_tnf=4, table=table, window=1, vsize=64)
+    _, otnf, oabd = _oracle_rows(s, rows, 4, 9, 1, 64)
+    assert np.array_equal(tnf.cpu().numpy(), otnf) and np.array_equal(abd.cpu().numpy(), oabd)
+
+
 def test_ragged_and_degenerate_runs():
     runs = [("", b"ACGTACGTN"), ("a", b""), ("b", b"N"), ("c", b"ACGN"), ("d", b"ACGTN" * 3), ("e", b"A" * 5000 + b"N"),
             ("f", b"NNNNACGTACGTACGTACGTACGTACGTNNNN"), ("g", b"acgtacgtacgtN"), ("h", (b"ACGT" * 9 + b"N") * 40),
@@ -266,8 +327,11 @@ def test_full_size_invariants():
     s = synth.generate(cfg, device=DEV, chunk_pairs=1 << 17, with_names=False)
     rows = s.rows(2000)
     assert len(rows) == 50_000
-    table = kmer.count_kmers(s, 21, kind="hash", distinct_hint=260_000_000)
-    tnf, abd = kmer.features(s, rows, k_tnf=4, table=table, window=10, vsize=400)
+    plan = kmer.Plan(rows, DEV)
+    table = kmer.count_kmers(s, 21, kind="hash", distinct_hint=260_000_000, rows=plan)
+    tnf, abd = kmer.features(s, plan, k_tnf=4, table=table, window=10, vsize=400)          # shuffle path
+    tnf_l, abd_l = kmer.features(s, rows, k_tnf=4, table=table, window=10, vsize=400)      # lookup path
+    assert torch.equal(tnf, tnf_l) and torch.equal(abd, abd_l)
     torch.cuda.synchronize()
     n21 = _valid_kmer_ends(s.valid, 21)
     n4 = _valid_kmer_ends(s.valid, 4)
@@ -287,7 +351,7 @@ def test_full_size_invariants():
     assert int(abd_all.to(torch.int64).sum().item()) + int(abd_c.sum().item()) == int(n21.sum().item())
     assert (abd.to(torch.int64).sum(1) <= abd_all.to(torch.int64).sum(1)).all()
     # (4) idempotence: a second launch into fresh outputs gives the same matrices
-    tnf2, abd2 = kmer.features(s, rows, k_tnf=4, table=table, window=10, vsize=400)
+    tnf2, abd2 = kmer.features(s, plan, k_tnf=4, table=table, window=10, vsize=400)
     assert torch.equal(tnf, tnf2) and torch.equal(abd, abd2)
     # (5) spot rows against the oracle (first, middle, last)
     text_rows = [0, 24_999, 49_999]
