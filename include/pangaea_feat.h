@@ -192,7 +192,7 @@ int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,
  * fill needed).  Requirements: the same `t` geometry, `rows` and word count as the counting call, one counting
  * call since the table was last reset, vsize <= PG_SHUFFLE_MAX_VSIZE.  workspace: pg_abundance_workspace_bytes. */
 #define PG_SHUFFLE_MAX_VSIZE 512
-int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize);
+int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize, const pg_table *t);
 int pg_abundance_from_records(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
                               const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
                               void *workspace, int64_t workspace_bytes, void *stream);

@@ -83,7 +83,7 @@ def load() -> C.CDLL:
         "pg_kmer_count": (i32, [vp, vp, i64, i64, tp, vp, vp]),
         "pg_kmer_count_workspace_bytes": (i64, [i64, tp]),
         "pg_kmer_count_bucketed": (i32, [vp, vp, i64, i64, tp, i32, rp, vp, i64, vp, vp]),
-        "pg_abundance_workspace_bytes": (i64, [i64, i64, i32]),
+        "pg_abundance_workspace_bytes": (i64, [i64, i64, i32, tp]),
         "pg_abundance_from_records": (i32, [tp, rp, i32, i32, vp, vp, i64, i64, vp, i64, vp]),
         "pg_kmer_merge": (i32, [vp, i64, tp, vp, vp]),
         "pg_kmer_merge_bucketed": (i32, [vp, vp, i32, tp, vp, vp]),

@@ -234,22 +234,21 @@ __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__res
 //
 // occurrence record = canonical code (low 42 bits) | row id << 42 (22 bits, ROW_NONE = not inside any row)
 
-constexpr int TILE0 = 8192;           // records per stream tile: 256 lanes x 32 characters
-constexpr int REC_PER_LANE = 16;      // record scatter passes: records a lane keeps in registers
-constexpr int TILE1 = BLOCK * REC_PER_LANE;
+constexpr int RPL64 = 16, RPL32 = 32; // record scatter passes: 8-byte / 4-byte records a lane keeps in registers
 constexpr int MAX_FAN_BITS = 9;       // <= 512-way scatter per pass
 constexpr int REC_KEY_BITS = 42;
 constexpr uint64_t REC_KEY_MASK = (1ull << REC_KEY_BITS) - 1;
 constexpr uint32_t ROW_NONE = (1u << (64 - REC_KEY_BITS)) - 1;
 constexpr int GROUP_ROWS_LOG2 = 6;    // rows per LDS row-histogram group (64 x 512 bins x 4 B = 128 KiB at most)
 
-// first row whose end lies beyond the first character of each 256-word tile (rows sorted, disjoint)
+constexpr int TILE_WORDS = 128;       // words per stream tile of the first scatter pass (= A1_TILE_WORDS)
+// first row whose end lies beyond the first character of each stream tile (rows sorted, disjoint)
 __global__ __launch_bounds__(BLOCK) void tile_rows_kernel(const int64_t *__restrict__ row_end, int64_t n_rows, int64_t word_begin,
                                                           int64_t n_tiles, int32_t *__restrict__ tile_row)
 {
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= n_tiles) return;
-    const int64_t c0 = (word_begin + t * BLOCK) * 32;
+    const int64_t c0 = (word_begin + t * TILE_WORDS) * 32;
     int64_t lo = 0, hi = n_rows;                                    // first r with row_end[r] > c0
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -259,33 +258,76 @@ __global__ __launch_bounds__(BLOCK) void tile_rows_kernel(const int64_t *__restr
 }
 
 // A0: histogram of final bucket ids (top `bits` bits of the hash) over every valid k-mer of the word range; one launch
-// covers the bins [bin_base, bin_base + n_bins) (n_bins <= 2^15: 128 KiB of LDS counters)
+// covers the bins [bin_base, bin_base + n_bins) (n_bins <= 2^15: 128 KiB of LDS counters).  With chunk_hist given it
+// also records, for every CHUNK_WORDS-word chunk of the range, how many k-mers fall into each first-pass digit
+// (top bits1 bits): chunk_hist[d * n_chunks + chunk].  A per-digit scan of that table gives every chunk its exact write
+// offsets, so the first scatter pass needs no global cursor atomics.
+constexpr int CHUNK_WORDS = 4096;     // = 32 stream tiles of the first scatter pass
 __global__ __launch_bounds__(BIG_BLOCK) void bucket_hist_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                                 int64_t word_begin, int64_t word_end, int k, int bits,
-                                                                uint32_t bin_base, int n_bins, unsigned long long *__restrict__ hist)
+                                                                uint32_t bin_base, int n_bins, unsigned long long *__restrict__ hist,
+                                                                int bits1, unsigned long long *__restrict__ chunk_hist, int64_t n_chunks,
+                                                                int64_t chunk_stride)
 {
+    // chunks are placed in the order slot = chunk * chunk_stride mod n_chunks (stride coprime to n_chunks): regions then
+    // hold the stream in scrambled chunk order, so later passes do not see row-sorted input
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *coarse = lds + n_bins;                                // [256]
     for (int i = threadIdx.x; i < n_bins; i += BIG_BLOCK) lds[i] = 0;
-    __syncthreads();
-    const int sh = 64 - bits;
-    for (int64_t w = word_begin + (int64_t)blockIdx.x * BIG_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * BIG_BLOCK) {
-        const Word x = load_word(codes, valid, w, k);
-        if (x.ok == 0) continue;
-        Roller<uint64_t> r;
-        r.init(k);
-        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(x.pw >> (2 * i)) & 3u);
+    const int sh = 64 - bits, sh1 = 64 - bits1;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        if (threadIdx.x < 256) coarse[threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t w0 = word_begin + chunk * CHUNK_WORDS;
+        const int64_t w1 = w0 + CHUNK_WORDS < word_end ? w0 + CHUNK_WORDS : word_end;
+        for (int64_t w = w0 + threadIdx.x; w < w1; w += BIG_BLOCK) {
+            const Word x = load_word(codes, valid, w, k);
+            if (x.ok == 0) continue;
+            Roller<uint64_t> r;
+            r.init(k);
+            for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(x.pw >> (2 * i)) & 3u);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            r.push((uint32_t)(x.cw >> (2 * j)) & 3u);
-            if ((x.ok >> j) & 1) {
-                const uint32_t bin = (uint32_t)(mix64(r.canon()) >> sh) - bin_base;
-                if (bin < (uint32_t)n_bins) atomicAdd(&lds[bin], 1u);
+            for (int j = 0; j < 32; ++j) {
+                r.push((uint32_t)(x.cw >> (2 * j)) & 3u);
+                if ((x.ok >> j) & 1) {
+                    const uint64_t h = mix64(r.canon());
+                    const uint32_t bin = (uint32_t)(h >> sh) - bin_base;
+                    if (bin < (uint32_t)n_bins) atomicAdd(&lds[bin], 1u);
+                    if (chunk_hist) atomicAdd(&coarse[h >> sh1], 1u);
+                }
             }
         }
+        __syncthreads();
+        if (chunk_hist && threadIdx.x < (1u << bits1))
+            chunk_hist[(int64_t)threadIdx.x * n_chunks + (int64_t)(((__int128)chunk * chunk_stride) % n_chunks)] = coarse[threadIdx.x];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_bins; i += BIG_BLOCK)
         if (lds[i]) atomicAdd(&hist[bin_base + i], (unsigned long long)lds[i]);
+}
+
+// per-digit exclusive scan of table[d][0..n) in place, plus base[d << base_shift]; totals[d] (may be NULL) = row sum.
+// One workgroup per digit.
+__global__ __launch_bounds__(BIG_BLOCK) void digit_scan_kernel(unsigned long long *__restrict__ table, int64_t n,
+                                                               const unsigned long long *__restrict__ base, int base_shift,
+                                                               unsigned long long *__restrict__ totals)
+{
+    __shared__ unsigned long long part[BIG_BLOCK];
+    unsigned long long *row = table + (int64_t)blockIdx.x * n;
+    const int64_t per = (n + BIG_BLOCK - 1) / BIG_BLOCK;
+    const int64_t a = threadIdx.x * per, b = a + per < n ? a + per : n;
+    unsigned long long s = 0;
+    for (int64_t i = a; i < b; ++i) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < BIG_BLOCK; ++i) { unsigned long long v = part[i]; part[i] = run; run += v; }
+        if (totals) totals[blockIdx.x] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x] + base[(int64_t)blockIdx.x << base_shift];
+    for (int64_t i = a; i < b; ++i) { const unsigned long long v = row[i]; row[i] = run; run += v; }
 }
 
 // exclusive prefix sum of hist[n] -> off[n+1] (one workgroup)
@@ -310,17 +352,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void scan_kernel(const unsigned long lon
 
 // LDS bookkeeping shared by the scatter passes
 struct ScatterLds {
-    uint32_t cnt[1 << MAX_FAN_BITS];
     uint32_t start[(1 << MAX_FAN_BITS) + 1];
-    unsigned long long gbase[1 << MAX_FAN_BITS];
+    unsigned long long gbase[1 << MAX_FAN_BITS];                    // its first half doubles as the digit counters until the scan
     uint32_t wave_tot[WAVES];
+    __device__ __forceinline__ uint32_t *cnt() { return reinterpret_cast<uint32_t *>(gbase); }
 };
 
 // exclusive scan of L.cnt[0..n_dig) into L.start[0..n_dig] (n_dig <= 512: two entries per lane); all lanes call
 __device__ __forceinline__ void scatter_scan(ScatterLds &L, int n_dig)
 {
     const int i0 = 2 * threadIdx.x, i1 = i0 + 1;
-    const uint32_t a = i0 < n_dig ? L.cnt[i0] : 0, b = i1 < n_dig ? L.cnt[i1] : 0;
+    const uint32_t a = i0 < n_dig ? L.cnt()[i0] : 0, b = i1 < n_dig ? L.cnt()[i1] : 0;
     const uint32_t v = a + b;
     uint32_t incl = v;
 #pragma unroll
@@ -339,36 +381,56 @@ __device__ __forceinline__ void scatter_scan(ScatterLds &L, int n_dig)
     __syncthreads();
 }
 
-// A1: stream -> 2^bits1 regions.  A lane keeps the <= 32 records of its word in registers; one returning LDS atomic
-// per record yields its rank inside its digit, the tile is then laid out digit-sorted in LDS and every digit's run
-// is appended to its region with one global cursor add, so HBM receives contiguous runs.
+// A1: stream -> 2^bits1 regions (bits1 <= 8).  A lane owns HALF a word (16 characters) and keeps its <= 16 records in
+// registers; one returning LDS atomic per record yields its rank inside its digit, the tile (128 words, <= 4096
+// records) is then laid out digit-sorted in LDS and every digit's run is appended to its region with one global cursor
+// add, so HBM receives contiguous runs.  36 KiB of LDS per workgroup: four workgroups (16 waves) per CU.
 // With rows given, every record also carries the index of the row its k-mer ends in (ROW_NONE outside all rows).
+constexpr int A1_CHARS = 16;
+constexpr int A1_TILE_WORDS = BLOCK * A1_CHARS / 32;
+static_assert(A1_TILE_WORDS == TILE_WORDS, "tile_rows_kernel and scatter_stream_kernel must agree on the tile size");
+constexpr int A1_TILE = BLOCK * A1_CHARS;
+struct StreamLds {
+    uint32_t cnt[256];
+    uint32_t start[257];
+    unsigned long long gbase[256];
+    unsigned long long cur[256];                                    // running write offsets of this chunk, per digit
+    uint32_t wave_tot[WAVES];
+};
+static_assert(CHUNK_WORDS % (BLOCK * 16 / 32) == 0, "a chunk is a whole number of stream tiles");
 __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                                int64_t word_begin, int64_t word_end, int k, int bits1,
                                                                const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end,
                                                                int64_t n_rows, const int32_t *__restrict__ tile_row,
-                                                               uint64_t *__restrict__ rec_out, const unsigned long long *__restrict__ off,
-                                                               unsigned long long *__restrict__ cursor, int off_shift)
+                                                               uint64_t *__restrict__ rec_out,
+                                                               const unsigned long long *__restrict__ chunk_off, int64_t n_chunks,
+                                                               int64_t chunk_stride)
 {
-    __shared__ uint64_t buf[TILE0];
-    __shared__ ScatterLds L;
+    // one workgroup per chunk: chunk_off[d * n_chunks + chunk] is where this chunk's records of digit d start
+    __shared__ uint64_t buf[A1_TILE];
+    __shared__ StreamLds L;
     const int n_dig = 1 << bits1;
     const int dsh = 64 - bits1;
-    const int64_t n_tiles = (word_end - word_begin + BLOCK - 1) / BLOCK;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt[i] = 0;
+    const int64_t n_tiles = (word_end - word_begin + A1_TILE_WORDS - 1) / A1_TILE_WORDS;
+    const int half = threadIdx.x & 1;                               // which 16 characters of the word
+    const int64_t chunk = blockIdx.x;
+    constexpr int TILES_PER_CHUNK = CHUNK_WORDS / A1_TILE_WORDS;
+    const int64_t slot = (int64_t)(((__int128)chunk * chunk_stride) % n_chunks);
+    if ((int)threadIdx.x < n_dig) L.cur[threadIdx.x] = chunk_off[(int64_t)threadIdx.x * n_chunks + slot];
+    for (int64_t tile = chunk * TILES_PER_CHUNK; tile < (chunk + 1) * TILES_PER_CHUNK && tile < n_tiles; ++tile) {
+        L.cnt[threadIdx.x] = 0;
         __syncthreads();
-        uint64_t rec[32];
-        uint32_t dr[32];                                            // digit << 16 | rank inside the digit
+        uint64_t rec[A1_CHARS];
+        uint32_t dr[A1_CHARS];                                      // digit << 16 | rank inside the digit
         uint32_t ok = 0;
-        const int64_t w = word_begin + tile * BLOCK + threadIdx.x;
+        const int64_t w = word_begin + tile * A1_TILE_WORDS + (threadIdx.x >> 1);
         if (w < word_end) {
             const Word x = load_word(codes, valid, w, k);
-            ok = x.ok;
+            ok = (x.ok >> (A1_CHARS * half)) & 0xffffu;
             if (ok) {
                 // row bookkeeping: r = first row that can still contain a position >= the current one
                 int64_t r = n_rows, rs = INT64_MAX, re = INT64_MAX;
-                const int64_t pos0 = w << 5;
+                const int64_t pos0 = (w << 5) + A1_CHARS * half;
                 if (row_start) {
                     r = tile_row[tile];
                     while (r < n_rows && row_end[r] <= pos0) ++r;
@@ -376,10 +438,13 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
                 }
                 Roller<uint64_t> rl;
                 rl.init(k);
-                for (int i = 33 - k; i < 32; ++i) rl.push((uint32_t)(x.pw >> (2 * i)) & 3u);
+                // pre-roll the k-1 characters before the lane's first one: word positions c in [first-(k-1), first)
+                for (int c = A1_CHARS * half - (k - 1); c < A1_CHARS * half; ++c)
+                    rl.push((uint32_t)((c < 0 ? x.pw >> (2 * (c + 32)) : x.cw >> (2 * c)) & 3u));
+                const uint32_t mine = (uint32_t)(x.cw >> (2 * A1_CHARS * half));
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    rl.push((uint32_t)(x.cw >> (2 * j)) & 3u);
+                for (int j = 0; j < A1_CHARS; ++j) {
+                    rl.push((mine >> (2 * j)) & 3u);
                     if ((ok >> j) & 1) {
                         const int64_t pos = pos0 + j;
                         while (pos >= re) {                         // rows are at least one character long: terminates
@@ -397,18 +462,34 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
             }
         }
         __syncthreads();
-        scatter_scan(L, n_dig);
-        for (int d = threadIdx.x; d < n_dig; d += BLOCK)
-            if (L.cnt[d]) L.gbase[d] = off[(int64_t)d << off_shift] + atomicAdd(&cursor[d], (unsigned long long)L.cnt[d]);
+        {   // exclusive scan of cnt[256] -> start[257]: one entry per lane
+            const uint32_t v = L.cnt[threadIdx.x];
+            uint32_t incl = v;
 #pragma unroll
-        for (int j = 0; j < 32; ++j)
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if ((int)(threadIdx.x & 63) >= d) incl += o;
+            }
+            if ((threadIdx.x & 63) == 63) L.wave_tot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += L.wave_tot[wv];
+            L.start[threadIdx.x] = before + incl - v;
+            if (threadIdx.x == BLOCK - 1) L.start[BLOCK] = before + incl;
+            if ((int)threadIdx.x < n_dig) { L.gbase[threadIdx.x] = L.cur[threadIdx.x]; L.cur[threadIdx.x] += v; }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < A1_CHARS; ++j)
             if ((ok >> j) & 1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
         __syncthreads();
-        // copy out run by run (a wave per digit): lanes write consecutive records of one digit to consecutive addresses
-        for (int d = threadIdx.x >> 6; d < n_dig; d += WAVES) {
-            const uint32_t a0 = L.start[d], c = L.start[d + 1] - a0;
-            const unsigned long long g0 = L.gbase[d];
-            for (uint32_t i = threadIdx.x & 63; i < c; i += 64) rec_out[g0 + i] = buf[a0 + i];
+        // copy out: LDS position i holds a record of digit d at rank i - start[d]; the digit is recomputed from the record
+        // (pure ALU), so the loop is a flat, pipelinable sweep and consecutive lanes write consecutive addresses per run
+        const uint32_t total = L.start[BLOCK];
+        for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {
+            const uint64_t r = buf[i];
+            const uint32_t d = (uint32_t)(mix64(r & REC_KEY_MASK) >> dsh);
+            rec_out[L.gbase[d] + (i - L.start[d])] = r;
         }
         __syncthreads();
     }
@@ -419,7 +500,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
 // Digit: DIG_HASH -> (mix64(key) >> dshift) & mask;  DIG_ROW -> (word >> dshift) & mask of a 32-bit (row, bin) word.
 // Destination of digit d: out[obase[(base + d) << oshift] + cursor[base + d] ...], base = flat ? 0 : region << dbits.
 enum { DIG_HASH = 0, DIG_ROW = 1 };
-template <typename REC, int DIG>
+template <typename REC, int DIG, int REC_PER_LANE>
 __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__restrict__ rec_in,
                                                                 const unsigned long long *__restrict__ in_begin,
                                                                 const unsigned long long *__restrict__ in_end, int in_shift,
@@ -428,6 +509,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
                                                                 unsigned long long *__restrict__ cursor, int oshift, int flat,
                                                                 int dbits, int dshift)
 {
+    constexpr int TILE1 = BLOCK * REC_PER_LANE;
     __shared__ REC buf[TILE1];
     __shared__ ScatterLds L;
     const int n_dig = 1 << dbits;
@@ -442,7 +524,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
         return ((uint32_t)r >> dshift) & dmask;
     };
     for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
-        for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt[i] = 0;
+        for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt()[i] = 0;
         __syncthreads();
         const int64_t t0 = r0 + tile * TILE1;
         REC rec[REC_PER_LANE];
@@ -457,23 +539,26 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) {
                 const uint32_t d = digit_of(rec[j]);
-                dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
+                dr[j] = (d << 16) | atomicAdd(&L.cnt()[d], 1u);
             }
         }
         __syncthreads();
         scatter_scan(L, n_dig);
-        for (int d = threadIdx.x; d < n_dig; d += BLOCK)
-            if (L.cnt[d]) L.gbase[d] = obase[(base_index + d) << oshift] + atomicAdd(&cursor[base_index + d], (unsigned long long)L.cnt[d]);
+        for (int d = threadIdx.x; d < n_dig; d += BLOCK) {          // cnt[] is gone (it shared gbase's storage): start[] has it
+            const uint32_t c = L.start[d + 1] - L.start[d];
+            if (c) L.gbase[d] = obase[(base_index + d) << oshift] + atomicAdd(&cursor[base_index + d], (unsigned long long)c);
+        }
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
         }
         __syncthreads();
-        for (int d = threadIdx.x >> 6; d < n_dig; d += WAVES) {
-            const uint32_t a0 = L.start[d], c = L.start[d + 1] - a0;
-            const unsigned long long g0 = L.gbase[d];
-            for (uint32_t i = threadIdx.x & 63; i < c; i += 64) rec_out[g0 + i] = buf[a0 + i];
+        const uint32_t total = L.start[n_dig];
+        for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {    // flat sweep: digit recomputed from the record
+            const REC r = buf[i];
+            const uint32_t d = digit_of(r);
+            rec_out[L.gbase[d] + (i - L.start[d])] = r;
         }
         __syncthreads();
     }
@@ -517,14 +602,21 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = accumulate ? slice[i] : 0ull;
     __syncthreads();
     bool full = false;
-    for (int64_t base = r0; base < r1; base += (int64_t)BIG_BLOCK * CNT_BATCH) {
+    // records are read as aligned 16-byte pairs: pair index q covers records 2q, 2q+1 of the buffer
+    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
+    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
+    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
         uint64_t rr[CNT_BATCH];
         bool live[CNT_BATCH];
 #pragma unroll
-        for (int j = 0; j < CNT_BATCH; ++j) {
-            const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            live[j] = i < r1;
-            rr[j] = live[j] ? rec[i] & REC_KEY_MASK : 0ull;
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            ulonglong2 v = make_ulonglong2(0ull, 0ull);
+            if (q < q1) v = rec2[q];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            rr[2 * j] = live[2 * j] ? v.x & REC_KEY_MASK : 0ull;
+            rr[2 * j + 1] = live[2 * j + 1] ? v.y & REC_KEY_MASK : 0ull;
         }
         uint32_t ss[CNT_BATCH];
         unsigned long long first[CNT_BATCH];
@@ -631,14 +723,20 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup_kernel(const uint64_t
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = slice[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    for (int64_t base = r0; base < r1; base += (int64_t)BIG_BLOCK * CNT_BATCH) {
+    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;                 // aligned 16-byte pairs, as in bucket_count_kernel
+    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
+    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
         uint64_t rr[CNT_BATCH];
         bool live[CNT_BATCH];
 #pragma unroll
-        for (int j = 0; j < CNT_BATCH; ++j) {
-            const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            live[j] = i < r1;
-            rr[j] = live[j] ? rec[i] : ~0ull;                       // a padding lane carries ROW_NONE
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            ulonglong2 v = make_ulonglong2(~0ull, ~0ull);            // a padding lane carries ROW_NONE
+            if (q < q1) v = rec2[q];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            rr[2 * j] = live[2 * j] ? v.x : ~0ull;
+            rr[2 * j + 1] = live[2 * j + 1] ? v.y : ~0ull;
         }
         uint32_t ss[CNT_BATCH];
         unsigned long long first[CNT_BATCH];
@@ -696,9 +794,16 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const uint32_t *__r
     __syncthreads();
     const int64_t a = (int64_t)goff[g], b = a + (int64_t)gcnt[g];
     const uint32_t bmask = (1u << vbits) - 1u;
-    for (int64_t i = a + threadIdx.x; i < b; i += BIG_BLOCK) {
-        const uint32_t e = words[i];
-        atomicAdd(&hist[((e >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e & bmask)], 1u);
+    for (int64_t base = a; base < b; base += (int64_t)BIG_BLOCK * 8) {
+        uint32_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                                // 8 loads per lane in flight
+            const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            e[j] = i < b ? words[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (e[j] != 0xffffffffu) atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e[j] & bmask)], 1u);
     }
     __syncthreads();
     int32_t *dst = abd_out + row0 * (int64_t)vsize;
@@ -867,7 +972,7 @@ HashView view_of(const pg_table *t)
 int raise_lds_limit(const void *kernel, size_t bytes, const char *who)
 {
     if (bytes <= 64 * 1024) return PG_OK;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
         return pg_fail(PG_EHIP, "%s: cannot raise the dynamic LDS limit", who);
     return PG_OK;
 }
@@ -875,8 +980,8 @@ int raise_lds_limit(const void *kernel, size_t bytes, const char *who)
 // workspace carving of the bucketed counter
 struct BucketPlan {
     int bits, bits1, bits2;           // bucket id bits, split over the two scatter passes
-    int64_t cap, n_tiles;             // record capacity of each record buffer; 256-word tiles of the range
-    size_t hist_off, off_off, cur1_off, cur2_off, tile_off, bufa_off, bufb_off, total;
+    int64_t cap, n_tiles, n_chunks;   // record capacity of each record buffer; stream tiles and chunks of the range
+    size_t hist_off, off_off, cur1_off, cur2_off, tile_off, chunk_off, bufa_off, bufb_off, total;
     size_t final_off() const { return bits2 ? bufb_off : bufa_off; }
 };
 
@@ -893,7 +998,8 @@ int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
     p->bits2 = p->bits - p->bits1;
     if (p->bits2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many buckets for two scatter passes");
     p->cap = n_words * 32;
-    p->n_tiles = (n_words + BLOCK - 1) / BLOCK;
+    p->n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
+    p->n_chunks = (n_words + CHUNK_WORDS - 1) / CHUNK_WORDS;
     const size_t nb = (size_t)1 << p->bits;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
@@ -902,6 +1008,7 @@ int plan_buckets(const pg_table *t, int64_t n_words, BucketPlan *p)
     p->cur1_off = take(((size_t)1 << p->bits1) * 8);
     p->cur2_off = take(nb * 8);
     p->tile_off = take((size_t)(p->n_tiles + 1) * 4);
+    p->chunk_off = take(((size_t)p->n_chunks << p->bits1) * 8);
     p->bufa_off = take((size_t)p->cap * 8);
     p->bufb_off = p->bits2 ? take((size_t)p->cap * 8) : p->bufa_off;
     p->total = o;
@@ -921,10 +1028,10 @@ int check_rows(const pg_rows *rows, const char *who)
 struct ShufflePlan {
     int vbits, gbits, gb1, gb2;
     int64_t n_groups, n_groups_padded;
-    size_t emit_off, caps_off, goff_off, gcur1_off, gcur2_off, words_e_off, words_a_off, words_b_off, total;
+    size_t emit_off, caps_off, goff_off, gcur1_off, gcur2_off, dhist_off, words_e_off, words_a_off, words_b_off, total;
 };
 
-int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, ShufflePlan *p)
+int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, ShufflePlan *p)
 {
     if (vsize < 1 || vsize > PG_SHUFFLE_MAX_VSIZE)
         return pg_fail(PG_EINVAL, "the shuffle path needs 1 <= vector size <= %d (got %d)", PG_SHUFFLE_MAX_VSIZE, vsize);
@@ -945,6 +1052,8 @@ int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, ShufflePlan *p)
     p->goff_off = take((size_t)(p->n_groups_padded + 1) * 8);
     p->gcur1_off = take(((size_t)1 << p->gb1) * 8);
     p->gcur2_off = take((size_t)p->n_groups_padded * 8);
+    p->dhist_off = o;
+    (void)n_buckets;
     p->words_e_off = take((size_t)cap * 4);                              // emitted by the lookup pass, bucket order
     p->words_a_off = take((size_t)cap * 4);                              // after the first row pass
     p->words_b_off = p->gb2 ? p->words_e_off : p->words_a_off;           // the second row pass reuses the first buffer
@@ -1015,44 +1124,50 @@ extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *val
     char *ws = (char *)workspace;
     auto *hist = (unsigned long long *)(ws + p.hist_off);
     auto *off = (unsigned long long *)(ws + p.off_off);
-    auto *cur1 = (unsigned long long *)(ws + p.cur1_off);
     auto *cur2 = (unsigned long long *)(ws + p.cur2_off);
     auto *tile_row = (int32_t *)(ws + p.tile_off);
+    auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
     auto *bufa = (uint64_t *)(ws + p.bufa_off);
     auto *bufb = (uint64_t *)(ws + p.bufb_off);
     const int nb = 1 << p.bits;
     // counters are contiguous at the front of the workspace: one clear
     if (hipMemsetAsync(ws, 0, p.tile_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_kmer_count_bucketed: memset failed");
-    const int64_t n_words = word_end - word_begin;
     const size_t slice_lds = (size_t)8 << t->log2_bucket_slots;
-    if ((rc = raise_lds_limit((const void *)bucket_hist_kernel, (size_t)(nb < (1 << 15) ? nb : (1 << 15)) * 4, "pg_kmer_count_bucketed"))) return rc;
+    const int hist_bins = nb < (1 << 15) ? nb : (1 << 15);
+    const size_t hist_lds = (size_t)hist_bins * 4 + 1024;
+    if ((rc = raise_lds_limit((const void *)bucket_hist_kernel, hist_lds, "pg_kmer_count_bucketed"))) return rc;
     if ((rc = raise_lds_limit((const void *)bucket_count_kernel, slice_lds, "pg_kmer_count_bucketed"))) return rc;
 
     const bool with_rows = rows && rows->n_rows > 0;
     if (with_rows)
         hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((p.n_tiles + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_end, rows->n_rows,
                            word_begin, p.n_tiles, tile_row);
-    // A0 histogram of final bucket ids, then offsets
+    // golden-ratio stride, made coprime to the chunk count: a bijection on chunk indices
+    int64_t chunk_stride = (int64_t)((double)p.n_chunks * 0.6180339887) | 1;
     {
-        int grid = (int)((n_words + BIG_BLOCK - 1) / BIG_BLOCK);
-        if (grid > 512) grid = 512;
-        const int per = nb < (1 << 15) ? nb : (1 << 15);
-        for (int base = 0; base < nb; base += per)
-            hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(BIG_BLOCK), (size_t)per * 4, s, codes, valid, word_begin, word_end,
-                               t->k, p.bits, (uint32_t)base, per, hist);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, hist, (int64_t)nb, off);
+        auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
+        while (gcd(chunk_stride, p.n_chunks) != 1) chunk_stride += 2;
     }
-    // A1: stream -> 2^bits1 regions (region d1 = final buckets [d1 << bits2, (d1+1) << bits2))
+    // A0 histogram of final bucket ids + per-chunk first-digit counts, then offsets of buckets and of chunks
     {
-        int grid = (int)(p.n_tiles > 8192 ? 8192 : p.n_tiles);
-        hipLaunchKernelGGL(scatter_stream_kernel, dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k, p.bits1,
-                           with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
-                           with_rows ? rows->n_rows : (int64_t)0, (const int32_t *)tile_row, bufa, (const unsigned long long *)off, cur1, p.bits2);
+        const int grid = (int)(p.n_chunks < 512 ? p.n_chunks : 512);
+        for (int base = 0; base < nb; base += hist_bins)
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(BIG_BLOCK), hist_lds, s, codes, valid, word_begin, word_end,
+                               t->k, p.bits, (uint32_t)base, hist_bins, hist, p.bits1, base == 0 ? chunk_tab : (unsigned long long *)nullptr, p.n_chunks,
+                               chunk_stride);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)hist, (int64_t)nb, off);
+        hipLaunchKernelGGL(digit_scan_kernel, dim3(1u << p.bits1), dim3(BIG_BLOCK), 0, s, chunk_tab, p.n_chunks, (const unsigned long long *)off,
+                           p.bits2, (unsigned long long *)nullptr);
     }
+    // A1: stream -> 2^bits1 regions (region d1 = final buckets [d1 << bits2, (d1+1) << bits2)); one workgroup per chunk
+    hipLaunchKernelGGL(scatter_stream_kernel, dim3((unsigned)p.n_chunks), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k, p.bits1,
+                       with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
+                       with_rows ? rows->n_rows : (int64_t)0, (const int32_t *)tile_row, bufa, (const unsigned long long *)chunk_tab, p.n_chunks,
+                       chunk_stride);
     // A2: every region -> its 2^bits2 final buckets
     if (p.bits2) {
         const int tiles_x = 96;
-        hipLaunchKernelGGL((scatter_records_kernel<uint64_t, DIG_HASH>), dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((scatter_records_kernel<uint64_t, DIG_HASH, RPL64>), dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s,
                            (const uint64_t *)bufa, (const unsigned long long *)off, (const unsigned long long *)(off + ((size_t)1 << p.bits2)),
                            p.bits2, (const unsigned long long *)nullptr, tiles_x, bufb, (const unsigned long long *)off, cur2, 0, 0,
                            p.bits2, 64 - p.bits);
@@ -1091,12 +1206,15 @@ extern "C" int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg,
     return check_launch("pg_kmer_merge_bucketed");
 }
 
-extern "C" int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize)
+extern "C" int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize, const pg_table *t)
 {
     if (n_words_counted < 0 || n_rows < 0) return pg_fail(PG_EINVAL, "negative size");
-    ShufflePlan sp;
-    int rc = plan_shuffle(n_words_counted * 32, n_rows, vsize, &sp);
+    int rc = check_table(t);
     if (rc) return rc;
+    BucketPlan p;
+    if ((rc = plan_buckets(t, n_words_counted, &p))) return rc;
+    ShufflePlan sp;
+    if ((rc = plan_shuffle(p.cap, n_rows, vsize, (int64_t)1 << p.bits, &sp))) return rc;
     return (int64_t)sp.total;
 }
 
@@ -1116,7 +1234,7 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     if ((rc = plan_buckets(t, n_words_counted, &p))) return rc;
     if ((int64_t)p.total > count_workspace_bytes) return pg_fail(PG_EINVAL, "pg_abundance_from_records: count workspace does not match n_words_counted");
     ShufflePlan sp;
-    if ((rc = plan_shuffle(p.cap, rows->n_rows, vsize, &sp))) return rc;
+    if ((rc = plan_shuffle(p.cap, rows->n_rows, vsize, (int64_t)1 << p.bits, &sp))) return rc;
     if ((int64_t)sp.total > workspace_bytes)
         return pg_fail(PG_EINVAL, "pg_abundance_from_records: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return pg_fail(PG_EINVAL, "pg_abundance_from_records: workspace must be 256-byte aligned");
@@ -1139,20 +1257,21 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
     if ((rc = raise_lds_limit((const void *)bucket_lookup_kernel, slice_lds, "pg_abundance_from_records"))) return rc;
     if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
-    if (hipMemsetAsync(ws, 0, sp.words_e_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
+    if (hipMemsetAsync(ws, 0, sp.dhist_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
 
     // row-group capacities -> offsets of the group regions
     hipLaunchKernelGGL(group_caps_kernel, dim3((unsigned)((sp.n_groups_padded + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_start, rows->row_end,
                        rows->n_rows, sp.n_groups_padded, caps);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)caps, sp.n_groups_padded, goff);
     // S1: counts out of the LDS copies of the slices -> (row, bin) words, packed per bucket
+    const int gshift = sp.vbits + GROUP_ROWS_LOG2;
     hipLaunchKernelGGL(bucket_lookup_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, recs, off, view_of(t), (uint32_t)window, (uint32_t)vsize, sp.vbits,
                        words_e, emit_end);
-    // S2: scatter the words by row group: first gb1 bits, then the remaining gb2 bits
-    const int gshift = sp.vbits + GROUP_ROWS_LOG2;
+    // S2a: scatter the words by the first gb1 bits of their row group (global cursors: measured faster here than
+    // per-bucket offsets, unlike the stream pass, because a bucket's few tiles would be serialised in one workgroup)
     {
         const int tiles_x = 4;
-        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW>), dim3((unsigned)(tiles_x * nb)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32>), dim3((unsigned)(tiles_x * nb)), dim3(BLOCK), 0, s,
                            (const uint32_t *)words_e, off, (const unsigned long long *)emit_end, 0, (const unsigned long long *)nullptr, tiles_x,
                            words_a, (const unsigned long long *)goff, gcur1, sp.gb2, 1, sp.gb1, gshift + sp.gb2);
     }
@@ -1160,7 +1279,7 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     const uint32_t *final_words = words_a;
     if (sp.gb2) {
         const int tiles_x = 64;
-        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW>), dim3((unsigned)(tiles_x << sp.gb1)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32>), dim3((unsigned)(tiles_x << sp.gb1)), dim3(BLOCK), 0, s,
                            (const uint32_t *)words_a, (const unsigned long long *)goff, (const unsigned long long *)nullptr, sp.gb2,
                            (const unsigned long long *)gcur1, tiles_x, words_b, (const unsigned long long *)goff, gcur2, 0, 0, sp.gb2, gshift);
         gcnt = gcur2;

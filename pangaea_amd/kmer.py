@@ -175,7 +175,7 @@ class KmerTable:
             raise RuntimeError("no partition records for these rows: count(stream, rows=plan) first")
         n_words = self._records[1]
         L = _lib.load()
-        need = _lib.check(L.pg_abundance_workspace_bytes(n_words, plan.n_rows, vsize))
+        need = _lib.check(L.pg_abundance_workspace_bytes(n_words, plan.n_rows, vsize, self.desc()))
         if self._shuffle_ws is None or self._shuffle_ws.numel() < need:
             self._shuffle_ws = None
             self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
