@@ -15,17 +15,38 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE = {"bucket_hist_kernel": "kmer_count", "bucket_scan_kernel": "kmer_count", "scatter_stream_kernel": "kmer_count",
-         "scatter_records_kernel": "kmer_count", "bucket_count_kernel": "kmer_count", "kmer_count_kernel": "kmer_count",
-         "features_kernel": "features", "bucket_lookup_kernel": "features", "scatter_bins_kernel": "features",
-         "row_hist_kernel": "features"}
+# kernel (as it appears in rocprofv3 names) -> (stage, FETCH_SIZE correction).  gfx950's FETCH_SIZE counts 64 B per 128-B
+# request of a wide coalesced stream (MI355X_MICROARCH.md, HBM section), i.e. half the bytes; the factor is calibrated per
+# kernel on byte counts known exactly for this workload:
+#   scatter_records<unsigned long>  reads 2.6e9 records x 8 B = 20.8 GB, reports 10.4 GB            -> x2
+#   bucket_count / bucket_lookup    read the same 20.8 GB (+ 4.3 GB of slices), report 10.4 / 12.6   -> x2
+#   scatter_records<unsigned int>, row_hist read 4-byte words with 4 B/lane coalesced loads          -> x2 (same pattern class)
+#   bucket_hist / features<NONE>    read the 1.13 GB stream with 8 B + 4 B per lane, report 0.6 GB   -> x2
+#   scatter_stream                  two lanes share each 8-byte word; reports the 1.13 GB as it is   -> x1
+#   features<HASH> / kmer_count     one random 8-byte slot per lane = one 64-B request each          -> x1
+KERNELS = [
+    ("bucket_hist_kernel", "kmer_count", 2.0), ("scan_kernel", "kmer_count", 1.0), ("digit_scan_kernel", "kmer_count", 1.0),
+    ("tile_rows_kernel", "kmer_count", 1.0), ("scatter_stream_kernel", "kmer_count", 1.0),
+    ("scatter_records_kernel<unsigned long", "kmer_count", 2.0), ("bucket_count_kernel", "kmer_count", 2.0),
+    ("kmer_count_kernel", "kmer_count", 1.0),
+    ("bucket_lookup_kernel", "features", 2.0), ("scatter_records_kernel<unsigned int", "features", 2.0),
+    ("row_hist_kernel", "features", 2.0), ("group_caps_kernel", "features", 1.0),
+    ("features_kernel<unsigned int, 0", "features", 2.0), ("features_kernel", "features", 1.0),
+]
 
 
 def short(name):
-    for k in STAGE:
-        if k in name:
-            return k
+    for key, _, _ in KERNELS:
+        if key in name:
+            return key
     return None
+
+
+def info(key):
+    for k, stage, corr in KERNELS:
+        if k == key:
+            return stage, corr
+    raise KeyError(key)
 
 
 def main():
@@ -53,24 +74,19 @@ def main():
                     e["launches"] += 1
     stages = {}
     for k, e in detail.items():
-        # streaming kernels read with wide coalesced loads: FETCH_SIZE under-counts those by 2x on gfx950
-        # (MI355X_MICROARCH.md, HBM section).  The table lookups of features_kernel / kmer_count_kernel are one 8-byte
-        # slot per lane at random addresses = one 64-B request each, which the raw count already matches.
-        # Calibrated on known byte counts of this workload: scatter_records reads exactly 2.6e9 records x 8 B = 20.8 GB
-        # and reports 10.45 GB; the stream readers read 1.13 GB of codes+validity and report 0.61 GB.
-        wide = k in ("scatter_records_kernel", "bucket_count_kernel", "bucket_lookup_kernel", "scatter_bins_kernel", "row_hist_kernel",
-                     "bucket_hist_kernel", "scatter_stream_kernel")
-        e["fetch_correction"] = 2.0 if wide else 1.0
-        e["hbm_bytes"] = (e["FETCH_SIZE_KB"] * e["fetch_correction"] + e["WRITE_SIZE_KB"]) * 1024
-        stages[STAGE[k]] = stages.get(STAGE[k], 0.0) + e["hbm_bytes"]
+        stage, corr = info(k)
+        e["fetch_correction"] = corr
+        e["hbm_bytes"] = (e["FETCH_SIZE_KB"] * corr + e["WRITE_SIZE_KB"]) * 1024
+        stages[stage] = stages.get(stage, 0.0) + e["hbm_bytes"]
     json.dump({"pairs": pairs, "tag": tag,
                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around bench.py --steps 1 --warmup 0",
                "note": "counters are KiB; per kernel: hbm_bytes = (FETCH_SIZE x fetch_correction + WRITE_SIZE) x 1024; "
-                       "fetch_correction = 2 for kernels whose reads are wide coalesced streams (gfx950 FETCH_SIZE counts 64 B per "
-                       "128-B request), 1 for random 8-byte slot reads; stages sum their kernels, one launch of each per step",
+                       "fetch_correction = 2 for kernels whose reads are coalesced streams (gfx950 FETCH_SIZE counts 64 B per "
+                       "128-B request; calibrated on known byte counts, see tools/collect_profiles.py), 1 otherwise; stages sum "
+                       "their kernels' launches of one step",
                "detail": detail, "kernels": stages}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     for k, e in sorted(detail.items()):
-        print(f"{k:26s} fetch {e['FETCH_SIZE_KB']*1024/1e9:8.2f} GB (x{e['fetch_correction']:.0f})  write {e['WRITE_SIZE_KB']*1024/1e9:8.2f} GB")
+        print(f"{k:40s} fetch {e['FETCH_SIZE_KB']*1024/1e9:8.2f} GB (x{e['fetch_correction']:.0f})  write {e['WRITE_SIZE_KB']*1024/1e9:8.2f} GB")
     print(stages)
 
 
