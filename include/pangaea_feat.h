@@ -65,6 +65,9 @@ int pg_device_count(void);
 typedef struct pg_reads pg_reads;
 
 int pg_ingest_fastq(const char *r1_or_interleaved, const char *r2_or_null, pg_reads **out);
+/* Threads the interleaved parser may use (0 = all hardware threads, at most 32; PG_INGEST_THREADS overrides the
+ * default).  The result does not depend on it. */
+void pg_set_ingest_threads(int n);
 void pg_reads_free(pg_reads *r);
 int64_t pg_reads_n_chars(const pg_reads *r);
 int64_t pg_reads_n_words(const pg_reads *r); /* padded word count of codes[] and valid[] */

@@ -11,11 +11,19 @@
 // memchr; characters go straight into 2-bit/1-bit words; a run is only a pair of stream offsets.
 #include <stdarg.h>
 #include <stdio.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -75,27 +83,80 @@ struct StreamWriter {
     }
 };
 
-// whole-file decode; zlib reads gzip and plain files alike
-int slurp(const char *path, std::string &out)
+// a whole file in memory (malloc'd: no zero fill of hundreds of MB before they are overwritten)
+struct FileBuf {
+    char *p = nullptr;
+    size_t n = 0;
+    FileBuf() = default;
+    FileBuf(const FileBuf &) = delete;
+    FileBuf &operator=(const FileBuf &) = delete;
+    ~FileBuf() { free(p); }
+    const char *data() const { return p ? p : ""; }
+    size_t size() const { return n; }
+    bool reserve_exact(size_t cap) { char *q = (char *)realloc(p, cap ? cap : 1); if (!q) return false; p = q; return true; }
+};
+
+int ingest_threads();
+template <typename F> void run_threads(int T, F &&f);
+
+// whole file into memory.  Plain files are read straight into a buffer of the file's size; gzip files (magic 1f 8b) go
+// through zlib -- so both kinds are accepted transparently, as gzstream's gzopen does for the reference.
+int slurp(const char *path, FileBuf &out)
 {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return pg_fail(PG_EIO, "cannot open %s", path);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got_magic = pread(fd, magic, 2, 0);
+    const bool gz = got_magic == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    struct stat st;
+    const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    if (!gz && regular) {
+        const size_t size = (size_t)st.st_size;
+        if (!out.reserve_exact(size)) { close(fd); return pg_fail(PG_ENOMEM, "out of memory reading %s", path); }
+        // page-cache (or NVMe) reads scale with threads: every thread preads its own slice
+        const int T = size >= ((size_t)8 << 20) ? ingest_threads() : 1;
+        std::vector<char> bad(T, 0);
+        run_threads(T, [&](int t) {
+            size_t a = size * (size_t)t / T, b = size * (size_t)(t + 1) / T;
+            while (a < b) {
+                const ssize_t got = pread(fd, out.p + a, b - a, (off_t)a);
+                if (got <= 0) { bad[t] = 1; return; }
+                a += (size_t)got;
+            }
+        });
+        close(fd);
+        for (char x : bad) if (x) return pg_fail(PG_EIO, "read error in %s", path);
+        out.n = size;
+        return PG_OK;
+    }
+    close(fd);
+    // gzip (or a pipe): zlib reads both, as the reference's gzstream does
     gzFile f = gzopen(path, "rb");
     if (!f) return pg_fail(PG_EIO, "cannot open %s", path);
     gzbuffer(f, 1 << 22);
-    std::vector<char> buf(1 << 22);
+    size_t cap = (size_t)1 << 24;
+    if (!out.reserve_exact(cap)) { gzclose(f); return pg_fail(PG_ENOMEM, "out of memory reading %s", path); }
+    size_t n = 0;
     for (;;) {
-        int got = gzread(f, buf.data(), (unsigned)buf.size());
+        if (cap - n < ((size_t)1 << 22)) {
+            cap *= 2;
+            if (!out.reserve_exact(cap)) { gzclose(f); return pg_fail(PG_ENOMEM, "out of memory reading %s", path); }
+        }
+        int got = gzread(f, out.p + n, (unsigned)std::min<size_t>(cap - n, (size_t)1 << 30));
         if (got < 0) { gzclose(f); return pg_fail(PG_EIO, "read error in %s", path); }
         if (got == 0) break;
-        out.append(buf.data(), (size_t)got);
+        n += (size_t)got;
     }
     gzclose(f);
+    out.n = n;
     return PG_OK;
 }
 
 // getline-style cursor over an in-memory file
 struct Lines {
     const char *p, *end;
-    explicit Lines(const std::string &s) : p(s.data()), end(s.data() + s.size()) {}
+    explicit Lines(const FileBuf &s) : p(s.data()), end(s.data() + s.size()) {}
+    Lines(const char *b, size_t n) : p(b), end(b + n) {}
     bool next(const char *&b, size_t &len)
     {
         if (p >= end) return false;
@@ -174,14 +235,239 @@ struct pg_reads {
     int mode = MODE_UNSET;
 };
 
+// ------------------------------------------------------------------------------------ parallel interleaved ingest
+//
+// Same result as the serial loop below, in phases that each split the in-memory file over T threads:
+//   1. line index   : newline counts per byte chunk -> byte offset of any line number
+//   2. latch scan   : first header that fixes the grammar ("BX:Z" -> 10x, else '#' -> stLFR); headers before it are
+//                     parsed with the grammar still undecided, exactly as the sequential latch would
+//   3. parse        : per 8-line unit: barcode span, sequence spans, character count
+//   4. prefix       : character offset of every thread's first unit
+//   5. pack         : 2-bit codes + validity written at their exact bit offsets (atomic OR only on the words two
+//                     threads share)
+//   6. runs         : barcode change points stitched across threads, in order (the append-then-compare rule)
+namespace {
+
+int g_ingest_threads = 0;      // 0 = hardware concurrency (capped)
+
+int ingest_threads()
+{
+    if (g_ingest_threads > 0) return g_ingest_threads;
+    if (const char *e = getenv("PG_INGEST_THREADS")) { int v = atoi(e); if (v > 0) return v; }
+    unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(hc ? hc : 1, 32);
+}
+
+template <typename F> void run_threads(int T, F &&f)
+{
+    std::vector<std::thread> th;
+    th.reserve(T);
+    for (int t = 1; t < T; ++t) th.emplace_back([&f, t] { f(t); });
+    f(0);
+    for (auto &x : th) x.join();
+}
+
+struct Unit {                 // one 8-line record group of the interleaved file
+    const char *bc; uint32_t bc_n;
+    const char *s1; uint32_t s1_n;
+    const char *s2; uint32_t s2_n;
+    uint8_t have;             // bit0: line 2 present, bit1: line 6 present (pair complete), bit2: bad header
+};
+
+struct Packer {               // writes characters at absolute positions into shared word arrays
+    uint64_t *codes; uint32_t *valid;
+    int64_t pos, first_word, last_word;
+    uint64_t cw = 0; uint32_t vw = 0;
+    void flush()
+    {
+        const int64_t w = (pos - 1) >> 5;
+        if (w == first_word || w == last_word) {
+            __atomic_fetch_or(&codes[w], cw, __ATOMIC_RELAXED);
+            __atomic_fetch_or(&valid[w], vw, __ATOMIC_RELAXED);
+        } else {
+            codes[w] = cw; valid[w] = vw;
+        }
+        cw = 0; vw = 0;
+    }
+    inline void put(unsigned char c)
+    {
+        const bool ok = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+        const int sh = (int)(pos & 31);
+        if (ok) { cw |= (uint64_t)((c >> 1) & 3) << (2 * sh); vw |= 1u << sh; }
+        ++pos;
+        if (sh == 31) flush();
+    }
+    void finish() { if (pos & 31) flush(); }
+};
+
+struct PhaseTimer {
+    bool on = getenv("PG_INGEST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pg_ingest] %-10s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+int ingest_interleaved_parallel(const FileBuf &f, const char *path, pg_reads *R, int T)
+{
+    PhaseTimer tm;
+    const char *base = f.data();
+    const size_t n = f.size();
+    // ---- 1. line index
+    std::vector<size_t> cb(T + 1);
+    for (int t = 0; t <= T; ++t) cb[t] = n * (size_t)t / T;
+    std::vector<uint64_t> nl(T, 0);
+    run_threads(T, [&](int t) {
+        uint64_t c = 0;
+        const char *p = base + cb[t], *e = base + cb[t + 1];
+        while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = q + 1; }
+        nl[t] = c;
+    });
+    std::vector<uint64_t> nl_before(T + 1, 0);
+    for (int t = 0; t < T; ++t) nl_before[t + 1] = nl_before[t] + nl[t];
+    const uint64_t n_lines = nl_before[T] + ((n && base[n - 1] != '\n') ? 1 : 0);
+    const uint64_t n_units = (n_lines + 7) / 8;
+    if (n_units == 0) { R->run_off.push_back(0); R->run_name.emplace_back(); R->st.finish(); return PG_OK; }
+    // byte offset of the first character of line `ln` (0-based)
+    auto line_start = [&](uint64_t ln) -> size_t {
+        if (ln == 0) return 0;
+        // the ln-th newline (1-based) ends line ln-1; find the chunk holding it
+        int t = (int)(std::upper_bound(nl_before.begin(), nl_before.end(), ln - 1) - nl_before.begin()) - 1;
+        uint64_t need = ln - nl_before[t];
+        const char *p = base + cb[t], *e = base + cb[t + 1];
+        while (need) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); p = q + 1; --need; }
+        return (size_t)(p - base);
+    };
+    // units per thread
+    std::vector<uint64_t> ub(T + 1);
+    for (int t = 0; t <= T; ++t) ub[t] = n_units * (uint64_t)t / T;
+    std::vector<size_t> ustart(T + 1);
+    run_threads(T, [&](int t) { ustart[t] = ub[t] < n_units ? line_start(ub[t] * 8) : n; });
+    ustart[T] = n;
+    tm.lap("lines");
+    // ---- 2. latch scan
+    struct Latch { uint64_t unit; int mode; };
+    std::vector<Latch> latch(T, Latch{UINT64_MAX, MODE_UNSET});
+    run_threads(T, [&](int t) {
+        const char *p = base + ustart[t], *e = base + n;
+        for (uint64_t u = ub[t]; u < ub[t + 1] && p < e; ++u) {
+            const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+            const size_t len = q ? (size_t)(q - p) : (size_t)(e - p);
+            int m = MODE_UNSET;
+            if (find_bxz(p, len) != NPOS) m = MODE_10X;
+            else if (find_chr(p, len, '#', 0) != NPOS) m = MODE_STLFR;
+            if (m != MODE_UNSET) { latch[t] = Latch{u, m}; return; }
+            // skip the other 7 lines of the unit
+            const char *r = q ? q + 1 : e;
+            for (int k = 0; k < 7 && r < e; ++k) { const char *z = (const char *)memchr(r, '\n', (size_t)(e - r)); r = z ? z + 1 : e; }
+            p = r;
+        }
+    });
+    Latch L{UINT64_MAX, MODE_UNSET};
+    for (int t = 0; t < T; ++t) if (latch[t].unit < L.unit) L = latch[t];
+    tm.lap("latch");
+    // ---- 3. parse
+    std::vector<std::vector<Unit>> units(T);
+    std::vector<int64_t> chars(T, 0), pairs(T, 0);
+    std::vector<uint64_t> bad(T, UINT64_MAX);
+    run_threads(T, [&](int t) {
+        auto &U = units[t];
+        U.reserve((size_t)(ub[t + 1] - ub[t]));
+        const char *p = base + ustart[t], *e = base + n;
+        int64_t c = 0, np = 0;
+        for (uint64_t u = ub[t]; u < ub[t + 1]; ++u) {
+            Unit x{nullptr, 0, nullptr, 0, nullptr, 0, 0};
+            for (int k = 1; k <= 8 && p < e; ++k) {
+                const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+                const size_t len = q ? (size_t)(q - p) : (size_t)(e - p);
+                if (k == 1) {
+                    int mode = u < L.unit ? MODE_UNSET : L.mode;      // the latching header decides for itself
+                    Span nm, bc;
+                    if (!header_fields(p, len, mode, nm, bc)) { x.have |= 4; if (bad[t] == UINT64_MAX) bad[t] = u; }
+                    x.bc = p + bc.b; x.bc_n = (uint32_t)bc.n;
+                } else if (k == 2) {
+                    x.s1 = p; x.s1_n = (uint32_t)len; x.have |= 1; c += (int64_t)len + 1;
+                } else if (k == 6) {
+                    x.s2 = p; x.s2_n = (uint32_t)len; x.have |= 2; c += (int64_t)len + 1; ++np;
+                }
+                p = q ? q + 1 : e;
+            }
+            U.push_back(x);
+        }
+        chars[t] = c; pairs[t] = np;
+    });
+    uint64_t first_bad = UINT64_MAX;
+    for (int t = 0; t < T; ++t) first_bad = std::min(first_bad, bad[t]);
+    if (first_bad != UINT64_MAX)
+        return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag (the reference aborts here)", path, (unsigned long long)(first_bad * 8 + 1));
+    tm.lap("parse");
+    // ---- 4. prefix
+    std::vector<int64_t> cstart(T + 1, 0);
+    for (int t = 0; t < T; ++t) cstart[t + 1] = cstart[t] + chars[t];
+    const int64_t total = cstart[T];
+    {
+        size_t words = (size_t)((total + 31) / 32);
+        size_t padded = (words + PG_WORD_ALIGN - 1) / PG_WORD_ALIGN * PG_WORD_ALIGN;
+        if (padded == 0) padded = PG_WORD_ALIGN;
+        R->st.codes.assign(padded, 0);
+        R->st.valid.assign(padded, 0);
+        R->st.n = total;
+    }
+    tm.lap("alloc");
+    // ---- 5. pack
+    run_threads(T, [&](int t) {
+        if (chars[t] == 0) return;
+        Packer P{R->st.codes.data(), R->st.valid.data(), cstart[t], cstart[t] >> 5, (cstart[t + 1] - 1) >> 5};
+        for (const Unit &x : units[t]) {
+            if (x.have & 1) { for (uint32_t i = 0; i < x.s1_n; ++i) P.put((unsigned char)x.s1[i]); P.put('N'); }
+            if (x.have & 2) { for (uint32_t i = 0; i < x.s2_n; ++i) P.put((unsigned char)x.s2[i]); P.put('N'); }
+        }
+        P.finish();
+    });
+    tm.lap("pack");
+    // ---- 6. runs (sequential over units, but only string compares)
+    R->mode = L.mode;
+    R->run_off.push_back(0);
+    const char *last = ""; uint32_t last_n = 0;
+    int64_t pos = 0;
+    for (int t = 0; t < T; ++t) {
+        R->n_pairs += pairs[t];
+        for (const Unit &x : units[t]) {
+            if (x.have & 1) pos += (int64_t)x.s1_n + 1;
+            if (x.have & 2) {
+                pos += (int64_t)x.s2_n + 1;
+                if (x.bc_n != last_n || (last_n && memcmp(x.bc, last, last_n) != 0)) {
+                    R->run_off.push_back(pos);
+                    R->run_name.emplace_back(last, last_n);
+                    last = x.bc; last_n = x.bc_n;
+                }
+            }
+        }
+    }
+    R->run_off.push_back(pos);
+    R->run_name.emplace_back(last, last_n);
+    tm.lap("runs");
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" void pg_set_ingest_threads(int n) { g_ingest_threads = n > 0 ? n : 0; }
+
 extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
 {
     if (!r1 || !out) return pg_fail(PG_EINVAL, "pg_ingest_fastq: null argument");
     *out = nullptr;
-    std::string f1, f2;
+    FileBuf f1, f2;
+    PhaseTimer tm_read;
     int rc = slurp(r1, f1);
     if (rc) return rc;
     if (r2 && (rc = slurp(r2, f2))) return rc;
+    tm_read.lap("read");
 
     pg_reads *R = new (std::nothrow) pg_reads();
     if (!R) return pg_fail(PG_ENOMEM, "out of memory");
@@ -193,6 +479,14 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
         const char *b; size_t len;
         Span nm, bc;
 
+        const int T = ingest_threads();
+        if (!r2 && T > 1 && f1.size() >= ((size_t)1 << 16) * (size_t)T) {
+            R->run_off.clear();
+            rc = ingest_interleaved_parallel(f1, r1, R, T);
+            if (rc) { delete R; return rc; }
+            *out = R;
+            return PG_OK;
+        }
         if (!r2) {
             Lines L(f1);
             uint64_t line_no = 0;
@@ -465,7 +759,7 @@ extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clus
         for (auto &b : bins) { b.flush(); if (b.fq) fclose(b.fq); if (b.bc) fclose(b.bc); }
     };
     {
-        Lines L(tsv);
+        Lines L(tsv.data(), tsv.size());
         const char *b; size_t len;
         while (L.next(b, len)) {
             size_t pos = find_chr(b, len, '\t', 0);
@@ -492,7 +786,7 @@ extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clus
             }
         }
     }
-    std::string f1, f2;
+    FileBuf f1, f2;
     int rc = slurp(r1, f1);
     if (!rc && r2) rc = slurp(r2, f2);
     if (rc) { close_all(); return rc; }

@@ -156,3 +156,31 @@ def test_kernels_refuse_cpu_tensors():
         kmer.features(s, s.rows(0), k_tnf=4)
     with pytest.raises(ValueError):
         kmer.KmerTable.default_kind(22)
+
+
+def test_parallel_ingest_equals_serial(tmp_path):
+    """the threaded interleaved parser (line index, latch scan, parse, bit-offset packing, run stitching) gives the very
+    same stream, runs and counters as the sequential loop, for any thread count, also when the grammar latches late"""
+    from pangaea_amd import synth
+    L = _lib.load()
+    cfg = synth.SynthConfig(n_pairs=9000, n_barcodes=41, n_genomes=2, genome_len=30_000, fragment=5_000, n_rate=0.3, unbarcoded=0.05)
+    fq = str(tmp_path / "a.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, fq)
+    # prepend untagged pairs (grammar undecided for a while) and cut the last record short
+    text = open(fq).read()
+    head = "".join(f"@u{i}/1\nACGTNACGT\n+\nIIIIIIIII\n@u{i}/2\nTTGCA\n+\nIIIII\n" for i in range(700))
+    lines = (head + text).splitlines(keepends=True)
+    open(fq, "w").write("".join(lines[:-5]))
+    try:
+        L.pg_set_ingest_threads(1)
+        ref = ReadStream.from_fastq(fq)
+        for T in (2, 3, 7, 16):
+            L.pg_set_ingest_threads(T)
+            got = ReadStream.from_fastq(fq)
+            assert np.array_equal(ref.codes.numpy(), got.codes.numpy()) and np.array_equal(ref.valid.numpy(), got.valid.numpy())
+            assert np.array_equal(ref.run_off, got.run_off) and ref.run_names == got.run_names
+            assert (ref.n_chars, ref.n_pairs, ref.mode) == (got.n_chars, got.n_pairs, got.mode)
+    finally:
+        L.pg_set_ingest_threads(0)
+    rd = oracle.Reads(fq)
+    assert ref.run_names == rd.names and np.array_equal(ref.run_off, rd.seq_off) and ref.n_pairs == rd.n_pairs

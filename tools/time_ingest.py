@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""time pg_ingest_fastq on a synthetic interleaved FASTQ for several thread counts (host-only; no GPU work)"""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pangaea_amd import _lib, synth  # noqa: E402
+
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
+path = "/tmp/pg_ingest_test.fq"
+cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=max(1, n_pairs // 200))
+synth.write_fastq(synth.generate(cfg), cfg, path)
+L = _lib.load()
+print(f"{n_pairs} pairs, {os.path.getsize(path) / 1e6:.0f} MB, nproc {os.cpu_count()}, affinity {len(os.sched_getaffinity(0))}")
+for T in (1, 2, 4, 8, 16, 32):
+    L.pg_set_ingest_threads(T)
+    best = 1e9
+    for _ in range(3):
+        h = C.c_void_p()
+        t = time.perf_counter()
+        _lib.check(L.pg_ingest_fastq(path.encode(), None, C.byref(h)))
+        best = min(best, time.perf_counter() - t)
+        L.pg_reads_free(h)
+    print(f"threads {T:2d}: {best * 1e3:7.1f} ms  {n_pairs / best / 1e6:6.2f} M pairs/s")
+os.remove(path)
