@@ -22,6 +22,7 @@ def test_integration_stub_runs_and_matches_oracle():
     stub = stub.replace('b"reads.sorted.fastq"', repr(fq.encode()))
     stub = stub.replace("1 << 29", "1 << 16").replace("pg_table(2, 21, 29, 0,", "pg_table(2, 21, 16, 0,")
     stub = stub.replace("L.pg_reads_rows(h, 2000,", "L.pg_reads_rows(h, 1000,")
+    assert "1 << 16" in stub and "(h, 1000," in stub
     ns = {}
     exec(stub, ns)
     rd = oracle.Reads(fq)
