@@ -31,7 +31,7 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "liboracle.so")
+    path = os.environ.get("PG_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # PG_ORACLE_LIB: sanitizer builds
     if not os.path.exists(path):
         build(ref=False)
     L = C.CDLL(path)
@@ -276,3 +276,33 @@ def vae_embedding(state: dict, abd: np.ndarray, tnf: np.ndarray) -> np.ndarray:
                          training=False, eps=1e-5)
         x = F.leaky_relu(x, negative_slope=1.0)
     return F.linear(x, t["l_mu.weight"], t["l_mu.bias"]).numpy()
+
+
+def vae_forward_loss(state: dict, abd: np.ndarray, tnf: np.ndarray, epsilon: np.ndarray, wa: float, wt: float, w_kl: float):
+    """eval-mode training forward (``forward`` + ``unlabeled_loss``): encoder -> mu, logsigma = softplus(l_sigma(h)),
+    z = mu + eps * exp(logsigma / 2), decoder (same layer pattern) -> output -> softmax over the two blocks; losses =
+    cross entropies with eps 1e-9, KL = -1/2 sum(1 + logsigma - mu^2 - exp(logsigma)), total = wa*abd + wt*tnf + w_kl*KL."""
+    import torch
+    import torch.nn.functional as F
+
+    t = {k: torch.as_tensor(np.asarray(v)) for k, v in state.items()}
+
+    def stack(x, prefix):
+        for lin, bn in ((prefix + ".0", prefix + ".1"), (prefix + ".4", prefix + ".5")):
+            x = F.linear(x, t[lin + ".weight"], t[lin + ".bias"])
+            x = F.batch_norm(x, t[bn + ".running_mean"], t[bn + ".running_var"], t[bn + ".weight"], t[bn + ".bias"], training=False, eps=1e-5)
+        return x
+
+    a, b = torch.as_tensor(abd).float(), torch.as_tensor(tnf).float()
+    h = stack(torch.cat([a, b], 1), "encoder")
+    mu = F.linear(h, t["l_mu.weight"], t["l_mu.bias"])
+    logsigma = F.softplus(F.linear(h, t["l_sigma.weight"], t["l_sigma.bias"]))
+    z = mu + torch.as_tensor(epsilon) * torch.exp(logsigma / 2)
+    out = F.linear(stack(z, "decoder"), t["output.weight"], t["output.bias"])
+    n_abd = a.shape[1]
+    abd_rec, tnf_rec = F.softmax(out[:, :n_abd], 1), F.softmax(out[:, n_abd:], 1)
+    l_abd = -(torch.log(abd_rec + 1e-9) * a).sum(-1).mean()
+    l_tnf = -(torch.log(tnf_rec + 1e-9) * b).sum(-1).mean()
+    l_kl = (-0.5 * (1 + logsigma - mu.pow(2) - logsigma.exp()).sum(1)).mean()
+    return {"mu": mu.numpy(), "logsigma": logsigma.numpy(), "abd_rec": abd_rec.numpy(), "tnf_rec": tnf_rec.numpy(),
+            "abd": float(l_abd), "tnf": float(l_tnf), "kl": float(l_kl), "total": float(wa * l_abd + wt * l_tnf + w_kl * l_kl)}

@@ -1,0 +1,112 @@
+"""``pangaea_amd.data.Data`` and ``pangaea_amd.models.VAENET`` against vectors produced by the reference's own modules
+(tests/golden/data_g4.npz, vae_g5.npz) and against the oracle's restatements; CPU-torch and GPU variants.
+Tolerance for latents: 1e-5 relative to max |mu| (north-star), fp32; Data is bit-exact (fp64 division of integers)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from pangaea_amd.data import Data
+from pangaea_amd.loader import shuffled_batches, weighted_batches
+from pangaea_amd.models.VAENET import VAENET, VaritionalAutoEncoder
+
+from .conftest import GOLDEN
+
+DEVICES = ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)]
+
+
+def _g5():
+    g = np.load(os.path.join(GOLDEN, "vae_g5.npz"))
+    return g, {k[len("state/"):]: g[k] for k in g.files if k.startswith("state/")}
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_data_is_bit_identical_to_reference(device):
+    g = np.load(os.path.join(GOLDEN, "data_g4.npz"))
+    d = Data(np.array([f"bc{i}" for i in range(37)], dtype=object), g["abd_in"], g["tnf_in"], device=device)
+    assert d.abd.dtype == np.float32 and d.tnf.dtype == np.float32 and d.weights.dtype == np.float64
+    assert np.array_equal(d.abd, g["abd"]) and np.array_equal(d.tnf, g["tnf"]) and np.array_equal(d.weights, g["weights"])
+    item = d[3]
+    assert set(item) == {"abd", "tnf", "bc"} and item["bc"] == "bc3"
+    assert np.array_equal(item["abd"], g["item3_abd"]) and np.array_equal(item["tnf"], g["item3_tnf"]) and len(d) == 37
+    # device tensors given directly (what the feature kernels hand over) behave the same
+    d2 = Data(d.bc, torch.from_numpy(g["abd_in"]).to(device), torch.from_numpy(g["tnf_in"]).to(device))
+    assert np.array_equal(d2.abd, g["abd"]) and np.array_equal(d2.weights, g["weights"])
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_network_matches_reference_vectors(device):
+    g, state = _g5()
+    net = VaritionalAutoEncoder(400, 136, hidden_sizes=[48, 40]).to(device)
+    assert set(net.state_dict()) == set(state)                       # the reference's state_dict keys
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    net.eval()
+    abd, tnf, eps = (torch.from_numpy(g[k]).to(device) for k in ("abd", "tnf", "epsilon"))
+    scale = np.abs(g["mu"]).max()
+    with torch.no_grad():
+        mu = net.emebdding(abd, tnf).cpu().numpy()
+        out = net(abd, tnf, eps)
+    assert np.abs(mu - g["mu"]).max() <= 1e-5 * scale
+    assert np.abs(mu - oracle.vae_embedding(state, g["abd"], g["tnf"])).max() <= 1e-5 * scale
+    for key, ref in (("mu", "fwd_mu"), ("logsigma", "fwd_logsigma"), ("abd_rec", "fwd_abd_rec"), ("tnf_rec", "fwd_tnf_rec")):
+        assert np.abs(out[key].cpu().numpy() - g[ref]).max() <= 1e-5 * max(1e-3, np.abs(g[ref]).max()), key
+    vn = VAENET(400, 136, 32, 5, 1, device != "cpu", 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+    assert np.isclose(vn.wa, float(g["wa"])) and np.isclose(vn.wt, float(g["wt"])) and np.isclose(vn.w_kl, float(g["w_kl"]))
+    losses = vn.unlabeled_loss(out)
+    for key, ref in (("total", "loss_total"), ("abd_rec", "loss_abd"), ("tnf_rec", "loss_tnf"), ("kl_loss", "loss_kl")):
+        assert abs(losses[key].item() - float(g[ref])) <= 1e-5 * abs(float(g[ref])), key
+    o = oracle.vae_forward_loss(state, g["abd"], g["tnf"], g["epsilon"], vn.wa, vn.wt, vn.w_kl)
+    assert abs(o["total"] - float(g["loss_total"])) <= 1e-5 * abs(float(g["loss_total"]))
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_train_writes_the_reference_files_and_resumes(device, tmp_path):
+    rs = np.random.RandomState(0)
+    n = 300
+    abd = rs.poisson(2.0, (n, 400)); tnf = rs.poisson(30.0, (n, 136))
+    names = np.array([f"b{i}" for i in range(n)], dtype=object)
+    data = Data(names, abd, tnf, device=device)
+    np.random.seed(2021); torch.manual_seed(2021)
+    train = weighted_batches(data, 64)
+    test = weighted_batches(data, 64, num_samples=int(n * 0.7), replacement=False)
+    original = shuffled_batches(data, 64)
+    assert len(train) == 5 and len(test) == 4 and len(original) == 5
+    idx = np.concatenate([b["bc"] for b in original])
+    assert sorted(idx) == sorted(names)                              # a permutation
+    vae = VAENET(400, 136, 32, 5, 3, device != "cpu", 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+    model = tmp_path / "2.vae"
+    with pytest.raises(Exception, match="model path not exist"):
+        vae.train(train, test, original, str(model), 20)
+    model.mkdir()
+    vae.train(train, test, original, str(model), 20)
+    for f in ("train_model.pk", "latent.npz", "barcodes.npz", "model_finished"):
+        assert (model / f).is_file(), f
+    latent = np.load(model / "latent.npz")["arr_0"]; bcs = np.load(model / "barcodes.npz")["arr_0"]
+    assert latent.shape == (n, 32) and latent.dtype == np.float32 and list(bcs) == list(names)
+    state = {k: v.cpu().numpy() for k, v in torch.load(model / "train_model.pk", map_location="cpu").items()}
+    want = oracle.vae_embedding(state, data.abd, data.tnf)
+    assert np.abs(latent - want).max() <= 1e-5 * np.abs(want).max()
+    # resume: existing checkpoint and latents are kept
+    before = (model / "latent.npz").stat().st_mtime_ns
+    VAENET(400, 136, 32, 5, 3, device != "cpu", 1, 0.005, 0.2, 0.1, 0.015, 0.0001).train(train, test, original, str(model), 20)
+    assert (model / "latent.npz").stat().st_mtime_ns == before
+
+
+def test_sampler_draws_are_the_reference_draws():
+    """CustomWeightedRandomSampler semantics (utils.py:13-21): np.random.choice over p = w / sum(w) from numpy's global
+    generator, with and without replacement"""
+    w = np.array([0.1, 0.4, 0.2, 0.05, 0.25])
+
+    class D:
+        weights, abd_dev, tnf_dev, bc = w, torch.zeros(5, 2), torch.zeros(5, 2), np.arange(5)
+        def __len__(self): return 5
+    np.random.seed(7)
+    got = np.concatenate([b["bc"] for b in weighted_batches(D(), 2)])
+    np.random.seed(7)
+    assert list(got) == list(np.random.choice(range(5), size=5, p=w / w.sum(), replace=True))
+    np.random.seed(8)
+    got = np.concatenate([b["bc"] for b in weighted_batches(D(), 2, num_samples=3, replacement=False)])
+    np.random.seed(8)
+    assert list(got) == list(np.random.choice(range(5), size=3, p=w / w.sum(), replace=False))
