@@ -116,12 +116,17 @@ int pg_tnf_colmap(int k, uint16_t *colmap /* [4^k] host */, uint32_t *col_code /
  *                   is split into buckets of 2^b consecutive slots and probing wraps inside the
  *                   bucket (b = 0: one bucket = the whole table); pg_kmer_count_bucketed needs
  *                   b <= PG_BUCKET_MAX_LOG2_SLOTS so that one bucket fits in LDS.
+ *   PG_TABLE_WIDE   k <= 31 (the reference's whole range, count_kmer.cpp:11-21): uint64_t keys[2^log2_slots]
+ *                   holding code + 1 (0 = empty), immediately followed by uint32_t counts[2^log2_slots]
+ *                   (12 bytes per slot); same placement and probing, unbucketed, built and read by the direct
+ *                   kernels (pg_kmer_count / pg_features) only; counts are plain uint32 (no saturation).
  * Tables must be zero-filled by the caller before the first count; counting accumulates, so a stream
  * may be counted in pieces (and tables of several GPUs can be summed).
  * ---------------------------------------------------------------------------------------------- */
-enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2 };
+enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3 };
 #define PG_DENSE_MAX_K 16
 #define PG_HASH_MAX_K 21
+#define PG_WIDE_MAX_K 31
 #define PG_HASH_COUNT_BITS 22
 #define PG_HASH_COUNT_SAT (1u << 21)
 #define PG_BUCKET_MAX_LOG2_SLOTS 14   /* 2^14 slots x 8 B = 128 KiB of the CU's 160 KiB LDS */
@@ -132,7 +137,7 @@ typedef struct {
     int32_t k;
     int32_t log2_slots;        /* hash only */
     int32_t log2_bucket_slots; /* hash only; 0 = unbucketed */
-    void *data;         /* device: uint32_t[4^k] or uint64_t[2^log2_slots] */
+    void *data;         /* device: uint32_t[4^k], uint64_t[2^log2_slots], or the wide form's keys followed by counts */
 } pg_table;
 
 /* Count the k-mers ending in words [word_begin, word_end) of the stream into `t`.
@@ -166,6 +171,9 @@ int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t
 /* Add n (code,count) pairs -- `pairs[i] = (code << 22) | count`, the slot format -- into a hash table:
  * the merge step after tables of other GPUs have been gathered. */
 int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t, uint32_t *status, void *stream);
+
+/* (code, count) pairs into a wide table (separate arrays). */
+int pg_kmer_merge_wide(const uint64_t *codes, const uint32_t *counts, int64_t n, const pg_table *t, uint32_t *status, void *stream);
 
 /* The same merge for a bucketed table whose foreign entries arrive in bucket order (a table's slots are laid out
  * bucket by bucket, so the occupied slots of another rank's table, in slot order, already are): one workgroup per

@@ -42,7 +42,7 @@ constexpr uint64_t HASH_CMASK = (1ull << HASH_CBITS) - 1;
 constexpr uint32_t HASH_SAT = PG_HASH_COUNT_SAT;
 constexpr uint32_t MAX_PROBE = 1u << 14;
 
-enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2 };
+enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2, TK_WIDE = 3 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -160,6 +160,48 @@ __device__ __forceinline__ uint32_t hash_probe(const HashView &t, uint64_t s, ui
     return 0;
 }
 
+// Wide form (k <= 31): keys[2^s] hold code + 1 (0 = empty), counts[2^s] (uint32) follow the key array.  Same placement
+// and probing as the packed form; counts wrap modulo 2^32 like any uint32 counter.
+__device__ __forceinline__ uint32_t *wide_counts(const HashView &t) { return reinterpret_cast<uint32_t *>(t.slots + (1ull << t.log2_slots)); }
+
+__device__ __forceinline__ void wide_add(const HashView &t, uint64_t code, uint32_t add, uint32_t *status)
+{
+    const uint32_t limit = t.limit();
+    const uint64_t key1 = code + 1;
+    uint64_t s = t.home(code);
+    for (uint32_t i = 0; i < limit; ++i) {
+        uint64_t cur = t.slots[s];
+        if (cur == 0) {
+            cur = atomicCAS((unsigned long long *)&t.slots[s], 0ull, (unsigned long long)key1);
+            if (cur == 0) cur = key1;
+        }
+        if (cur == key1) { atomicAdd(&wide_counts(t)[s], add); return; }
+        s = t.next(s);
+    }
+    atomicOr(status, 1u);
+}
+
+__device__ __forceinline__ uint32_t wide_probe(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, bool *found)
+{
+    const uint32_t limit = t.limit();
+    const uint64_t key1 = code + 1;
+    for (uint32_t i = 0; i < limit; ++i) {
+        if (cur == 0) break;
+        if (cur == key1) { *found = true; return wide_counts(t)[s]; }
+        s = t.next(s);
+        cur = t.slots[s];
+    }
+    *found = false;
+    return 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void wide_merge_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ counts, int64_t n,
+                                                           HashView t, uint32_t *status)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        if (counts[i]) wide_add(t, codes[i], counts[i], status);
+}
+
 // -------------------------------------------------------------------------------- K2 direct: global counts
 
 template <typename KT, int TK>
@@ -186,6 +228,8 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
                 if ((x.ok >> j) & 1) {
                     if (TK == TK_DENSE) {
                         dense_add(dense, (uint32_t)canon[u]);
+                    } else if (TK == TK_WIDE) {
+                        wide_add(t, (uint64_t)canon[u], 1u, status);
                     } else {                       // issue the first probe of the whole batch before resolving any
                         hh[u] = t.home((uint64_t)canon[u]);
                         cur[u] = t.slots[hh[u]];
@@ -895,6 +939,8 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                         if (TK == TK_DENSE) {
                             cnt = (uint32_t)cur[u];
                             found = cnt != 0;       // absent from the table <=> never counted
+                        } else if (TK == TK_WIDE) {
+                            cnt = wide_probe(t, hh[u], cur[u], (uint64_t)canon[u], &found);
                         } else {
                             cnt = hash_probe(t, hh[u], cur[u], (uint64_t)canon[u], &found);
                         }
@@ -954,6 +1000,10 @@ int check_table(const pg_table *t)
         if (t->log2_slots < 10 || t->log2_slots > 40) return pg_fail(PG_EINVAL, "log2_slots %d out of range [10,40]", t->log2_slots);
         if (t->log2_bucket_slots != 0 && (t->log2_bucket_slots < 4 || t->log2_bucket_slots > t->log2_slots))
             return pg_fail(PG_EINVAL, "log2_bucket_slots %d out of range [4,%d]", t->log2_bucket_slots, t->log2_slots);
+    } else if (t->kind == PG_TABLE_WIDE) {
+        if (t->k < 1 || t->k > PG_WIDE_MAX_K) return pg_fail(PG_EINVAL, "wide table needs 1 <= k <= %d (got %d)", PG_WIDE_MAX_K, t->k);
+        if (t->log2_slots < 10 || t->log2_slots > 40) return pg_fail(PG_EINVAL, "log2_slots %d out of range [10,40]", t->log2_slots);
+        if (t->log2_bucket_slots != 0) return pg_fail(PG_EINVAL, "wide tables are not bucketed");
     } else {
         return pg_fail(PG_EINVAL, "unknown table kind %d", t->kind);
     }
@@ -1078,7 +1128,7 @@ extern "C" int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_count: bad word range [%lld,%lld)", (long long)word_begin, (long long)word_end);
     int rc = check_table(t);
     if (rc) return rc;
-    if (t->kind == PG_TABLE_HASH && !status) return pg_fail(PG_EINVAL, "pg_kmer_count: hash tables need a status word");
+    if (t->kind != PG_TABLE_DENSE && !status) return pg_fail(PG_EINVAL, "pg_kmer_count: hash tables need a status word");
     if (word_end == word_begin) return PG_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = grid_for(word_end - word_begin);
@@ -1086,6 +1136,9 @@ extern "C" int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64
         HashView none{nullptr, 0, 0};
         hipLaunchKernelGGL((kmer_count_kernel<uint32_t, TK_DENSE>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end,
                            t->k, (uint32_t *)t->data, none, status);
+    } else if (t->kind == PG_TABLE_WIDE) {
+        hipLaunchKernelGGL((kmer_count_kernel<uint64_t, TK_WIDE>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end,
+                           t->k, (uint32_t *)nullptr, view_of(t), status);
     } else {
         hipLaunchKernelGGL((kmer_count_kernel<uint64_t, TK_HASH>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end,
                            t->k, (uint32_t *)nullptr, view_of(t), status);
@@ -1187,6 +1240,17 @@ extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t
     if (n == 0) return PG_OK;
     hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, view_of(t), status);
     return check_launch("pg_kmer_merge");
+}
+
+extern "C" int pg_kmer_merge_wide(const uint64_t *codes, const uint32_t *counts, int64_t n, const pg_table *t, uint32_t *status, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_WIDE) return pg_fail(PG_EINVAL, "pg_kmer_merge_wide: wide tables only");
+    if (n < 0 || (n > 0 && (!codes || !counts)) || !status) return pg_fail(PG_EINVAL, "pg_kmer_merge_wide: bad arguments");
+    if (n == 0) return PG_OK;
+    hipLaunchKernelGGL(wide_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, codes, counts, n, view_of(t), status);
+    return check_launch("pg_kmer_merge_wide");
 }
 
 extern "C" int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t, uint32_t *status, void *stream)
@@ -1320,7 +1384,7 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
         if (t->kind == PG_TABLE_HASH && (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
             return pg_fail(PG_EINVAL, "pg_features: window*vector_size %lld exceeds the exact range of the hash table (%u)",
                            (long long)window * vsize, PG_HASH_COUNT_SAT);
-        kind = t->kind == PG_TABLE_DENSE ? TK_DENSE : TK_HASH;
+        kind = t->kind == PG_TABLE_DENSE ? TK_DENSE : t->kind == PG_TABLE_WIDE ? TK_WIDE : TK_HASH;
         k = t->k;
         if (kind == TK_DENSE) dense = (const uint32_t *)t->data;
         else view = view_of(t);
@@ -1335,6 +1399,7 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
                        k_tnf, colmap, tnf_cols, tnf_copies, abd_copies, tnf_out, k, dense, view, (uint32_t)window, vsize, abd_out)
     if (kind == TK_NONE) PG_LAUNCH(uint32_t, TK_NONE);
     else if (kind == TK_DENSE) PG_LAUNCH(uint32_t, TK_DENSE);
+    else if (kind == TK_WIDE) PG_LAUNCH(uint64_t, TK_WIDE);
     else PG_LAUNCH(uint64_t, TK_HASH);
 #undef PG_LAUNCH
     return check_launch("pg_features");

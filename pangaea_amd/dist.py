@@ -100,6 +100,24 @@ def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTabl
         return table
     me = dist.get_rank(group)
     world = dist.get_world_size(group)
+    if table.kind == "wide":
+        # wide tables (k > 21): gather occupied keys and their counts, add the other ranks' entries with global atomics
+        import ctypes as C
+        from . import _lib
+        from .kmer import _stream_ptr
+        keys, cnts = table._wide_parts()
+        occ = keys != 0
+        all_codes = gather_pairs((keys[occ] - 1).contiguous(), group)
+        all_counts = gather_pairs(cnts[occ].to(torch.int64).contiguous(), group)
+        for r in range(world):
+            if r != me and all_codes[r].numel():
+                c, n = all_codes[r].contiguous(), all_counts[r].to(torch.int32).contiguous()
+                with torch.cuda.device(table.device):
+                    _lib.check(_lib.load().pg_kmer_merge_wide(c.data_ptr(), n.data_ptr(), c.numel(), table.desc(),
+                                                              table.status.data_ptr(), _stream_ptr(table.device)))
+        if check:
+            table.check_status()
+        return table
     parts = gather_pairs(table.compact(), group)
     if table.log2_bucket:
         # every rank built its table with the same geometry, so compacted tables are bucket-ordered: exchange the

@@ -35,6 +35,8 @@ class KmerTable:
     slot = (code << 22) | count, 0 = empty (k <= 21), optionally split into buckets of 2^log2_bucket slots
     (probing wraps inside a bucket); bucketed tables are built by the partition + LDS-count pipeline
     (``pg_kmer_count_bucketed``), unbucketed ones by one global atomic per occurrence (``pg_kmer_count``).
+    ``wide`` (22 <= k <= 31, the rest of the reference's range): 2^log2_slots int64 keys (code + 1) followed by as
+    many int32 counts in the same tensor; direct kernels only.
     """
 
     WORKSPACE_BUDGET = 96 << 30          # bytes of scratch one bucketed launch may use; longer streams go in pieces
@@ -42,8 +44,8 @@ class KmerTable:
     def __init__(self, k: int, kind: str, data: torch.Tensor, log2_slots: int = 0, log2_bucket: int = 0):
         self.k, self.kind, self.data, self.log2_slots, self.log2_bucket = int(k), kind, data, int(log2_slots), int(log2_bucket)
         self.status = torch.zeros(2, dtype=torch.int32, device=data.device)
-        self._desc = _lib.pg_table(_lib.TABLE_DENSE if kind == "dense" else _lib.TABLE_HASH, self.k, self.log2_slots,
-                                   self.log2_bucket, data.data_ptr())
+        code = {"dense": _lib.TABLE_DENSE, "hash": _lib.TABLE_HASH, "wide": _lib.TABLE_WIDE}[kind]
+        self._desc = _lib.pg_table(code, self.k, self.log2_slots, self.log2_bucket, data.data_ptr())
         self._empty = True               # nothing counted since allocation / reset()
         self._workspace = None
         self._shuffle_ws = None
@@ -53,8 +55,10 @@ class KmerTable:
 
     @staticmethod
     def default_kind(k: int) -> str:
-        if k < 1 or k > _lib.HASH_MAX_K:
-            raise ValueError(f"k-mer size {k} unsupported on the GPU path (1..{_lib.HASH_MAX_K})")
+        if k < 1 or k > _lib.WIDE_MAX_K:
+            raise ValueError(f"k-mer size {k} unsupported (1..{_lib.WIDE_MAX_K}, as the reference)")
+        if k > _lib.HASH_MAX_K:
+            return "wide"
         # measured at 10 M pairs: k=15 dense 191 ms vs hash (partition + LDS) 70 ms; k=11 135 vs 69 ms.  Dense tables only
         # where 4^k counters stay cache resident.
         return "dense" if k <= 8 else "hash"
@@ -77,13 +81,24 @@ class KmerTable:
             if k > _lib.DENSE_MAX_K:
                 raise ValueError(f"dense tables need k <= {_lib.DENSE_MAX_K}")
             return cls(k, "dense", torch.zeros(4 ** k, dtype=torch.int32, device=device))
-        if kind != "hash":
+        if kind not in ("hash", "wide"):
             raise ValueError(f"unknown table kind {kind!r}")
-        if k > _lib.HASH_MAX_K:
+        if kind == "hash" and k > _lib.HASH_MAX_K:
             raise ValueError(f"hash tables need k <= {_lib.HASH_MAX_K}")
         want = max(1024, int((distinct_hint or 1 << 20) / load))
         log2 = max(10, math.ceil(math.log2(want)))
+        if kind == "wide":
+            return cls.wide_with_slots(k, device, log2)
         return cls.with_slots(k, device, log2, log2_bucket)
+
+    @classmethod
+    def wide_with_slots(cls, k: int, device, log2_slots: int) -> "KmerTable":
+        n = 1 << log2_slots
+        return cls(k, "wide", torch.zeros(n + n // 2, dtype=torch.int64, device=device), log2_slots, 0)
+
+    def _wide_parts(self):
+        n = 1 << self.log2_slots
+        return self.data[:n], self.data[n:].view(torch.int32)
 
     @classmethod
     def with_slots(cls, k: int, device, log2_slots: int, log2_bucket: int | None = None) -> "KmerTable":
@@ -97,7 +112,15 @@ class KmerTable:
         codes = torch.as_tensor(np.asarray(codes).astype(np.int64))
         counts = torch.as_tensor(np.asarray(counts).astype(np.int64))
         table = cls.alloc(k, device, kind, distinct_hint=max(1024, codes.numel()))
-        if table.kind == "dense":
+        if table.kind == "wide":
+            c = codes.to(table.device).contiguous()
+            n = counts.to(table.device, torch.int32).contiguous()
+            table._empty = False
+            with torch.cuda.device(table.device):
+                _lib.check(_lib.load().pg_kmer_merge_wide(c.data_ptr(), n.data_ptr(), c.numel(), table.desc(), table.status.data_ptr(),
+                                                          _stream_ptr(table.device)))
+            table.check_status()
+        elif table.kind == "dense":
             table.data[codes.to(table.device)] = counts.to(table.device, torch.int32)
         else:
             sat = torch.clamp(counts, max=_lib.HASH_COUNT_SAT)
@@ -188,7 +211,7 @@ class KmerTable:
         return out
 
     def check_status(self) -> None:
-        if self.kind == "hash" and int(self.status[0].item()) != 0:
+        if self.kind != "dense" and int(self.status[0].item()) != 0:
             raise _lib.PangaeaError(_lib.PG_ETABLEFULL, f"hash table with 2^{self.log2_slots} slots is full")
 
     def merge(self, pairs: torch.Tensor, check: bool = True) -> "KmerTable":
@@ -251,6 +274,8 @@ class KmerTable:
         return self.data[self.data != 0]
 
     def occupancy(self) -> float:
+        if self.kind == "wide":
+            return float(torch.count_nonzero(self._wide_parts()[0]).item()) / (1 << self.log2_slots)
         if self.kind != "hash":
             return float("nan")
         return float(torch.count_nonzero(self.data).item()) / self.data.numel()
@@ -261,6 +286,13 @@ class KmerTable:
             t = self.data.cpu().numpy().view(np.uint32)
             codes = np.nonzero(t)[0].astype(np.uint64)
             return codes, t[codes.astype(np.int64)].astype(np.uint64)
+        if self.kind == "wide":
+            keys, cnts = self._wide_parts()
+            occ = keys != 0
+            codes = (keys[occ] - 1).cpu().numpy().view(np.uint64)
+            counts = cnts[occ].cpu().numpy().view(np.uint32).astype(np.uint64)
+            order = np.argsort(codes)
+            return codes[order], counts[order]
         s = self.compact().cpu().numpy().view(np.uint64)
         codes, counts = s >> np.uint64(_lib.HASH_COUNT_BITS), s & np.uint64((1 << _lib.HASH_COUNT_BITS) - 1)
         order = np.argsort(codes)
@@ -279,6 +311,10 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
             if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
                 raise
             log2 = min(max_log2_slots, table.log2_slots + 2)
+            if table.kind == "wide":
+                del table
+                table = KmerTable.wide_with_slots(k, stream.device, log2)
+                continue
             lb = None if log2_bucket is None else min(log2_bucket + 2, _lib.BUCKET_MAX_LOG2_SLOTS)
             if lb is not None and log2 - lb > _lib.BUCKET_MAX_LOG2_BUCKETS:
                 lb = 0

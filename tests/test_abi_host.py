@@ -154,8 +154,9 @@ def test_kernels_refuse_cpu_tensors():
     s = ReadStream.from_runs([("x", b"ACGTACGTACGTN")])
     with pytest.raises(RuntimeError, match="no CPU path"):
         kmer.features(s, s.rows(0), k_tnf=4)
+    assert [kmer.KmerTable.default_kind(k) for k in (4, 8, 9, 15, 21, 22, 31)] == ["dense", "dense", "hash", "hash", "hash", "wide", "wide"]
     with pytest.raises(ValueError):
-        kmer.KmerTable.default_kind(22)
+        kmer.KmerTable.default_kind(32)
 
 
 def test_parallel_ingest_equals_serial(tmp_path):

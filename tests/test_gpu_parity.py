@@ -64,9 +64,11 @@ def test_tnf_golden(case, tmp_path):
 def test_abundance_golden(case, kind, tmp_path):
     k = case["k"]
     if k > _lib.HASH_MAX_K:
-        with pytest.raises(ValueError):
-            kmer.KmerTable.default_kind(k)
-        return
+        if kind == "hash":
+            with pytest.raises(ValueError):
+                kmer.KmerTable.alloc(k, DEV, "hash")
+            return
+        assert kmer.KmerTable.default_kind(k) == "wide"
     s, _ = _stream(case["input"])
     rows = s.rows(case["min_len"])
     # the table the reference was given: the (possibly holed) dump, loaded with its own loader semantics
@@ -84,6 +86,7 @@ def test_abundance_golden(case, kind, tmp_path):
         mine = kmer.count_kmers(s, k, kind=None if kind == "default" else "hash")
         c2, n2 = mine.items()
         assert np.array_equal(c2, codes) and np.array_equal(n2, np.minimum(counts, _lib.HASH_COUNT_SAT) if mine.kind == "hash" else counts)
+        assert mine.kind == ("wide" if k > 21 else "dense" if (kind == "default" and k <= 8) else "hash")
 
 
 # ------------------------------------------------------------------ seeded synthetic reads vs the oracle
@@ -99,6 +102,7 @@ def _oracle_rows(s: ReadStream, rows: Rows, k_tnf, k, window, vsize):
 
 @pytest.mark.parametrize("k,kind,k_tnf,window,vsize,seg", [
     (15, "dense", 4, 10, 400, 16384), (21, "hash", 4, 10, 400, 16384), (21, "hash", 3, 1, 6, 64),
+    (22, "wide", 4, 10, 400, 16384), (27, "wide", 2, 1, 6, 96), (31, "wide", 4, 3, 700, 4096), (13, "wide", 4, 2, 50, 512),
     (11, "dense", 5, 2, 50, 32), (11, "hash", 6, 3, 1500, 4096), (17, "hash", 1, 7, 33, 1024), (4, "dense", 2, 100, 400, 512),
 ])
 def test_synthetic_against_oracle(k, kind, k_tnf, window, vsize, seg):
