@@ -688,31 +688,84 @@ extern "C" int pg_tnf_colmap(int k, uint16_t *colmap, uint32_t *col_code)
 
 // ------------------------------------------------------------------------------------ CSV cache
 
+namespace {
+
+// ",<value>" as `ostream << double` prints it: %g with 6 significant digits.  Non-negative integers below 10^6 print as
+// plain decimals under %g, which is the whole matrix in practice -- only larger counts take the snprintf path.
+inline void append_number(std::string &out, int32_t v)
+{
+    out.push_back(',');
+    if (v >= 0 && v < 1000000) {
+        char tmp[8];
+        int n = 0;
+        do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) out.push_back(tmp[--n]);
+    } else {
+        char num[48];
+        const int m = snprintf(num, sizeof num, "%g", (double)v);
+        out.append(num, (size_t)m);
+    }
+}
+
+// one complete gzip member holding `text`
+bool gzip_member(const std::string &text, std::string &out)
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&z, (uLong)text.size()) + 64);
+    z.next_in = (Bytef *)text.data();
+    z.avail_in = (uInt)text.size();
+    z.next_out = (Bytef *)&out[0];
+    z.avail_out = (uInt)out.size();
+    const int rc = deflate(&z, Z_FINISH);
+    const size_t produced = out.size() - z.avail_out;
+    deflateEnd(&z);
+    if (rc != Z_STREAM_END) return false;
+    out.resize(produced);
+    return true;
+}
+
+}  // namespace
+
 extern "C" int pg_write_csv_gz(const char *path, const char *names, const int32_t *mat, int64_t n_rows, int64_t n_cols)
 {
     if (!path || n_rows < 0 || n_cols < 0 || (n_rows > 0 && (!names || (n_cols > 0 && !mat))))
         return pg_fail(PG_EINVAL, "pg_write_csv_gz: bad arguments");
-    gzFile f = gzopen(path, "wb1");
-    if (!f) return pg_fail(PG_EIO, "cannot create %s", path);
-    gzbuffer(f, 1 << 20);
-    std::string line;
-    char num[48];
-    const char *nm = names;
-    for (int64_t i = 0; i < n_rows; ++i) {
-        line.assign(nm);
-        nm += line.size() + 1;
-        for (int64_t j = 0; j < n_cols; ++j) {
-            // the reference streams each count through ostream<<double: %g with 6 significant digits
-            int m = snprintf(num, sizeof num, ",%g", (double)mat[i * n_cols + j]);
-            line.append(num, (size_t)m);
-        }
-        line.push_back('\n');
-        if (gzwrite(f, line.data(), (unsigned)line.size()) != (int)line.size()) {
-            gzclose(f);
-            return pg_fail(PG_EIO, "write error on %s", path);
-        }
+    // row chunks are formatted and compressed independently (each becomes one gzip member; a gzip file may hold any
+    // number of members and reads back as their concatenation), then written in order
+    std::vector<const char *> name_at((size_t)n_rows);
+    {
+        const char *nm = names;
+        for (int64_t i = 0; i < n_rows; ++i) { name_at[(size_t)i] = nm; nm += strlen(nm) + 1; }
     }
-    if (gzclose(f) != Z_OK) return pg_fail(PG_EIO, "close error on %s", path);
+    const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(((size_t)1 << 22) / (size_t)(8 * (n_cols + 4))));   // ~4 MB of text
+    const int64_t n_chunks = n_rows ? (n_rows + rows_per_chunk - 1) / rows_per_chunk : 1;
+    std::vector<std::string> packed((size_t)n_chunks);
+    std::vector<char> bad((size_t)n_chunks, 0);
+    const int T = (int)std::min<int64_t>(ingest_threads(), n_chunks);
+    std::atomic<int64_t> next{0};
+    run_threads(T, [&](int) {
+        std::string text;
+        for (;;) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= n_chunks) break;
+            text.clear();
+            const int64_t r0 = c * rows_per_chunk, r1 = std::min(n_rows, r0 + rows_per_chunk);
+            for (int64_t i = r0; i < r1; ++i) {
+                text.append(name_at[(size_t)i]);
+                for (int64_t j = 0; j < n_cols; ++j) append_number(text, mat[i * n_cols + j]);
+                text.push_back('\n');
+            }
+            if (!gzip_member(text, packed[(size_t)c])) bad[(size_t)c] = 1;
+        }
+    });
+    for (char x : bad) if (x) return pg_fail(PG_ENOMEM, "pg_write_csv_gz: compression failed");
+    FILE *f = fopen(path, "wb");
+    if (!f) return pg_fail(PG_EIO, "cannot create %s", path);
+    for (const std::string &m : packed)
+        if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); return pg_fail(PG_EIO, "write error on %s", path); }
+    if (fclose(f) != 0) return pg_fail(PG_EIO, "close error on %s", path);
     return PG_OK;
 }
 

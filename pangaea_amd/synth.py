@@ -176,8 +176,11 @@ def generate(cfg: SynthConfig, device="cpu", chunk_pairs: int = 1 << 16, with_na
     return ReadStream(codes, valid, n_chars, run_off.astype(np.int64), names, n_pairs=cfg.n_pairs)
 
 
-def write_fastq(stream: ReadStream, cfg: SynthConfig, path: str, n_pairs: int | None = None) -> int:
-    """interleaved FASTQ of the first ``n_pairs`` pairs (headers ``@r<i> BX:Z:<barcode>-1``); returns pairs written"""
+def write_fastq(stream: ReadStream, cfg: SynthConfig, path: str, n_pairs: int | None = None, style: str = "10x") -> int:
+    """interleaved FASTQ of the first ``n_pairs`` pairs; returns pairs written.  Header styles:
+    ``10x``    ``@r<i> BX:Z:<barcode>-1``                         (run_pangaea -s 10x / tellseq)
+    ``stlfr``  ``@r<i>#<b1>_<b2>_<b3>/<mate>``, unbarcoded ``#0_0_0``   (raw stLFR, count_tnf.cpp:35-42)
+    ``hybrid`` ``@r<i> BX:Z:lr_<0000000>-1``                      (long-read names as barcodes, assign_barcodes.cpp:156)"""
     n = cfg.n_pairs if n_pairs is None else min(n_pairs, cfg.n_pairs)
     cpp, L, P = cfg.chars_per_pair, cfg.read_len, cfg.pairs_per_barcode
     qual = "I" * L
@@ -189,8 +192,14 @@ def write_fastq(stream: ReadStream, cfg: SynthConfig, path: str, n_pairs: int | 
             out = []
             for p in range(p0, p1):
                 o = (p - p0) * cpp
-                b = p // P
-                tag = f" BX:Z:{barcode_name(cfg, cfg.first_pair // P + b)}-1" if p < P * cfg.n_barcodes else ""
-                out.append(f"@r{p}{tag}\n{txt[o:o + L]}\n+\n{qual}\n@r{p}{tag}\n{txt[o + L + 1:o + 2 * L + 1]}\n+\n{qual}\n")
+                b = cfg.first_pair // P + p // P
+                has_bc = p < P * cfg.n_barcodes
+                if style == "stlfr":
+                    tag = f"#{b % 1536 + 1}_{(b // 1536) % 1536 + 1}_{b // (1536 * 1536) + 1}" if has_bc else "#0_0_0"
+                    h1, h2 = f"@r{p}{tag}/1", f"@r{p}{tag}/2"
+                else:
+                    name = barcode_name(cfg, b) if style == "10x" else f"lr_{b:07d}"
+                    h1 = h2 = f"@r{p} BX:Z:{name}-1" if has_bc else f"@r{p}"
+                out.append(f"{h1}\n{txt[o:o + L]}\n+\n{qual}\n{h2}\n{txt[o + L + 1:o + 2 * L + 1]}\n+\n{qual}\n")
             f.write("".join(out))
     return n

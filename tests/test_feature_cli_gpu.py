@@ -92,3 +92,27 @@ def test_cli_tools_write_the_reference_files(tmp_path):
     assert _run("count_tnf", "-i", "x.fq").returncode == 1
     assert _run("count_kmer", "-i", "x.fq", "-o", out).returncode == 1
     assert _run("count_tnf", "-1", "only_one.fq", "-o", out).returncode == 1
+
+
+@pytest.mark.parametrize("style,k,clusters", [("stlfr", 21, 30), ("hybrid", 15, 40)])
+def test_stlfr_and_hybrid_style_inputs(style, k, clusters, tmp_path):
+    """BASELINE configs 4 and 5 in miniature: raw stLFR headers (barcode in the read name, 0_0_0 = none) and hybrid mode
+    (long-read names as barcodes) through Feature on the GPU, against the oracle's reading of the same file"""
+    from oracle import oracle
+    from pangaea_amd import synth
+    from pangaea_amd.feature import Feature
+    cfg = synth.SynthConfig(n_pairs=5000, n_barcodes=60, n_genomes=3, genome_len=60_000, fragment=15_000, seed=11)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, fq, style=style)
+    args = _args(tmp_path, interleaved_reads=fq, kmer=k, min_length=2000)
+    names, abd, tnf = Feature(args, ROOT).extract_features()
+    rd = oracle.Reads(fq)
+    assert rd.mode == ("stLFR" if style == "stlfr" else "10x")
+    table = oracle.Table(k, threads=4).count(rd.all_seq())
+    onames, otnf, oabd = rd.features(2000, k_tnf=4, k_abd=k, table=table, window=10, vsize=400, threads=4)
+    assert list(names) == onames and len(onames) == 60
+    assert np.array_equal(tnf, otnf) and np.array_equal(abd, oabd)
+    if style == "stlfr":
+        assert names[0] == "1_1_1"
+    else:
+        assert names[0] == "lr_0000000"
