@@ -146,6 +146,13 @@ typedef struct {
 int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
                   const pg_table *t, uint32_t *status, void *stream);
 
+/* HyperLogLog sketch of the distinct canonical k-mers of a word range, for sizing a table before counting:
+ * registers = device uint32_t[PG_HLL_REGISTERS], zeroed by the caller (several ranges / GPUs combine by element-wise
+ * max).  Estimate = alpha * m^2 / sum_j 2^-registers[j] with the usual small-range correction (pangaea_amd/kmer.py). */
+#define PG_HLL_REGISTERS 4096
+int pg_kmer_distinct_sketch(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, int k,
+                            uint32_t *registers, void *stream);
+
 /* Rows = barcode runs that yield an output row: sorted, disjoint character ranges of the stream (device arrays). */
 typedef struct {
     const int64_t *row_start; /* device [n_rows] */

@@ -23,6 +23,7 @@ TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
 SHUFFLE_MAX_VSIZE = 512
+HLL_REGISTERS = 4096
 MAX_ROWS = (1 << 22) - 2
 
 
@@ -82,6 +83,7 @@ def load() -> C.CDLL:
         "pg_tnf_ncols": (i32, [i32]),
         "pg_tnf_colmap": (i32, [i32, vp, vp]),
         "pg_kmer_count": (i32, [vp, vp, i64, i64, tp, vp, vp]),
+        "pg_kmer_distinct_sketch": (i32, [vp, vp, i64, i64, i32, vp, vp]),
         "pg_kmer_count_workspace_bytes": (i64, [i64, tp]),
         "pg_kmer_count_bucketed": (i32, [vp, vp, i64, i64, tp, i32, rp, vp, i64, vp, vp]),
         "pg_abundance_workspace_bytes": (i64, [i64, i64, i32, tp]),
@@ -105,7 +107,7 @@ def load() -> C.CDLL:
 EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_set_ingest_threads", "pg_reads_free", "pg_reads_n_chars",
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
            "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
-           "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_count_workspace_bytes",
+           "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_distinct_sketch", "pg_kmer_count_workspace_bytes",
            "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed", "pg_kmer_merge_wide", "pg_abundance_workspace_bytes",
            "pg_abundance_from_records",
            "pg_features", "pg_write_csv_gz", "pg_extract_reads"]

@@ -274,6 +274,39 @@ __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__res
     }
 }
 
+// HyperLogLog sketch of the canonical k-mers of a word range: registers[j] = max over k-mers with hash prefix j of
+// (1 + leading zeros of the remaining hash bits).  4096 registers: ~1.6 % standard error -- enough to size a table.
+constexpr int HLL_BITS = 12;
+__global__ __launch_bounds__(BIG_BLOCK) void distinct_sketch_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                                    int64_t word_begin, int64_t word_end, int k, uint32_t *__restrict__ registers)
+{
+    __shared__ uint32_t reg[1 << HLL_BITS];
+    for (int i = threadIdx.x; i < (1 << HLL_BITS); i += BIG_BLOCK) reg[i] = 0;
+    __syncthreads();
+    for (int64_t w = word_begin + (int64_t)blockIdx.x * BIG_BLOCK + threadIdx.x; w < word_end; w += (int64_t)gridDim.x * BIG_BLOCK) {
+        const Word x = load_word(codes, valid, w, k);
+        if (x.ok == 0) continue;
+        Roller<uint64_t> r;
+        r.init(k);
+        for (int i = 33 - k; i < 32; ++i) r.push((uint32_t)(x.pw >> (2 * i)) & 3u);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            r.push((uint32_t)(x.cw >> (2 * j)) & 3u);
+            if ((x.ok >> j) & 1) {
+                // an independent hash (the table's own hash decides bucket membership; reusing it would not bias the
+                // sketch, but keeping them apart costs nothing)
+                const uint64_t h = mix64(r.canon() ^ 0x9E3779B97F4A7C15ull);
+                const uint32_t idx = (uint32_t)(h >> (64 - HLL_BITS));
+                const uint64_t rest = (h << HLL_BITS) | (1ull << (HLL_BITS - 1));      // sentinel bit bounds the rank
+                atomicMax(&reg[idx], (uint32_t)__clzll((long long)rest) + 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 << HLL_BITS); i += BIG_BLOCK)
+        if (reg[i]) atomicMax(&registers[i], reg[i]);
+}
+
 // -------------------------------------------------------------------------------- partition machinery
 //
 // occurrence record = canonical code (low 42 bits) | row id << 42 (22 bits, ROW_NONE = not inside any row)
@@ -1144,6 +1177,19 @@ extern "C" int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64
                            t->k, (uint32_t *)nullptr, view_of(t), status);
     }
     return check_launch("pg_kmer_count");
+}
+
+extern "C" int pg_kmer_distinct_sketch(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, int k,
+                                       uint32_t *registers, void *stream)
+{
+    if (!codes || !valid || !registers) return pg_fail(PG_EINVAL, "pg_kmer_distinct_sketch: null argument");
+    if (k < 1 || k > PG_WIDE_MAX_K) return pg_fail(PG_EINVAL, "pg_kmer_distinct_sketch: k %d out of range", k);
+    if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_distinct_sketch: bad word range");
+    if (word_end == word_begin) return PG_OK;
+    int grid = (int)((word_end - word_begin + BIG_BLOCK - 1) / BIG_BLOCK);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(distinct_sketch_kernel, dim3(grid), dim3(BIG_BLOCK), 0, (hipStream_t)stream, codes, valid, word_begin, word_end, k, registers);
+    return check_launch("pg_kmer_distinct_sketch");
 }
 
 extern "C" int64_t pg_kmer_count_workspace_bytes(int64_t n_words, const pg_table *t)

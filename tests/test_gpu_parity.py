@@ -362,3 +362,19 @@ def test_full_size_invariants():
     for r in text_rows:
         txt = s.decode(int(rows.start[r]), int(rows.end[r]))
         assert np.array_equal(tnf[r].cpu().numpy(), oracle.tnf_row(txt, 4))
+
+
+def test_distinct_estimate_sizes_tables():
+    """the HyperLogLog pass lands within a few percent of the true number of distinct canonical k-mers, at both ends of
+    its range, and count_kmers sizes its table from it (no overflow-and-redo on low-coverage input)"""
+    for n_pairs, genome_len in ((300, 1000), (20_000, 400_000)):
+        cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=max(2, n_pairs // 150), n_genomes=3, genome_len=genome_len,
+                                fragment=min(10_000, genome_len // 2), seed=13)
+        s = synth.generate(cfg, device=DEV)
+        for k in (11, 21, 31):
+            true = len(oracle.Table(k, threads=4).count(s.decode()))
+            est = kmer.estimate_distinct(s, k)
+            assert abs(est - true) <= 0.06 * true + 20, (n_pairs, k, est, true)
+            t = kmer.count_kmers(s, k)
+            assert len(t.items()[0]) == true
+            assert (1 << t.log2_slots) >= 2 * true and (1 << t.log2_slots) <= max(1 << 16, 12 * true)
