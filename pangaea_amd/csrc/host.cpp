@@ -429,28 +429,47 @@ int ingest_interleaved_parallel(const FileBuf &f, const char *path, pg_reads *R,
         P.finish();
     });
     tm.lap("pack");
-    // ---- 6. runs (sequential over units, but only string compares)
+    // ---- 6. runs: every thread finds the barcode changes inside its units (the pair that differs from its predecessor
+    // closes the predecessor's run); the first complete pair of a thread is compared with the last one of the threads
+    // before it while stitching, in order
     R->mode = L.mode;
-    R->run_off.push_back(0);
-    const char *last = ""; uint32_t last_n = 0;
-    int64_t pos = 0;
-    for (int t = 0; t < T; ++t) {
-        R->n_pairs += pairs[t];
+    struct Change { int64_t end_pos; const char *prev; uint32_t prev_n; };
+    std::vector<std::vector<Change>> changes(T);
+    struct Edge { const char *first = nullptr; uint32_t first_n = 0; int64_t first_end = 0; const char *last = nullptr; uint32_t last_n = 0; bool any = false; };
+    std::vector<Edge> edge(T);
+    run_threads(T, [&](int t) {
+        int64_t pos = cstart[t];
+        const char *last = nullptr; uint32_t last_n = 0;
+        Edge e;
         for (const Unit &x : units[t]) {
             if (x.have & 1) pos += (int64_t)x.s1_n + 1;
             if (x.have & 2) {
                 pos += (int64_t)x.s2_n + 1;
-                if (x.bc_n != last_n || (last_n && memcmp(x.bc, last, last_n) != 0)) {
-                    R->run_off.push_back(pos);
-                    R->run_name.emplace_back(last, last_n);
-                    last = x.bc; last_n = x.bc_n;
-                }
+                if (!e.any) { e.any = true; e.first = x.bc; e.first_n = x.bc_n; e.first_end = pos; }
+                else if (x.bc_n != last_n || (last_n && memcmp(x.bc, last, last_n) != 0)) changes[t].push_back(Change{pos, last, last_n});
+                last = x.bc; last_n = x.bc_n;
             }
         }
+        e.last = last; e.last_n = last_n;
+        edge[t] = e;
+    });
+    R->run_off.push_back(0);
+    const char *last = ""; uint32_t last_n = 0;
+    for (int t = 0; t < T; ++t) {
+        R->n_pairs += pairs[t];
+        if (!edge[t].any) continue;
+        if (edge[t].first_n != last_n || (last_n && memcmp(edge[t].first, last, last_n) != 0)) {
+            R->run_off.push_back(edge[t].first_end);
+            R->run_name.emplace_back(last, last_n);
+        }
+        for (const Change &c : changes[t]) { R->run_off.push_back(c.end_pos); R->run_name.emplace_back(c.prev, c.prev_n); }
+        last = edge[t].last; last_n = edge[t].last_n;
     }
-    R->run_off.push_back(pos);
+    R->run_off.push_back(total);
     R->run_name.emplace_back(last, last_n);
     tm.lap("runs");
+    { std::vector<std::vector<Unit>>().swap(units); }
+    tm.lap("free units");
     return PG_OK;
 }
 
@@ -484,6 +503,8 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
             R->run_off.clear();
             rc = ingest_interleaved_parallel(f1, r1, R, T);
             if (rc) { delete R; return rc; }
+            // unmapping hundreds of MB costs ~0.1 s of page-table teardown: let a detached thread do it
+            { char *gone = f1.p; f1.p = nullptr; f1.n = 0; std::thread([gone] { free(gone); }).detach(); }
             *out = R;
             return PG_OK;
         }
