@@ -31,6 +31,18 @@ class Rows:
         return len(self.names)
 
 
+class _IngestHandle:
+    """owns a pg_reads handle: the stream arrays of a host ReadStream are views of the library's memory"""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.pg_reads_free(self._h)
+            self._h = None
+
+
 @dataclass
 class ReadStream:
     codes: torch.Tensor            # int64 [n_words]: 32 characters per word, 2 bits each (A0 C1 T2 G3)
@@ -41,7 +53,7 @@ class ReadStream:
     n_pairs: int = 0
     n_unpaired: int = 0
     mode: str = ""
-    _dev: dict = field(default_factory=dict, repr=False)
+    _owner: object = field(default=None, repr=False)     # keeps library-owned host memory alive
 
     @property
     def n_words(self) -> int:
@@ -59,16 +71,15 @@ class ReadStream:
         L = _lib.load()
         h = C.c_void_p()
         _lib.check(L.pg_ingest_fastq(str(reads1).encode(), str(reads2).encode() if reads2 else None, C.byref(h)))
-        try:
-            nw, nr = L.pg_reads_n_words(h), L.pg_reads_n_runs(h)
-            codes = np.ctypeslib.as_array(C.cast(L.pg_reads_codes(h), C.POINTER(C.c_int64)), shape=(nw,)).copy()
-            valid = np.ctypeslib.as_array(C.cast(L.pg_reads_valid(h), C.POINTER(C.c_int32)), shape=(nw,)).copy()
-            run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
-            names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
-            out = cls(torch.from_numpy(codes), torch.from_numpy(valid), int(L.pg_reads_n_chars(h)), run_off, names,
-                      int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode())
-        finally:
-            L.pg_reads_free(h)
+        owner = _IngestHandle(L, h)
+        nw, nr = L.pg_reads_n_words(h), L.pg_reads_n_runs(h)
+        # zero-copy views of the library's arrays (the handle is freed with the last reference to this stream)
+        codes = np.ctypeslib.as_array(C.cast(L.pg_reads_codes(h), C.POINTER(C.c_int64)), shape=(nw,))
+        valid = np.ctypeslib.as_array(C.cast(L.pg_reads_valid(h), C.POINTER(C.c_int32)), shape=(nw,))
+        run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
+        names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
+        out = cls(torch.from_numpy(codes), torch.from_numpy(valid), int(L.pg_reads_n_chars(h)), run_off, names,
+                  int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode(), _owner=owner)
         return out.to(device)
 
     @classmethod
