@@ -378,3 +378,34 @@ def test_distinct_estimate_sizes_tables():
             t = kmer.count_kmers(s, k)
             assert len(t.items()[0]) == true
             assert (1 << t.log2_slots) >= 2 * true and (1 << t.log2_slots) <= max(1 << 16, 12 * true)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_configurations(seed):
+    """random k / bucket geometry / window / vector size / row filter / error rates: partition + shuffle path == lookup path
+    == oracle, bit for bit"""
+    rng = np.random.RandomState(1000 + seed)
+    k = int(rng.choice([5, 9, 12, 15, 16, 19, 21]))
+    k_tnf = int(rng.choice([1, 2, 3, 4, 5, 6]))
+    window = int(rng.choice([1, 2, 7, 10, 25]))
+    vsize = int(rng.choice([3, 17, 64, 400, 512]))
+    n_pairs = int(rng.choice([64, 700, 2500]))
+    n_bc = int(rng.choice([1, 7, 40]))
+    cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=min(n_bc, n_pairs // 2), n_genomes=int(rng.randint(1, 4)),
+                            genome_len=int(rng.choice([3_000, 50_000])), fragment=2_000, sub_rate=float(rng.choice([0.0, 0.02])),
+                            n_rate=float(rng.choice([0.0, 0.3, 1.0])), unbarcoded=float(rng.choice([0.0, 0.1])), seed=seed)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(int(rng.choice([0, 302, 2000])))
+    plan = kmer.Plan(rows, DEV, seg_chars=int(rng.choice([32, 256, 16384])))
+    log2_slots = int(rng.choice([17, 18, 20]))
+    log2_bucket = int(rng.choice([5, 8, 11, 14]))
+    table = kmer.KmerTable.with_slots(k, DEV, log2_slots, log2_bucket).count(s, rows=plan)
+    tnf, abd = kmer.features(s, plan, k_tnf=k_tnf, table=table, window=window, vsize=vsize)
+    tnf_l, abd_l = kmer.features(s, rows, k_tnf=k_tnf, table=table, window=window, vsize=vsize, seg_chars=64)
+    assert torch.equal(tnf, tnf_l) and torch.equal(abd, abd_l)
+    if len(rows):
+        otab, otnf, oabd = _oracle_rows(s, rows, k_tnf, k, window, vsize)
+        assert all(np.array_equal(x, y) for x, y in zip(table.items(), otab.items()))
+        assert np.array_equal(tnf.cpu().numpy(), otnf) and np.array_equal(abd.cpu().numpy(), oabd)
+    else:
+        assert tuple(abd.shape) == (0, vsize)
