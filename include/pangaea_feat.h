@@ -68,6 +68,16 @@ int pg_ingest_fastq(const char *r1_or_interleaved, const char *r2_or_null, pg_re
 /* Threads the interleaved parser may use (0 = all hardware threads, at most 32; PG_INGEST_THREADS overrides the
  * default).  The result does not depend on it. */
 void pg_set_ingest_threads(int n);
+/* Sharded ingest, one shard per rank/GPU (contiguous ranges of barcode runs): shard `part` of `n_parts`
+ * parses only its byte range [size*part/n_parts, size*(part+1)/n_parts) of an UNCOMPRESSED interleaved file, moved
+ * forward at both ends to the end of the barcode run in progress there, so that the shards' runs concatenated in
+ * rank order are exactly the runs pg_ingest_fastq gives for the whole file (the producer loop of
+ * count_tnf.cpp:238-289 is inherently serial; this is its data-parallel form).  Record alignment comes from line
+ * numbers, not from guessing at '@': first every rank calls pg_fastq_count_newlines for its own range, the counts
+ * are exchanged, and newlines_before[i] (i = 0..n_parts) = number of '\n' in bytes [0, size*i/n_parts).  gzip input
+ * fails with PG_EFORMAT (callers fall back to pg_ingest_fastq on every rank). */
+int pg_fastq_count_newlines(const char *path, int part, int n_parts, int64_t *n_newlines);
+int pg_ingest_fastq_shard(const char *path, int part, int n_parts, const int64_t *newlines_before, pg_reads **out);
 void pg_reads_free(pg_reads *r);
 int64_t pg_reads_n_chars(const pg_reads *r);
 int64_t pg_reads_n_words(const pg_reads *r); /* padded word count of codes[] and valid[] */

@@ -64,6 +64,8 @@ def load() -> C.CDLL:
         "pg_last_error": (cp, []),
         "pg_device_count": (i32, []),
         "pg_ingest_fastq": (i32, [cp, cp, C.POINTER(vp)]),
+        "pg_fastq_count_newlines": (i32, [cp, i32, i32, C.POINTER(i64)]),
+        "pg_ingest_fastq_shard": (i32, [cp, i32, i32, C.POINTER(i64), C.POINTER(vp)]),
         "pg_set_ingest_threads": (None, [i32]),
         "pg_reads_free": (None, [vp]),
         "pg_reads_n_chars": (i64, [vp]),
@@ -104,7 +106,8 @@ def load() -> C.CDLL:
     return L
 
 
-EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_set_ingest_threads", "pg_reads_free", "pg_reads_n_chars",
+EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_fastq_count_newlines", "pg_ingest_fastq_shard",
+           "pg_set_ingest_threads", "pg_reads_free", "pg_reads_n_chars",
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
            "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
            "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_distinct_sketch", "pg_kmer_count_workspace_bytes",

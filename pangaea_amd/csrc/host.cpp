@@ -248,24 +248,61 @@ bool header_fields(const char *s, size_t n, int &mode, Span &name, Span &bc)
 }  // namespace
 
 struct pg_reads {
-    StreamWriter st;
+    StreamWriter st;                   // the serial loops build the stream here ...
+    void *huge_c = nullptr, *huge_v = nullptr;   // ... the threaded one in uninitialised huge-page arrays
+    uint64_t *codes_w = nullptr;
+    uint32_t *valid_w = nullptr;
+    int64_t n_words = 0, n_chars = 0;
     std::vector<int64_t> run_off;      // [n_runs + 1]
     std::vector<std::string> run_name;
     int64_t n_pairs = 0, n_unpaired = 0;
     int mode = MODE_UNSET;
+
+    pg_reads() = default;
+    pg_reads(const pg_reads &) = delete;
+    pg_reads &operator=(const pg_reads &) = delete;
+    ~pg_reads() { free(huge_c); free(huge_v); }
+    void seal_serial()
+    {
+        st.finish();
+        codes_w = st.codes.data(); valid_w = st.valid.data();
+        n_words = (int64_t)st.codes.size(); n_chars = st.n;
+    }
+    bool alloc_stream(int64_t total_chars)
+    {
+        size_t words = (size_t)((total_chars + 31) / 32);
+        size_t padded = (words + PG_WORD_ALIGN - 1) / PG_WORD_ALIGN * PG_WORD_ALIGN;
+        if (padded == 0) padded = PG_WORD_ALIGN;
+        auto grab = [](size_t bytes) -> void * {
+            const size_t align = bytes >= ((size_t)4 << 20) ? (size_t)2 << 20 : 64;
+            void *q = nullptr;
+            if (posix_memalign(&q, align, (bytes + align - 1) / align * align) != 0) return nullptr;
+#ifdef MADV_HUGEPAGE
+            if (align > 64) madvise(q, (bytes + align - 1) / align * align, MADV_HUGEPAGE);
+#endif
+            return q;
+        };
+        huge_c = grab(padded * sizeof(uint64_t));
+        huge_v = grab(padded * sizeof(uint32_t));
+        if (!huge_c || !huge_v) return false;
+        codes_w = (uint64_t *)huge_c; valid_w = (uint32_t *)huge_v;
+        n_words = (int64_t)padded; n_chars = total_chars;
+        return true;
+    }
 };
 
 // ------------------------------------------------------------------------------------ parallel interleaved ingest
 //
-// Same result as the serial loop below, in phases that each split the in-memory file over T threads:
-//   1. line index   : newline counts per byte chunk -> byte offset of any line number
-//   2. latch scan   : first header that fixes the grammar ("BX:Z" -> 10x, else '#' -> stLFR); headers before it are
-//                     parsed with the grammar still undecided, exactly as the sequential latch would
-//   3. parse        : per 8-line unit: barcode span, sequence spans, character count
-//   4. prefix       : character offset of every thread's first unit
-//   5. pack         : 2-bit codes + validity written at their exact bit offsets (atomic OR only on the words two
-//                     threads share)
-//   6. runs         : barcode change points stitched across threads, in order (the append-then-compare rule)
+// Same result as the serial loop below.  The file is never held in memory: T threads stream their byte ranges through
+// small block buffers (which stay in cache), twice:
+//   A. newline counts per range -> the line number at every range start, hence each thread's first 8-line unit
+//   B. per unit: header -> barcode, both sequences packed (2-bit codes + validity) into a thread-local stream, barcode
+//      change points noted
+// then   C. the local streams are shifted into place in the (uninitialised, huge-page) output arrays -- atomic OR only
+//           on the words two threads share --
+//        D. and the change points are stitched in thread order (the append-then-compare rule).
+// The grammar latch (first header with "BX:Z", else '#') is found first, from the start of the file, so that every
+// header is parsed exactly as the sequential latch would.
 namespace {
 
 int g_ingest_threads = 0;      // 0 = hardware concurrency (capped)
@@ -287,39 +324,6 @@ template <typename F> void run_threads(int T, F &&f)
     for (auto &x : th) x.join();
 }
 
-struct Unit {                 // one 8-line record group of the interleaved file
-    const char *bc; uint32_t bc_n;
-    const char *s1; uint32_t s1_n;
-    const char *s2; uint32_t s2_n;
-    uint8_t have;             // bit0: line 2 present, bit1: line 6 present (pair complete), bit2: bad header
-};
-
-struct Packer {               // writes characters at absolute positions into shared word arrays
-    uint64_t *codes; uint32_t *valid;
-    int64_t pos, first_word, last_word;
-    uint64_t cw = 0; uint32_t vw = 0;
-    void flush()
-    {
-        const int64_t w = (pos - 1) >> 5;
-        if (w == first_word || w == last_word) {
-            __atomic_fetch_or(&codes[w], cw, __ATOMIC_RELAXED);
-            __atomic_fetch_or(&valid[w], vw, __ATOMIC_RELAXED);
-        } else {
-            codes[w] = cw; valid[w] = vw;
-        }
-        cw = 0; vw = 0;
-    }
-    inline void put(unsigned char c)
-    {
-        const bool ok = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
-        const int sh = (int)(pos & 31);
-        if (ok) { cw |= (uint64_t)((c >> 1) & 3) << (2 * sh); vw |= 1u << sh; }
-        ++pos;
-        if (sh == 31) flush();
-    }
-    void finish() { if (pos & 31) flush(); }
-};
-
 struct PhaseTimer {
     bool on = getenv("PG_INGEST_TIMING") != nullptr;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -332,164 +336,258 @@ struct PhaseTimer {
     }
 };
 
-int ingest_interleaved_parallel(const FileBuf &f, const char *path, pg_reads *R, int T)
+struct Latch { uint64_t unit; int mode; };     // first unit whose header fixes the grammar (UINT64_MAX: none)
+
+// what a byte range of a file inherits from the bytes before it (pg_ingest_fastq_shard); a whole file uses the defaults
+struct ShardCtx {
+    uint64_t unit_base = 0;       // index in the file of the range's first unit
+    std::string last;             // barcode of the pair before the range (the comparison state at entry)
+    bool trailing = true;         // the range ends at the end of the file: enqueue the trailing accumulator
+};
+
+struct UnitLines { const char *p[8]; size_t n[8]; int count; size_t off; };   // up to 8 lines; off = file offset of the unit
+
+// sequential reader of file bytes [begin, end) through one block buffer; hands out lines and 8-line units
+class UnitReader {
+public:
+    UnitReader(int fd, size_t begin, size_t end, size_t block) : fd_(fd), base_(begin), end_(end), buf_(block) {}
+    bool io_error() const { return io_error_; }
+    size_t offset() const { return base_ + cur_; }
+    // the rest of the current line (up to and including its '\n'); false if the range ends first
+    bool skip_line()
+    {
+        for (;;) {
+            if (cur_ < have_) {
+                const char *q = (const char *)memchr(buf_.data() + cur_, '\n', have_ - cur_);
+                if (q) { cur_ = (size_t)(q - buf_.data()) + 1; return true; }
+                cur_ = have_;
+            }
+            if (eof_ || !more()) return false;
+        }
+    }
+    uint64_t count_newlines()
+    {
+        uint64_t c = 0;
+        for (;;) {
+            const char *p = buf_.data() + cur_, *e = buf_.data() + have_;
+            while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = q + 1; }
+            cur_ = have_;
+            if (eof_ || !more()) return c;
+        }
+    }
+    bool next(UnitLines &u)
+    {
+        for (;;) {
+            size_t q = cur_;
+            int k = 0;
+            while (k < 8 && q < have_) {
+                const char *b = buf_.data() + q;
+                const char *nl = (const char *)memchr(b, '\n', have_ - q);
+                if (!nl) break;
+                u.p[k] = b; u.n[k] = (size_t)(nl - b); ++k;
+                q = (size_t)(nl - buf_.data()) + 1;
+            }
+            if (k < 8) {
+                if (!eof_) { if (more()) continue; if (io_error_) return false; }
+                if (q < have_) { u.p[k] = buf_.data() + q; u.n[k] = have_ - q; ++k; q = have_; }   // unterminated last line
+                if (k == 0) return false;
+            }
+            u.count = k; u.off = base_ + cur_;
+            cur_ = q;
+            return true;
+        }
+    }
+private:
+    // keep the unread tail, read on; false at the end of the range (or on error)
+    bool more()
+    {
+        if (cur_ > 0) { memmove(buf_.data(), buf_.data() + cur_, have_ - cur_); base_ += cur_; have_ -= cur_; cur_ = 0; }
+        if (have_ == buf_.size()) buf_.resize(buf_.size() * 2);
+        const size_t at = base_ + have_;
+        const size_t want = std::min(buf_.size() - have_, end_ > at ? end_ - at : 0);
+        if (want == 0) { eof_ = true; return false; }
+        const ssize_t got = pread(fd_, buf_.data() + have_, want, (off_t)at);
+        if (got <= 0) { eof_ = true; io_error_ = got < 0 || at < end_; return false; }
+        have_ += (size_t)got;
+        return true;
+    }
+    int fd_;
+    size_t base_, end_;                 // file offset of buf_[0]; end of the range
+    std::vector<char> buf_;
+    size_t have_ = 0, cur_ = 0;
+    bool eof_ = false, io_error_ = false;
+};
+
+// block size of the readers (PG_INGEST_BLOCK overrides: tests use tiny blocks to exercise refills and growth)
+size_t reader_block(size_t dflt)
+{
+    if (const char *e = getenv("PG_INGEST_BLOCK")) { long v = atol(e); if (v >= 16) return (size_t)v; }
+    return dflt;
+}
+
+inline int mode_of(const Latch &L, uint64_t unit) { return unit < L.unit ? (int)MODE_UNSET : L.mode; }
+
+// first R1 header from the start of the file that fixes the grammar
+Latch find_latch(int fd, size_t size)
+{
+    UnitReader rd(fd, 0, size, reader_block((size_t)1 << 16));
+    UnitLines u;
+    for (uint64_t i = 0; rd.next(u); ++i) {
+        if (find_bxz(u.p[0], u.n[0]) != NPOS) return Latch{i, MODE_10X};
+        if (find_chr(u.p[0], u.n[0], '#', 0) != NPOS) return Latch{i, MODE_STLFR};
+    }
+    return Latch{UINT64_MAX, MODE_UNSET};
+}
+
+struct LocalStream {          // one thread's characters, packed from bit 0
+    std::vector<uint64_t> codes;
+    std::vector<uint32_t> valid;
+    int64_t n = 0;
+    uint64_t cw = 0; uint32_t vw = 0;
+    inline void put(unsigned char c)
+    {
+        const bool ok = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+        const int sh = (int)(n & 31);
+        if (ok) { cw |= (uint64_t)((c >> 1) & 3) << (2 * sh); vw |= 1u << sh; }
+        ++n;
+        if (sh == 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; }
+    }
+    void put_line(const char *s, size_t len) { for (size_t i = 0; i < len; ++i) put((unsigned char)s[i]); put('N'); }
+    void finish() { if (n & 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; } }
+};
+
+struct Change { int64_t end_pos; std::string prev; };       // a run ends at end_pos (thread-local); it carries `prev`
+
+struct ThreadOut {
+    LocalStream st;
+    std::vector<Change> changes;
+    bool any = false;             // saw a complete pair
+    std::string first, last;      // barcodes of the first and the last complete pair
+    int64_t first_end = 0;        // local position after the first complete pair
+    int64_t pairs = 0;
+    uint64_t bad_unit = UINT64_MAX;
+    bool io_error = false;
+};
+
+// bytes [A, B) of the open file: A is the start of a unit, B the start of a unit or the end of the file
+int ingest_interleaved_range(int fd, size_t A, size_t B, const char *path, pg_reads *R, int T, const Latch &L, const ShardCtx &ctx)
 {
     PhaseTimer tm;
-    const char *base = f.data();
-    const size_t n = f.size();
-    // ---- 1. line index
-    std::vector<size_t> cb(T + 1);
-    for (int t = 0; t <= T; ++t) cb[t] = n * (size_t)t / T;
+    const size_t n = B - A;
+    const size_t block = reader_block((size_t)1 << 20);
+    std::vector<size_t> rb(T + 1);
+    for (int t = 0; t <= T; ++t) rb[t] = A + (size_t)((unsigned __int128)n * (unsigned)t / (unsigned)T);
+    // ---- A. newlines per range; does the range start at the start of a line?
     std::vector<uint64_t> nl(T, 0);
+    std::vector<char> at_line_start(T, 1), io_bad(T, 0);
     run_threads(T, [&](int t) {
-        uint64_t c = 0;
-        const char *p = base + cb[t], *e = base + cb[t + 1];
-        while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = q + 1; }
-        nl[t] = c;
+        if (t > 0 && rb[t] > A) { char c = 0; if (pread(fd, &c, 1, (off_t)(rb[t] - 1)) != 1) io_bad[t] = 1; at_line_start[t] = c == '\n'; }
+        UnitReader rd(fd, rb[t], rb[t + 1], block);
+        nl[t] = rd.count_newlines();
+        if (rd.io_error()) io_bad[t] = 1;
     });
+    for (char x : io_bad) if (x) return pg_fail(PG_EIO, "read error in %s", path);
     std::vector<uint64_t> nl_before(T + 1, 0);
     for (int t = 0; t < T; ++t) nl_before[t + 1] = nl_before[t] + nl[t];
-    const uint64_t n_lines = nl_before[T] + ((n && base[n - 1] != '\n') ? 1 : 0);
-    const uint64_t n_units = (n_lines + 7) / 8;
-    if (n_units == 0) { R->run_off.push_back(0); R->run_name.emplace_back(); R->st.finish(); return PG_OK; }
-    // byte offset of the first character of line `ln` (0-based)
-    auto line_start = [&](uint64_t ln) -> size_t {
-        if (ln == 0) return 0;
-        // the ln-th newline (1-based) ends line ln-1; find the chunk holding it
-        int t = (int)(std::upper_bound(nl_before.begin(), nl_before.end(), ln - 1) - nl_before.begin()) - 1;
-        uint64_t need = ln - nl_before[t];
-        const char *p = base + cb[t], *e = base + cb[t + 1];
-        while (need) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); p = q + 1; --need; }
-        return (size_t)(p - base);
-    };
-    // units per thread
-    std::vector<uint64_t> ub(T + 1);
-    for (int t = 0; t <= T; ++t) ub[t] = n_units * (uint64_t)t / T;
-    std::vector<size_t> ustart(T + 1);
-    run_threads(T, [&](int t) { ustart[t] = ub[t] < n_units ? line_start(ub[t] * 8) : n; });
-    ustart[T] = n;
     tm.lap("lines");
-    // ---- 2. latch scan
-    struct Latch { uint64_t unit; int mode; };
-    std::vector<Latch> latch(T, Latch{UINT64_MAX, MODE_UNSET});
+    // ---- B. parse + pack into thread-local streams
+    std::vector<ThreadOut> out(T);
     run_threads(T, [&](int t) {
-        const char *p = base + ustart[t], *e = base + n;
-        for (uint64_t u = ub[t]; u < ub[t + 1] && p < e; ++u) {
-            const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
-            const size_t len = q ? (size_t)(q - p) : (size_t)(e - p);
-            int m = MODE_UNSET;
-            if (find_bxz(p, len) != NPOS) m = MODE_10X;
-            else if (find_chr(p, len, '#', 0) != NPOS) m = MODE_STLFR;
-            if (m != MODE_UNSET) { latch[t] = Latch{u, m}; return; }
-            // skip the other 7 lines of the unit
-            const char *r = q ? q + 1 : e;
-            for (int k = 0; k < 7 && r < e; ++k) { const char *z = (const char *)memchr(r, '\n', (size_t)(e - r)); r = z ? z + 1 : e; }
-            p = r;
-        }
-    });
-    Latch L{UINT64_MAX, MODE_UNSET};
-    for (int t = 0; t < T; ++t) if (latch[t].unit < L.unit) L = latch[t];
-    tm.lap("latch");
-    // ---- 3. parse
-    std::vector<std::vector<Unit>> units(T);
-    std::vector<int64_t> chars(T, 0), pairs(T, 0);
-    std::vector<uint64_t> bad(T, UINT64_MAX);
-    run_threads(T, [&](int t) {
-        auto &U = units[t];
-        U.reserve((size_t)(ub[t + 1] - ub[t]));
-        const char *p = base + ustart[t], *e = base + n;
-        int64_t c = 0, np = 0;
-        for (uint64_t u = ub[t]; u < ub[t + 1]; ++u) {
-            Unit x{nullptr, 0, nullptr, 0, nullptr, 0, 0};
-            for (int k = 1; k <= 8 && p < e; ++k) {
-                const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
-                const size_t len = q ? (size_t)(q - p) : (size_t)(e - p);
-                if (k == 1) {
-                    int mode = u < L.unit ? MODE_UNSET : L.mode;      // the latching header decides for itself
-                    Span nm, bc;
-                    if (!header_fields(p, len, mode, nm, bc)) { x.have |= 4; if (bad[t] == UINT64_MAX) bad[t] = u; }
-                    x.bc = p + bc.b; x.bc_n = (uint32_t)bc.n;
-                } else if (k == 2) {
-                    x.s1 = p; x.s1_n = (uint32_t)len; x.have |= 1; c += (int64_t)len + 1;
-                } else if (k == 6) {
-                    x.s2 = p; x.s2_n = (uint32_t)len; x.have |= 2; c += (int64_t)len + 1; ++np;
+        ThreadOut &o = out[t];
+        if (rb[t] >= rb[t + 1]) return;
+        UnitReader rd(fd, rb[t], B, block);
+        uint64_t line = nl_before[t];                      // index (from A) of the first line that starts in this range
+        if (!at_line_start[t]) { if (!rd.skip_line()) { o.io_error = rd.io_error(); return; } ++line; }
+        for (uint64_t skip = (8 - line % 8) % 8; skip; --skip, ++line)
+            if (!rd.skip_line()) { o.io_error = rd.io_error(); return; }
+        uint64_t unit = ctx.unit_base + line / 8;
+        o.st.codes.reserve((rb[t + 1] - rb[t]) / 64 + 64);
+        o.st.valid.reserve((rb[t + 1] - rb[t]) / 64 + 64);
+        UnitLines u;
+        while (rd.offset() < rb[t + 1] && rd.next(u)) {
+            int mode = mode_of(L, unit);
+            Span nm, bc;
+            if (!header_fields(u.p[0], u.n[0], mode, nm, bc)) { o.bad_unit = unit; return; }
+            if (u.count >= 2) o.st.put_line(u.p[1], u.n[1]);
+            if (u.count >= 6) {
+                o.st.put_line(u.p[5], u.n[5]);
+                ++o.pairs;
+                const char *b = u.p[0] + bc.b;
+                if (!o.any) { o.any = true; o.first.assign(b, bc.n); o.first_end = o.st.n; o.last = o.first; }
+                else if (bc.n != o.last.size() || (bc.n && memcmp(b, o.last.data(), bc.n) != 0)) {
+                    o.changes.push_back(Change{o.st.n, o.last});
+                    o.last.assign(b, bc.n);
                 }
-                p = q ? q + 1 : e;
             }
-            U.push_back(x);
+            ++unit;
         }
-        chars[t] = c; pairs[t] = np;
+        o.io_error = rd.io_error();
+        o.st.finish();
     });
     uint64_t first_bad = UINT64_MAX;
-    for (int t = 0; t < T; ++t) first_bad = std::min(first_bad, bad[t]);
+    for (int t = 0; t < T; ++t) {
+        if (out[t].io_error) return pg_fail(PG_EIO, "read error in %s", path);
+        first_bad = std::min(first_bad, out[t].bad_unit);
+    }
     if (first_bad != UINT64_MAX)
         return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag (the reference aborts here)", path, (unsigned long long)(first_bad * 8 + 1));
-    tm.lap("parse");
-    // ---- 4. prefix
+    tm.lap("parse+pack");
+    // ---- C. place the local streams
     std::vector<int64_t> cstart(T + 1, 0);
-    for (int t = 0; t < T; ++t) cstart[t + 1] = cstart[t] + chars[t];
+    for (int t = 0; t < T; ++t) cstart[t + 1] = cstart[t] + out[t].st.n;
     const int64_t total = cstart[T];
-    {
-        size_t words = (size_t)((total + 31) / 32);
-        size_t padded = (words + PG_WORD_ALIGN - 1) / PG_WORD_ALIGN * PG_WORD_ALIGN;
-        if (padded == 0) padded = PG_WORD_ALIGN;
-        R->st.codes.assign(padded, 0);
-        R->st.valid.assign(padded, 0);
-        R->st.n = total;
-    }
-    tm.lap("alloc");
-    // ---- 5. pack
-    run_threads(T, [&](int t) {
-        if (chars[t] == 0) return;
-        Packer P{R->st.codes.data(), R->st.valid.data(), cstart[t], cstart[t] >> 5, (cstart[t + 1] - 1) >> 5};
-        for (const Unit &x : units[t]) {
-            if (x.have & 1) { for (uint32_t i = 0; i < x.s1_n; ++i) P.put((unsigned char)x.s1[i]); P.put('N'); }
-            if (x.have & 2) { for (uint32_t i = 0; i < x.s2_n; ++i) P.put((unsigned char)x.s2[i]); P.put('N'); }
+    if (!R->alloc_stream(total)) return pg_fail(PG_ENOMEM, "out of memory while ingesting %s", path);
+    uint64_t *gc = R->codes_w; uint32_t *gv = R->valid_w;
+    for (int64_t w = (total + 31) >> 5; w < R->n_words; ++w) { gc[w] = 0; gv[w] = 0; }
+    for (int t = 0; t < T; ++t)
+        if (out[t].st.n) {
+            const int64_t a = cstart[t] >> 5, b = (cstart[t + 1] - 1) >> 5;
+            gc[a] = 0; gv[a] = 0; gc[b] = 0; gv[b] = 0;
         }
-        P.finish();
+    run_threads(T, [&](int t) {
+        const LocalStream &ls = out[t].st;
+        if (ls.n == 0) return;
+        const int64_t w0 = cstart[t] >> 5, w1 = (cstart[t + 1] - 1) >> 5;
+        const int sh = (int)(cstart[t] & 31);
+        const int64_t nw = (int64_t)ls.codes.size();
+        for (int64_t g = w0; g <= w1; ++g) {
+            const int64_t i = g - w0;
+            uint64_t c = i < nw ? ls.codes[i] << (2 * sh) : 0;
+            uint32_t v = i < nw ? ls.valid[i] << sh : 0;
+            if (sh && i > 0) { c |= ls.codes[i - 1] >> (64 - 2 * sh); v |= ls.valid[i - 1] >> (32 - sh); }
+            if (g == w0 || g == w1) { __atomic_fetch_or(&gc[g], c, __ATOMIC_RELAXED); __atomic_fetch_or(&gv[g], v, __ATOMIC_RELAXED); }
+            else { gc[g] = c; gv[g] = v; }
+        }
     });
-    tm.lap("pack");
-    // ---- 6. runs: every thread finds the barcode changes inside its units (the pair that differs from its predecessor
-    // closes the predecessor's run); the first complete pair of a thread is compared with the last one of the threads
-    // before it while stitching, in order
+    tm.lap("place");
+    // ---- D. runs: the first complete pair of a thread is compared with the last one of the threads before it
     R->mode = L.mode;
-    struct Change { int64_t end_pos; const char *prev; uint32_t prev_n; };
-    std::vector<std::vector<Change>> changes(T);
-    struct Edge { const char *first = nullptr; uint32_t first_n = 0; int64_t first_end = 0; const char *last = nullptr; uint32_t last_n = 0; bool any = false; };
-    std::vector<Edge> edge(T);
-    run_threads(T, [&](int t) {
-        int64_t pos = cstart[t];
-        const char *last = nullptr; uint32_t last_n = 0;
-        Edge e;
-        for (const Unit &x : units[t]) {
-            if (x.have & 1) pos += (int64_t)x.s1_n + 1;
-            if (x.have & 2) {
-                pos += (int64_t)x.s2_n + 1;
-                if (!e.any) { e.any = true; e.first = x.bc; e.first_n = x.bc_n; e.first_end = pos; }
-                else if (x.bc_n != last_n || (last_n && memcmp(x.bc, last, last_n) != 0)) changes[t].push_back(Change{pos, last, last_n});
-                last = x.bc; last_n = x.bc_n;
-            }
-        }
-        e.last = last; e.last_n = last_n;
-        edge[t] = e;
-    });
     R->run_off.push_back(0);
-    const char *last = ""; uint32_t last_n = 0;
+    const std::string *last = &ctx.last;
     for (int t = 0; t < T; ++t) {
-        R->n_pairs += pairs[t];
-        if (!edge[t].any) continue;
-        if (edge[t].first_n != last_n || (last_n && memcmp(edge[t].first, last, last_n) != 0)) {
-            R->run_off.push_back(edge[t].first_end);
-            R->run_name.emplace_back(last, last_n);
-        }
-        for (const Change &c : changes[t]) { R->run_off.push_back(c.end_pos); R->run_name.emplace_back(c.prev, c.prev_n); }
-        last = edge[t].last; last_n = edge[t].last_n;
+        R->n_pairs += out[t].pairs;
+        if (!out[t].any) continue;
+        if (out[t].first != *last) { R->run_off.push_back(cstart[t] + out[t].first_end); R->run_name.push_back(*last); }
+        for (const Change &c : out[t].changes) { R->run_off.push_back(cstart[t] + c.end_pos); R->run_name.push_back(c.prev); }
+        last = &out[t].last;
     }
-    R->run_off.push_back(total);
-    R->run_name.emplace_back(last, last_n);
+    if (ctx.trailing) { R->run_off.push_back(total); R->run_name.push_back(*last); }
     tm.lap("runs");
-    { std::vector<std::vector<Unit>>().swap(units); }
-    tm.lap("free units");
+    return PG_OK;
+}
+
+// a regular, uncompressed file?  (fd stays open on success)
+int open_plain(const char *path, int &fd, size_t &size, bool &plain)
+{
+    plain = false;
+    fd = open(path, O_RDONLY);
+    if (fd < 0) return pg_fail(PG_EIO, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+        size = (size_t)st.st_size;
+        unsigned char magic[2] = {0, 0};
+        plain = !(size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+    }
     return PG_OK;
 }
 
@@ -501,12 +599,33 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
 {
     if (!r1 || !out) return pg_fail(PG_EINVAL, "pg_ingest_fastq: null argument");
     *out = nullptr;
+    int rc;
+    const int T = ingest_threads();
+    if (!r2 && T > 1) {           // an uncompressed interleaved file of some size: threaded, streamed from the file
+        int fd; size_t size = 0; bool plain;
+        if ((rc = open_plain(r1, fd, size, plain))) return rc;
+        if (plain && size >= ((size_t)1 << 16) * (size_t)T) {
+            pg_reads *R = new (std::nothrow) pg_reads();
+            if (!R) { close(fd); return pg_fail(PG_ENOMEM, "out of memory"); }
+            try {
+                PhaseTimer tm;
+                const Latch L = find_latch(fd, size);
+                tm.lap("latch");
+                rc = ingest_interleaved_range(fd, 0, size, r1, R, T, L, ShardCtx());
+            } catch (const std::bad_alloc &) {
+                rc = pg_fail(PG_ENOMEM, "out of memory while ingesting %s", r1);
+            }
+            close(fd);
+            if (rc) { delete R; return rc; }
+            *out = R;
+            return PG_OK;
+        }
+        close(fd);
+    }
     FileBuf f1, f2;
-    PhaseTimer tm_read;
-    int rc = slurp(r1, f1);
+    rc = slurp(r1, f1);
     if (rc) return rc;
     if (r2 && (rc = slurp(r2, f2))) return rc;
-    tm_read.lap("read");
 
     pg_reads *R = new (std::nothrow) pg_reads();
     if (!R) return pg_fail(PG_ENOMEM, "out of memory");
@@ -518,17 +637,6 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
         const char *b; size_t len;
         Span nm, bc;
 
-        const int T = ingest_threads();
-        if (!r2 && T > 1 && f1.size() >= ((size_t)1 << 16) * (size_t)T) {
-            R->run_off.clear();
-            rc = ingest_interleaved_parallel(f1, r1, R, T);
-            if (rc) { delete R; return rc; }
-            PhaseTimer tm_free;
-            free(f1.p); f1.p = nullptr; f1.n = 0; f1.cap_ = 0;
-            tm_free.lap("free file");
-            *out = R;
-            return PG_OK;
-        }
         if (!r2) {
             Lines L(f1);
             uint64_t line_no = 0;
@@ -604,7 +712,7 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
             R->run_name.push_back(last);
             for (auto &o : orphans) { R->st.put_span(o.first, o.second); R->st.put('N'); }
         }
-        R->st.finish();
+        R->seal_serial();
     } catch (const std::bad_alloc &) {
         delete R;
         return pg_fail(PG_ENOMEM, "out of memory while ingesting %s", r1);
@@ -613,14 +721,139 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
     return PG_OK;
 }
 
+// ------------------------------------------------------------------------------------ sharded ingest (one rank per GPU)
+//
+// Rank `part` of `n_parts` parses only its own byte range of an uncompressed interleaved file.  Byte boundary i is
+// size * i / n_parts; the ranks count the newlines of their ranges (pg_fastq_count_newlines), exchange the counts, and
+// every rank then knows the line number at both of its boundaries -- so record alignment (line number mod 8) is exact,
+// not guessed from '@' characters.  A boundary is moved forward to the end of the run in progress: with c = the first
+// pair that begins at or after the boundary byte, the cut falls behind the first later pair whose barcode differs from
+// its predecessor's (that pair closes the predecessor's run, the append-then-compare rule), and the run that follows is
+// named after it.  Both neighbours derive the same cut from the same bytes, so every pair belongs to exactly one shard
+// and the shards' runs, concatenated in rank order, are the runs of the whole file.
+
+namespace {
+
+inline size_t shard_byte(size_t size, int i, int n_parts) { return (size_t)((unsigned __int128)size * (unsigned)i / (unsigned)n_parts); }
+
+struct Cut { size_t pos = 0; bool found = false; std::string last; uint64_t unit = 0; };
+
+// the cut that belongs to boundary byte b (0 < b < size); nl_before = newlines in [0, b)
+int find_cut(int fd, size_t size, size_t b, uint64_t nl_before, const Latch &L, const char *path, Cut &out)
+{
+    out = Cut(); out.pos = size;
+    UnitReader rd(fd, b, size, reader_block((size_t)1 << 16));
+    uint64_t line = nl_before;
+    char before = '\n';
+    if (b > 0 && pread(fd, &before, 1, (off_t)(b - 1)) != 1) return pg_fail(PG_EIO, "read error in %s", path);
+    if (before != '\n') { if (!rd.skip_line()) return rd.io_error() ? pg_fail(PG_EIO, "read error in %s", path) : (int)PG_OK; ++line; }
+    for (uint64_t skip = (8 - line % 8) % 8; skip; --skip, ++line)
+        if (!rd.skip_line()) return rd.io_error() ? pg_fail(PG_EIO, "read error in %s", path) : (int)PG_OK;
+    uint64_t u = line / 8;                            // the reader stands at the start of unit u: the context pair
+    UnitLines ul;
+    std::string prev;
+    bool have_prev = false;
+    for (; rd.next(ul); ++u) {
+        int mode = mode_of(L, u);
+        Span nm, bc;
+        if (!header_fields(ul.p[0], ul.n[0], mode, nm, bc))
+            return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag (the reference aborts here)", path, (unsigned long long)(u * 8 + 1));
+        if (ul.count < 6) break;                      // no further complete pair: the run lasts to the end of the file
+        const char *c = ul.p[0] + bc.b;
+        if (have_prev && (bc.n != prev.size() || (bc.n && memcmp(c, prev.data(), bc.n) != 0))) {
+            out.pos = rd.offset(); out.found = true; out.last.assign(c, bc.n); out.unit = u + 1;
+            return PG_OK;
+        }
+        if (!have_prev) { prev.assign(c, bc.n); have_prev = true; }
+    }
+    if (rd.io_error()) return pg_fail(PG_EIO, "read error in %s", path);
+    return PG_OK;
+}
+
+int open_for_shards(const char *path, int &fd, size_t &size)
+{
+    bool plain;
+    int rc = open_plain(path, fd, size, plain);
+    if (rc) return rc;
+    if (!plain) { close(fd); fd = -1; return pg_fail(PG_EFORMAT, "%s: sharded ingest needs an uncompressed regular file", path); }
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" int pg_fastq_count_newlines(const char *path, int part, int n_parts, int64_t *n_newlines)
+{
+    if (!path || !n_newlines || n_parts < 1 || part < 0 || part >= n_parts) return pg_fail(PG_EINVAL, "pg_fastq_count_newlines: bad argument");
+    int fd; size_t size = 0;
+    int rc = open_for_shards(path, fd, size);
+    if (rc) return rc;
+    PhaseTimer tm;
+    const size_t a = shard_byte(size, part, n_parts), b = shard_byte(size, part + 1, n_parts);
+    const int T = (b - a) >= ((size_t)8 << 20) ? ingest_threads() : 1;
+    std::vector<uint64_t> c(T, 0);
+    std::vector<char> bad(T, 0);
+    run_threads(T, [&](int t) {
+        UnitReader rd(fd, a + (b - a) * (size_t)t / T, a + (b - a) * (size_t)(t + 1) / T, reader_block((size_t)1 << 20));
+        c[t] = rd.count_newlines();
+        bad[t] = rd.io_error();
+    });
+    close(fd);
+    for (char x : bad) if (x) return pg_fail(PG_EIO, "read error in %s", path);
+    uint64_t total = 0;
+    for (uint64_t v : c) total += v;
+    *n_newlines = (int64_t)total;
+    tm.lap("newlines");
+    return PG_OK;
+}
+
+extern "C" int pg_ingest_fastq_shard(const char *path, int part, int n_parts, const int64_t *newlines_before, pg_reads **out)
+{
+    if (!path || !out || !newlines_before || n_parts < 1 || part < 0 || part >= n_parts) return pg_fail(PG_EINVAL, "pg_ingest_fastq_shard: bad argument");
+    *out = nullptr;
+    int fd; size_t size = 0;
+    int rc = open_for_shards(path, fd, size);
+    if (rc) return rc;
+    pg_reads *R = nullptr;
+    try {
+        PhaseTimer tm;
+        const Latch L = find_latch(fd, size);
+        Cut lo, hi;
+        lo.pos = 0; lo.found = true;
+        hi.pos = size; hi.found = false;
+        if (part > 0) rc = find_cut(fd, size, shard_byte(size, part, n_parts), (uint64_t)newlines_before[part], L, path, lo);
+        if (!rc && part + 1 < n_parts) rc = find_cut(fd, size, shard_byte(size, part + 1, n_parts), (uint64_t)newlines_before[part + 1], L, path, hi);
+        tm.lap("cuts");
+        if (!rc) R = new pg_reads();
+        if (!rc && !lo.found) {                       // the run in progress at this boundary lasts to the end of the file
+            R->mode = L.mode;
+            R->run_off.push_back(0);
+            R->seal_serial();
+        } else if (!rc) {
+            ShardCtx ctx;
+            ctx.unit_base = lo.unit;
+            ctx.last = lo.last;
+            ctx.trailing = !hi.found;
+            const size_t a = lo.pos, b = std::max(lo.pos, hi.pos);
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)ingest_threads(), (b - a) >> 16));
+            rc = ingest_interleaved_range(fd, a, b, path, R, T, L, ctx);
+        }
+    } catch (const std::bad_alloc &) {
+        rc = pg_fail(PG_ENOMEM, "out of memory while ingesting %s", path);
+    }
+    close(fd);
+    if (rc) { delete R; return rc; }
+    *out = R;
+    return PG_OK;
+}
+
 extern "C" void pg_reads_free(pg_reads *r) { delete r; }
-extern "C" int64_t pg_reads_n_chars(const pg_reads *r) { return r->st.n; }
-extern "C" int64_t pg_reads_n_words(const pg_reads *r) { return (int64_t)r->st.codes.size(); }
+extern "C" int64_t pg_reads_n_chars(const pg_reads *r) { return r->n_chars; }
+extern "C" int64_t pg_reads_n_words(const pg_reads *r) { return r->n_words; }
 extern "C" int64_t pg_reads_n_pairs(const pg_reads *r) { return r->n_pairs; }
 extern "C" int64_t pg_reads_n_unpaired(const pg_reads *r) { return r->n_unpaired; }
 extern "C" int64_t pg_reads_n_runs(const pg_reads *r) { return (int64_t)r->run_name.size(); }
-extern "C" const uint64_t *pg_reads_codes(const pg_reads *r) { return r->st.codes.data(); }
-extern "C" const uint32_t *pg_reads_valid(const pg_reads *r) { return r->st.valid.data(); }
+extern "C" const uint64_t *pg_reads_codes(const pg_reads *r) { return r->codes_w; }
+extern "C" const uint32_t *pg_reads_valid(const pg_reads *r) { return r->valid_w; }
 extern "C" const int64_t *pg_reads_run_off(const pg_reads *r) { return r->run_off.data(); }
 extern "C" const char *pg_reads_run_name(const pg_reads *r, int64_t i)
 {

@@ -1,8 +1,10 @@
 """Multi-GPU decomposition of the feature path (one process per GPU, torch.distributed; "nccl" is RCCL on ROCm).
 
 The reference is single-process; the decomposition is the build's own:
-  * rows (barcode runs) are independent -> every rank takes a contiguous range of runs, balanced by characters,
-    and produces its own block of the count matrices: no data-path collective for K1/K3 or the VAE encode;
+  * rows (barcode runs) are independent -> every rank takes a contiguous range of runs and produces its own block of
+    the count matrices: no data-path collective for K1/K3 or the VAE encode.  An uncompressed interleaved file is
+    already cut at ingest (byte ranges moved to run boundaries, `ingest_shard`), so no rank ever parses or holds
+    more than its share; other inputs are parsed whole and cut by runs, balanced by characters (`shard_stream`);
   * the k-mer multiplicity table is a global sum -> ONE exchange after counting: dense tables (k <= 16) are
     summed with an all-reduce; hash tables are compacted, all-gathered and merged -- bucket by bucket inside LDS,
     because every rank uses the same bucket geometry and a compacted table is already in bucket order -- after
@@ -64,6 +66,33 @@ def shard_stream(stream: ReadStream, rank: int, world: int) -> ReadStream:
         valid = torch.cat([valid, valid.new_zeros(pad)])
     run_off = stream.run_off[first:last + 1] - 32 * w0
     return ReadStream(codes, valid, c1 - 32 * w0, run_off.astype(np.int64), stream.run_names[first:last], mode=stream.mode)
+
+
+def ingest_shard(reads1: str, reads2: str | None = None, group=None) -> ReadStream:
+    """this rank's part of the input, as a host stream.
+
+    An uncompressed interleaved file (what ``run_pangaea`` sorts the reads into) is cut by bytes: every rank counts the
+    newlines of its own range, the counts are all-gathered (the only communication), and each rank reads and parses
+    just its range, moved to run boundaries (``pg_ingest_fastq_shard``) -- host work and memory per rank fall with the
+    number of ranks.  gzip and -1/-2 inputs cannot be cut by bytes: there every rank parses the file and keeps its
+    balanced range of runs (``shard_stream``)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sharded = reads2 is None
+    if sharded:
+        with open(reads1, "rb") as f:
+            sharded = f.read(2) != b"\x1f\x8b"
+    if not sharded:
+        return shard_stream(ReadStream.from_fastq(reads1, reads2), rank, world)
+    mine = torch.tensor([ReadStream.count_newlines(reads1, rank, world)], dtype=torch.int64)
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        counts = [c.to(dev) for c in counts]
+        dist.all_gather(counts, mine.to(dev), group=group)
+    else:
+        dist.all_gather(counts, mine, group=group)
+    before = np.concatenate([[0], np.cumsum([int(c.item()) for c in counts])]).astype(np.int64)
+    return ReadStream.from_fastq_shard(reads1, rank, world, before)
 
 
 def _staged(t: torch.Tensor, group=None) -> torch.Tensor:

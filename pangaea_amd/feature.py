@@ -74,9 +74,8 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     exchanged once, and the rows are gathered so every rank returns the full matrices."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    host = ReadStream.from_fastq(reads1, reads2)
-    world, rank = (torch.distributed.get_world_size(), torch.distributed.get_rank()) if pdist.is_distributed() else (1, 0)
-    part = pdist.shard_stream(host, rank, world) if world > 1 else host
+    world = torch.distributed.get_world_size() if pdist.is_distributed() else 1
+    part = pdist.ingest_shard(reads1, reads2) if world > 1 else ReadStream.from_fastq(reads1, reads2)
     stream = part.to(device)
     rows = stream.rows(min_len)
     plan = Plan(rows, device)

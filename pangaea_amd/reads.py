@@ -71,6 +71,34 @@ class ReadStream:
         L = _lib.load()
         h = C.c_void_p()
         _lib.check(L.pg_ingest_fastq(str(reads1).encode(), str(reads2).encode() if reads2 else None, C.byref(h)))
+        return cls._from_handle(L, h).to(device)
+
+    @classmethod
+    def from_fastq_shard(cls, reads: str, part: int, n_parts: int, newlines_before=None,
+                         device: str | torch.device = "cpu") -> "ReadStream":
+        """shard ``part`` of ``n_parts`` of an uncompressed interleaved FASTQ: only that byte range is read and parsed,
+        cut at run boundaries, so the shards' runs in rank order are the runs of the whole file.  ``newlines_before``
+        [n_parts + 1] are the newline counts in front of every byte boundary (``count_newlines`` per range, prefix
+        summed; ``pangaea_amd.dist.ingest_shard`` exchanges them between ranks); None counts them all here."""
+        L = _lib.load()
+        if newlines_before is None:
+            newlines_before = np.concatenate([[0], np.cumsum([cls.count_newlines(reads, i, n_parts) for i in range(n_parts)])])
+        before = np.ascontiguousarray(newlines_before, dtype=np.int64)
+        assert before.shape == (n_parts + 1,)
+        h = C.c_void_p()
+        _lib.check(L.pg_ingest_fastq_shard(str(reads).encode(), int(part), int(n_parts),
+                                           before.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(h)))
+        return cls._from_handle(L, h).to(device)
+
+    @staticmethod
+    def count_newlines(reads: str, part: int, n_parts: int) -> int:
+        """newlines in byte range ``part`` of ``n_parts`` of an uncompressed file (RuntimeError for gzip input)"""
+        n = C.c_int64()
+        _lib.check(_lib.load().pg_fastq_count_newlines(str(reads).encode(), int(part), int(n_parts), C.byref(n)))
+        return int(n.value)
+
+    @classmethod
+    def _from_handle(cls, L, h) -> "ReadStream":
         owner = _IngestHandle(L, h)
         nw, nr = L.pg_reads_n_words(h), L.pg_reads_n_runs(h)
         # zero-copy views of the library's arrays (the handle is freed with the last reference to this stream)
@@ -80,7 +108,7 @@ class ReadStream:
         names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
         out = cls(torch.from_numpy(codes), torch.from_numpy(valid), int(L.pg_reads_n_chars(h)), run_off, names,
                   int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode(), _owner=owner)
-        return out.to(device)
+        return out
 
     @classmethod
     def from_runs(cls, runs, device: str | torch.device = "cpu") -> "ReadStream":

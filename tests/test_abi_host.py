@@ -185,3 +185,86 @@ def test_parallel_ingest_equals_serial(tmp_path):
         L.pg_set_ingest_threads(0)
     rd = oracle.Reads(fq)
     assert ref.run_names == rd.names and np.array_equal(ref.run_off, rd.seq_off) and ref.n_pairs == rd.n_pairs
+
+
+def _shard_union(path, n_parts):
+    """(names, run texts, pairs, modes) of the shards of ``path`` in rank order"""
+    names, texts, pairs, modes = [], [], 0, set()
+    for r in range(n_parts):
+        s = ReadStream.from_fastq_shard(path, r, n_parts)
+        assert int(s.run_off[-1]) == s.n_chars          # interleaved: nothing outside the runs
+        names += s.run_names
+        texts += [s.decode(int(s.run_off[i]), int(s.run_off[i + 1])) for i in range(len(s.run_names))]
+        pairs += s.n_pairs
+        modes.add(s.mode)
+    return names, texts, pairs, modes
+
+
+def _whole(path):
+    s = ReadStream.from_fastq(path)
+    texts = [s.decode(int(s.run_off[i]), int(s.run_off[i + 1])) for i in range(len(s.run_names))]
+    return s, texts
+
+
+@pytest.mark.parametrize("spec", [s for s in _INPUTS.values() if "i" in s], ids=lambda s: s["i"])
+def test_sharded_ingest_reassembles_the_whole_file(spec, tmp_path):
+    """byte-range shards (any count, boundaries anywhere: inside headers, quality lines that start with '@', runs that
+    span several shards, the unbarcoded tail, a grammar that latches late) concatenate to the whole-file ingest"""
+    src = os.path.join(GOLDEN, spec["i"])
+    path = str(tmp_path / "plain.fq")
+    with (gzip.open(src, "rb") if src.endswith(".gz") else open(src, "rb")) as f:
+        open(path, "wb").write(f.read())
+    whole, texts = _whole(path)
+    for n_parts in (1, 2, 3, 5, 8, 13):
+        names, got, pairs, modes = _shard_union(path, n_parts)
+        assert names == whole.run_names and got == texts and pairs == whole.n_pairs
+        assert modes == {whole.mode}
+
+
+def test_sharded_ingest_large_file_and_errors(tmp_path):
+    from pangaea_amd import synth
+    L = _lib.load()
+    cfg = synth.SynthConfig(n_pairs=6000, n_barcodes=37, n_genomes=2, genome_len=30_000, fragment=5_000, n_rate=0.2, unbarcoded=0.2)
+    path = str(tmp_path / "a.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, path)
+    # quality lines made of '@' only: a boundary that lands there must not be taken for a header
+    lines = open(path).read().splitlines(keepends=True)
+    for i in range(3, len(lines), 4):
+        lines[i] = "@" * (len(lines[i]) - 1) + "\n"
+    head = "".join(f"@u{i}/1\nACGTNACGT\n+\n@@@@@@@@@\n@u{i}/2\nTTGCA\n+\n@@@@@\n" for i in range(300))
+    open(path, "w").write(head + "".join(lines[:-5]))          # late latch + a record cut short at the end
+    L.pg_set_ingest_threads(1)
+    whole, texts = _whole(path)                     # the sequential loop
+    try:
+        for T, block in ((1, None), (4, None), (3, "16"), (5, "4096")):      # tiny blocks: refills, growth, units across blocks
+            L.pg_set_ingest_threads(T)
+            if block:
+                os.environ["PG_INGEST_BLOCK"] = block
+            for n_parts in (2, 7, 8, 64):
+                names, got, pairs, _ = _shard_union(path, n_parts)
+                assert names == whole.run_names and got == texts and pairs == whole.n_pairs
+            if T > 1:
+                again = ReadStream.from_fastq(path)     # the threaded whole-file path through the same readers
+                assert np.array_equal(again.codes.numpy(), whole.codes.numpy()) and np.array_equal(again.valid.numpy(), whole.valid.numpy())
+                assert again.run_names == whole.run_names and np.array_equal(again.run_off, whole.run_off)
+    finally:
+        L.pg_set_ingest_threads(0)
+        os.environ.pop("PG_INGEST_BLOCK", None)
+    # the counts a caller exchanges: prefix sums over the ranges are the whole file's newline count
+    assert sum(ReadStream.count_newlines(path, r, 5) for r in range(5)) == open(path, "rb").read().count(b"\n")
+    # one barcode only: the run in progress never ends, every later shard is empty and rank 0 carries the lot
+    one = str(tmp_path / "one.fq")
+    open(one, "w").write("".join(f"@r{i} BX:Z:AAAA-1\nACGTACGTAC\n+\nIIIIIIIIII\n@r{i} BX:Z:AAAA-1\nGGGTTTAAAC\n+\nIIIIIIIIII\n" for i in range(50)))
+    w1, t1 = _whole(one)
+    names, got, pairs, _ = _shard_union(one, 4)
+    assert names == w1.run_names and got == t1 and pairs == 50
+    # gzip cannot be cut by bytes
+    gz = str(tmp_path / "a.fq.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(open(one, "rb").read())
+    with pytest.raises(RuntimeError, match="uncompressed"):
+        ReadStream.from_fastq_shard(gz, 0, 2)
+    with pytest.raises(RuntimeError, match="uncompressed"):
+        ReadStream.count_newlines(gz, 0, 2)
+    with pytest.raises(RuntimeError, match="cannot open"):
+        ReadStream.count_newlines(str(tmp_path / "missing.fq"), 0, 2)

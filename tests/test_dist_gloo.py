@@ -94,6 +94,36 @@ def test_two_ranks_gloo_cpu():
     _spawn(_gloo_worker, 2, os.path.join(GOLDEN, "tenx_mixed.fq"))
 
 
+def _ingest_worker(rank, world, port, fastq, gz):
+    _init(rank, world, port)
+    try:
+        whole = ReadStream.from_fastq(fastq)
+        want = [(n, whole.decode(int(a), int(b))) for n, a, b in zip(whole.run_names, whole.run_off[:-1], whole.run_off[1:])]
+        for path in (fastq, gz):            # cut by bytes at ingest / parsed whole and cut by runs
+            sh = pdist.ingest_shard(path)
+            mine = [(n, sh.decode(int(a), int(b))) for n, a, b in zip(sh.run_names, sh.run_off[:-1], sh.run_off[1:])]
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+            assert [r for p in parts for r in p] == want
+            pairs = torch.tensor([sh.n_pairs])
+            dist.all_reduce(pairs)
+            assert path == gz or int(pairs.item()) == whole.n_pairs
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_ingest_their_own_byte_ranges(world, tmp_path):
+    import gzip
+    from pangaea_amd import synth
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=23, n_genomes=2, genome_len=20_000, fragment=4_000, unbarcoded=0.1)
+    fq, gz = str(tmp_path / "a.fq"), str(tmp_path / "a.fq.gz")
+    synth.write_fastq(synth.generate(cfg), cfg, fq)
+    with gzip.open(gz, "wb") as f:
+        f.write(open(fq, "rb").read())
+    _spawn(_ingest_worker, world, fq, gz)
+
+
 def _gpu_worker(rank, world, port, fastq, outdir):
     _init(rank, world, port)
     try:

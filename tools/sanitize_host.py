@@ -51,6 +51,29 @@ for threads in (1, 2, 5, 16):
         else:
             ref[key] = (codes, off, names)
         lib.pg_reads_free(h)
+# sharded ingest of the plain files, also with tiny reader blocks (refills, buffer growth)
+for block in (None, "16", "300"):
+    if block:
+        os.environ["PG_INGEST_BLOCK"] = block
+    for threads in (1, 4):
+        lib.pg_set_ingest_threads(threads)
+        for path in (big, os.path.join(G, "tenx_mixed.fq"), os.path.join(G, "stlfr.fq")):
+            for parts in (1, 3, 8):
+                counts = []
+                for r in range(parts):
+                    c = i64(0)
+                    assert lib.pg_fastq_count_newlines(path.encode(), r, parts, C.byref(c)) == 0, lib.pg_last_error()
+                    counts.append(c.value)
+                before = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+                names, total = [], 0
+                for r in range(parts):
+                    h = vp()
+                    assert lib.pg_ingest_fastq_shard(path.encode(), r, parts, vp(before.ctypes.data), C.byref(h)) == 0, lib.pg_last_error()
+                    names += [lib.pg_reads_run_name(h, i) for i in range(lib.pg_reads_n_runs(h))]
+                    total += lib.pg_reads_n_chars(h)
+                    lib.pg_reads_free(h)
+                assert names == ref[(path, None)][2] and total == ref[(path, None)][1][-1]
+os.environ.pop("PG_INGEST_BLOCK", None)
 # error paths
 h = vp()
 assert lib.pg_ingest_fastq(b"/nonexistent", None, C.byref(h)) == -2
