@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -345,6 +346,9 @@ struct ShardCtx {
     bool trailing = true;         // the range ends at the end of the file: enqueue the trailing accumulator
 };
 
+uint64_t count_newlines_avx2(const char *p, size_t n);
+bool simd_ok();
+
 struct UnitLines { const char *p[8]; size_t n[8]; int count; size_t off; };   // up to 8 lines; off = file offset of the unit
 
 // sequential reader of file bytes [begin, end) through one block buffer; hands out lines and 8-line units
@@ -370,7 +374,8 @@ public:
         uint64_t c = 0;
         for (;;) {
             const char *p = buf_.data() + cur_, *e = buf_.data() + have_;
-            while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = q + 1; }
+            if (simd_) c += count_newlines_avx2(p, (size_t)(e - p));
+            else while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = q + 1; }
             cur_ = have_;
             if (eof_ || !more()) return c;
         }
@@ -416,6 +421,7 @@ private:
     std::vector<char> buf_;
     size_t have_ = 0, cur_ = 0;
     bool eof_ = false, io_error_ = false;
+    const bool simd_ = simd_ok();
 };
 
 // block size of the readers (PG_INGEST_BLOCK overrides: tests use tiny blocks to exercise refills and growth)
@@ -439,20 +445,83 @@ Latch find_latch(int fd, size_t size)
     return Latch{UINT64_MAX, MODE_UNSET};
 }
 
+// ---- character packing, 8 or 32 at a time.  A C G T -> valid, code (c >> 1) & 3; anything else -> invalid, code 0.
+
+// 8 characters (little-endian in x) -> 16 code bits + 8 validity bits, plain 64-bit arithmetic
+inline void pack8(uint64_t x, uint64_t &cb, uint32_t &vb)
+{
+    const uint64_t L7 = 0x7F7F7F7F7F7F7F7FULL;
+    auto is_zero = [&](uint64_t t) { return ~(((t & L7) + L7) | t | L7); };        // 0x80 in exactly the zero bytes
+    const uint64_t m = is_zero(x ^ 0x4141414141414141ULL) | is_zero(x ^ 0x4343434343434343ULL) |
+                       is_zero(x ^ 0x4747474747474747ULL) | is_zero(x ^ 0x5454545454545454ULL);
+    const uint64_t ones = m >> 7;                                                    // 0x01 per valid byte
+    vb = (uint32_t)((ones * 0x0102040810204080ULL) >> 56);                           // bit j = byte j
+    uint64_t y = (x >> 1) & 0x0303030303030303ULL & (ones * 0xFF);
+    y = (y | (y >> 6)) & 0x000F000F000F000FULL;
+    y = (y | (y >> 12)) & 0x000000FF000000FFULL;
+    cb = (y | (y >> 24)) & 0xFFFF;
+}
+
+// 32 characters -> 64 code bits + 32 validity bits
+__attribute__((target("avx2,bmi2"))) inline void pack32_avx2(const char *s, uint64_t &cb, uint32_t &vb)
+{
+    const __m256i x = _mm256_loadu_si256((const __m256i *)s);
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(x, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(x, _mm256_set1_epi8('C'))),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(x, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(x, _mm256_set1_epi8('T'))));
+    vb = (uint32_t)_mm256_movemask_epi8(ok);
+    const __m256i xm = _mm256_and_si256(x, ok);
+    const uint64_t M = 0x0606060606060606ULL;
+    cb = _pext_u64((uint64_t)_mm256_extract_epi64(xm, 0), M) | _pext_u64((uint64_t)_mm256_extract_epi64(xm, 1), M) << 16 |
+         _pext_u64((uint64_t)_mm256_extract_epi64(xm, 2), M) << 32 | _pext_u64((uint64_t)_mm256_extract_epi64(xm, 3), M) << 48;
+}
+
+__attribute__((target("avx2"))) uint64_t count_newlines_avx2(const char *p, size_t n)
+{
+    uint64_t c = 0;
+    const __m256i nl = _mm256_set1_epi8('\n');
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32)
+        c += (uint64_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nl)));
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+
+bool simd_ok()
+{
+    static const bool ok = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("PG_INGEST_NO_SIMD"); }();
+    return ok;
+}
+
 struct LocalStream {          // one thread's characters, packed from bit 0
     std::vector<uint64_t> codes;
     std::vector<uint32_t> valid;
     int64_t n = 0;
     uint64_t cw = 0; uint32_t vw = 0;
-    inline void put(unsigned char c)
+    const bool simd = simd_ok();
+    // `count` (1..32) characters; bits above them are zero
+    inline void put_bits(uint64_t cb, uint32_t vb, int count)
     {
-        const bool ok = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
         const int sh = (int)(n & 31);
-        if (ok) { cw |= (uint64_t)((c >> 1) & 3) << (2 * sh); vw |= 1u << sh; }
-        ++n;
-        if (sh == 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; }
+        cw |= cb << (2 * sh);
+        vw |= vb << sh;
+        n += count;
+        if (sh + count >= 32) {
+            codes.push_back(cw); valid.push_back(vw);
+            if (sh) { cw = cb >> (2 * (32 - sh)); vw = vb >> (32 - sh); } else { cw = 0; vw = 0; }
+        }
     }
-    void put_line(const char *s, size_t len) { for (size_t i = 0; i < len; ++i) put((unsigned char)s[i]); put('N'); }
+    // one sequence line followed by the separator the reference appends ('N': invalid)
+    void put_line(const char *s, size_t len)
+    {
+        size_t i = 0;
+        uint64_t cb; uint32_t vb;
+        if (simd) for (; i + 32 <= len; i += 32) { pack32_avx2(s + i, cb, vb); put_bits(cb, vb, 32); }
+        for (; i + 8 <= len; i += 8) { uint64_t x; memcpy(&x, s + i, 8); pack8(x, cb, vb); put_bits(cb, vb, 8); }
+        uint64_t x = 0;
+        memcpy(&x, s + i, len - i);                  // < 8 characters, zero padded (zero bytes are invalid), then the separator
+        pack8(x, cb, vb);
+        put_bits(cb, vb, (int)(len - i) + 1);
+    }
     void finish() { if (n & 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; } }
 };
 
