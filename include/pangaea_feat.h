@@ -199,6 +199,17 @@ int pg_kmer_merge_wide(const uint64_t *codes, const uint32_t *counts, int64_t n,
 int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
                            uint32_t *status, void *stream);
 
+/* The exchange step of the multi-GPU path in three launches around one all-gather (pangaea_amd/dist.py):
+ *   pg_table_bucket_fill      fill[b] = occupied slots of bucket b (device, [n_buckets])
+ *   pg_table_compact          occupied slots of bucket b -> out[seg[b] .. seg[b+1]), seg = exclusive scan of fill
+ *                             (device, [n_buckets + 1]); order inside a bucket is unspecified
+ *   pg_kmer_rebuild_bucketed  as pg_kmer_merge_bucketed, but the table is REBUILT from the parts alone (they include
+ *                             this rank's own compacted table): the old slots are neither read nor need be initialised */
+int pg_table_bucket_fill(const pg_table *t, int64_t *fill, void *stream);
+int pg_table_compact(const pg_table *t, const int64_t *seg, uint64_t *out, void *stream);
+int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
+                             uint32_t *status, void *stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Per-run feature rows (device).  One launch fills both matrices.
  *   tnf_out [n_rows, ncols(k_tnf)] int32: canonical k_tnf-mer counts        (count_tnf.cpp:78-113)

@@ -718,8 +718,10 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
 // into LDS, adds every foreign entry of that bucket (counts saturate exactly) and writes the slice back.
 //   pairs  : the foreign tables' occupied slots, concatenated part after part
 //   seg    : [n_parts][n_buckets + 1] offsets into `pairs` (absolute)
+// rebuild != 0: the slice is built from the parts alone (they include this rank's own compacted table), so the old
+// slice is neither read nor assumed to be initialised.
 __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
-                                                                 int n_parts, HashView t, uint32_t *status)
+                                                                 int n_parts, HashView t, uint32_t *status, int rebuild)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     const uint32_t n_slots = 1u << t.log2_bucket;
@@ -730,8 +732,8 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t 
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     int64_t total = 0;
     for (int p = 0; p < n_parts; ++p) total += seg[p * (n_buckets + 1) + blockIdx.x + 1] - seg[p * (n_buckets + 1) + blockIdx.x];
-    if (total == 0) return;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = slice[i];
+    if (total == 0 && !rebuild) return;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = rebuild ? 0ull : slice[i];
     __syncthreads();
     bool full = false;
     for (int p = 0; p < n_parts; ++p) {
@@ -762,6 +764,54 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t 
     if (full) atomicOr(status, 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+}
+
+// occupied slots of every bucket: the segment lengths of a bucket-ordered compaction (one workgroup per bucket)
+__global__ __launch_bounds__(BLOCK) void bucket_fill_kernel(const uint64_t *__restrict__ slots, int log2_bucket, long long *__restrict__ fill)
+{
+    __shared__ uint32_t part[WAVES];
+    const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(slots + ((uint64_t)blockIdx.x << log2_bucket));
+    const uint32_t n2 = 1u << (log2_bucket - 1);
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < n2; i += BLOCK) {
+        const ulonglong2 v = s2[i];
+        c += (v.x != 0) + (v.y != 0);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < WAVES; ++w) tot += part[w];
+        fill[blockIdx.x] = (long long)tot;
+    }
+}
+
+// bucket-ordered compaction: the occupied slots of bucket b go to out[seg[b] .. seg[b + 1]) (seg = exclusive scan of the
+// fills; order inside a bucket is free, the merge inserts them one by one)
+__global__ __launch_bounds__(BLOCK) void table_compact_kernel(const uint64_t *__restrict__ slots, int log2_bucket,
+                                                              const long long *__restrict__ seg, uint64_t *__restrict__ out)
+{
+    __shared__ uint32_t cursor;
+    if (threadIdx.x == 0) cursor = 0;
+    __syncthreads();
+    const uint64_t *slice = slots + ((uint64_t)blockIdx.x << log2_bucket);
+    uint64_t *dst = out + seg[blockIdx.x];
+    const uint32_t n = 1u << log2_bucket;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = 0; base < n; base += BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? slice[i] : 0ull;
+        const unsigned long long m = __ballot(v != 0);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t at = 0;
+            if ((int)lane == leader) at = atomicAdd(&cursor, (uint32_t)__popcll(m));
+            at = __shfl(at, leader);
+            if (v != 0) dst[at + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------- K3 by shuffle
@@ -1312,8 +1362,53 @@ extern "C" int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg,
     const size_t lds = (size_t)8 << t->log2_bucket_slots;
     if ((rc = raise_lds_limit((const void *)bucket_merge_kernel, lds, "pg_kmer_merge_bucketed"))) return rc;
     hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
-                       n_parts, view_of(t), status);
+                       n_parts, view_of(t), status, 0);
     return check_launch("pg_kmer_merge_bucketed");
+}
+
+extern "C" int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t, uint32_t *status, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_HASH || t->log2_bucket_slots == 0 || t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS)
+        return pg_fail(PG_EINVAL, "pg_kmer_rebuild_bucketed: needs a bucketed hash table with LDS-sized buckets");
+    if (n_parts < 1 || !pairs || !seg || !status) return pg_fail(PG_EINVAL, "pg_kmer_rebuild_bucketed: bad arguments");
+    const int bits = t->log2_slots - t->log2_bucket_slots;
+    if (bits < 0 || bits > 30) return pg_fail(PG_EINVAL, "pg_kmer_rebuild_bucketed: bad bucket geometry");
+    const size_t lds = (size_t)8 << t->log2_bucket_slots;
+    if ((rc = raise_lds_limit((const void *)bucket_merge_kernel, lds, "pg_kmer_rebuild_bucketed"))) return rc;
+    hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
+                       n_parts, view_of(t), status, 1);
+    return check_launch("pg_kmer_rebuild_bucketed");
+}
+
+static int check_bucketed(const pg_table *t, const char *who)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_HASH || t->log2_bucket_slots < 1) return pg_fail(PG_EINVAL, "%s: needs a bucketed hash table", who);
+    if (t->log2_slots - t->log2_bucket_slots > 30) return pg_fail(PG_EINVAL, "%s: too many buckets for one launch", who);
+    return PG_OK;
+}
+
+extern "C" int pg_table_bucket_fill(const pg_table *t, int64_t *fill, void *stream)
+{
+    int rc = check_bucketed(t, "pg_table_bucket_fill");
+    if (rc) return rc;
+    if (!fill) return pg_fail(PG_EINVAL, "pg_table_bucket_fill: null output");
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3(1u << (t->log2_slots - t->log2_bucket_slots)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint64_t *)t->data, t->log2_bucket_slots, (long long *)fill);
+    return check_launch("pg_table_bucket_fill");
+}
+
+extern "C" int pg_table_compact(const pg_table *t, const int64_t *seg, uint64_t *out, void *stream)
+{
+    int rc = check_bucketed(t, "pg_table_compact");
+    if (rc) return rc;
+    if (!seg || !out) return pg_fail(PG_EINVAL, "pg_table_compact: null argument");
+    hipLaunchKernelGGL(table_compact_kernel, dim3(1u << (t->log2_slots - t->log2_bucket_slots)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint64_t *)t->data, t->log2_bucket_slots, (const long long *)seg, out);
+    return check_launch("pg_table_compact");
 }
 
 extern "C" int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize, const pg_table *t)

@@ -6,9 +6,9 @@ The reference is single-process; the decomposition is the build's own (SURVEY 8e
     already cut at ingest (byte ranges moved to run boundaries, `ingest_shard`), so no rank ever parses or holds
     more than its share; other inputs are parsed whole and cut by runs, balanced by characters (`shard_stream`);
   * the k-mer multiplicity table is a global sum -> ONE exchange after counting: dense tables (k <= 16) are
-    summed with an all-reduce; hash tables are compacted, all-gathered and merged -- bucket by bucket inside LDS,
-    because every rank uses the same bucket geometry and a compacted table is already in bucket order -- after
-    which every rank holds the full table and looks up locally.
+    summed with an all-reduce; hash tables are compacted bucket by bucket straight into one gather buffer,
+    all-gathered in place, and rebuilt from all parts -- one workgroup per bucket inside LDS, because every rank uses
+    the same bucket geometry -- after which every rank holds the full table and looks up locally.
 """
 from __future__ import annotations
 
@@ -100,6 +100,19 @@ def _staged(t: torch.Tensor, group=None) -> torch.Tensor:
     return t.cpu() if t.is_cuda and dist.get_backend(group) == "gloo" else t
 
 
+def _all_gather_flat(out: torch.Tensor, mine: torch.Tensor, rank: int, group=None) -> None:
+    """all-gather of equal-sized contiguous vectors into one flat buffer (RCCL: one collective, no list copies);
+    gloo: staged through the host"""
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, mine, group=group)
+        return
+    n = mine.numel()
+    host = [torch.empty(n, dtype=out.dtype) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(host, mine.cpu().contiguous(), group=group)
+    for r, h in enumerate(host):
+        out[r * n:(r + 1) * n].copy_(h)
+
+
 def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
     """all-gather of variable-length int64 vectors (padded to the longest); returns one tensor per rank"""
     world = dist.get_world_size(group)
@@ -147,15 +160,28 @@ def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTabl
         if check:
             table.check_status()
         return table
-    parts = gather_pairs(table.compact(), group)
-    if table.log2_bucket:
-        # every rank built its table with the same geometry, so compacted tables are bucket-ordered: exchange the
-        # per-bucket counts too and merge bucket by bucket inside LDS (no global atomics)
-        mine = _staged(table.bucket_counts(), group)
-        counts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(counts, mine, group=group)
-        table.merge_parts([(parts[r], counts[r]) for r in range(world) if r != me], check=False)
+    if table._bucketed():
+        # every rank built its table with the same geometry.  Per-bucket fills are exchanged first (8 B per bucket); they
+        # give the segment offsets of every rank's bucket-ordered compaction; the compactions are gathered into ONE buffer
+        # (padded to the longest part; the padding is never read).  The table is
+        # then rebuilt bucket by bucket inside LDS from all parts, the own one included -- the sparse slices are read
+        # once (to compact) and written once (the merged image), and nothing is concatenated or scanned by torch.
+        fill = table.bucket_fill()
+        nb = table.n_buckets
+        fills = torch.empty((world, nb), dtype=torch.int64, device=fill.device)
+        _all_gather_flat(fills.view(-1), fill, me, group)
+        ends = torch.cumsum(fills, dim=1)
+        cap = max(int(ends[:, -1].max().item()), 1)
+        seg = torch.zeros((world, nb + 1), dtype=torch.int64, device=fill.device)
+        seg[:, 1:] = ends
+        buf = torch.empty(world * cap, dtype=torch.int64, device=fill.device)
+        mine = torch.empty(cap, dtype=torch.int64, device=fill.device)
+        table.compact_into(mine, seg[me].contiguous())
+        _all_gather_flat(buf, mine, me, group)
+        seg += torch.arange(world, device=fill.device, dtype=torch.int64)[:, None] * cap
+        table.rebuild_from(buf, seg, check=False)
     else:
+        parts = gather_pairs(table.compact(), group)
         for r, pairs in enumerate(parts):
             if r != me and pairs.numel():
                 table.merge(pairs, check=False)

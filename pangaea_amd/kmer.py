@@ -267,11 +267,56 @@ class KmerTable:
             self.check_status()
         return self
 
+    # ---- the exchange step's kernels (dist.exchange_table): fills -> bucket-ordered compaction -> rebuild from all parts
+
+    def _bucketed(self) -> bool:
+        return self.kind == "hash" and 0 < self.log2_bucket <= _lib.BUCKET_MAX_LOG2_SLOTS
+
+    def bucket_fill(self) -> torch.Tensor:
+        """``bucket_counts()`` by one kernel pass over the table (int64 [n_buckets], on the device)"""
+        if not self._bucketed():
+            raise ValueError("bucket_fill() is for bucketed hash tables")
+        if self._empty:
+            self.data.zero_()
+            self._empty = False
+        fill = torch.empty(self.n_buckets, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_table_bucket_fill(self.desc(), fill.data_ptr(), _stream_ptr(self.device)))
+        return fill
+
+    def compact_into(self, out: torch.Tensor, seg: torch.Tensor) -> None:
+        """occupied slots, bucket after bucket, into ``out`` at the offsets ``seg`` (int64 [n_buckets + 1], the exclusive
+        scan of ``bucket_fill()``); order inside a bucket is unspecified"""
+        if not self._bucketed():
+            raise ValueError("compact_into() is for bucketed hash tables")
+        _require_gpu(out, "the output")
+        assert out.dtype == torch.int64 and out.is_contiguous() and seg.dtype == torch.int64 and seg.numel() == self.n_buckets + 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_table_compact(self.desc(), seg.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
+
+    def rebuild_from(self, pairs: torch.Tensor, seg: torch.Tensor, check: bool = True) -> "KmerTable":
+        """replace the table by the merge of ``seg.shape[0]`` bucket-ordered compacted tables of this geometry laid out in
+        ``pairs`` (``seg`` int64 [n_parts, n_buckets + 1], absolute offsets): one workgroup per bucket, inside LDS"""
+        if not self._bucketed():
+            raise ValueError("rebuild_from() is for bucketed hash tables")
+        _require_gpu(pairs, "the pairs")
+        assert pairs.dtype == torch.int64 and seg.dtype == torch.int64 and seg.is_contiguous() and seg.shape[1] == self.n_buckets + 1
+        self._empty = False                 # (the row-tagged records of this rank's count stay valid: the geometry is the same)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_kmer_rebuild_bucketed(pairs.data_ptr(), seg.data_ptr(), int(seg.shape[0]), self.desc(),
+                                                            self.status.data_ptr(), _stream_ptr(self.device)))
+        if check:
+            self.check_status()
+        return self
+
     def compact(self) -> torch.Tensor:
         """occupied slots of a hash table as an int64 vector (slot format)"""
         if self.kind != "hash":
             raise ValueError("compact() is for hash tables")
-        return self.data[self.data != 0]
+        step = 1 << 30                       # torch's masked select overflows its 32-bit indexing at 2^31 elements
+        if self.data.numel() <= step:
+            return self.data[self.data != 0]
+        return torch.cat([c[c != 0] for c in self.data.split(step)])
 
     def occupancy(self) -> float:
         if self.kind == "wide":

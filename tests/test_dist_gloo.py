@@ -147,3 +147,28 @@ def test_two_ranks_real_kernels_match_single_process(tmp_path):
     names, tnf, abd = rd.features(100, k_tnf=4, k_abd=21, table=table, window=1, vsize=6)
     assert list(got["names"]) == names
     assert np.array_equal(got["tnf"], tnf) and np.array_equal(got["abd"], abd)
+
+
+def _rccl_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        # the collectives of the exchange as RCCL sees them (a one-rank group is all a one-GPU box can hold)
+        mine = torch.arange(1000, dtype=torch.int64, device="cuda") * 3
+        out = torch.empty(1000, dtype=torch.int64, device="cuda")
+        pdist._all_gather_flat(out, mine, rank)
+        assert torch.equal(out, mine)
+        parts = pdist.gather_pairs(mine)
+        assert len(parts) == 1 and torch.equal(parts[0], mine)
+        t = torch.ones(8, dtype=torch.int32, device="cuda")
+        dist.all_reduce(t)
+        assert int(t.sum()) == 8
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_of_the_exchange_run():
+    _spawn(_rccl_worker, 1)

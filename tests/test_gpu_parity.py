@@ -265,6 +265,41 @@ def test_merging_tables_bucket_by_bucket(log2_slots, log2_bucket):
     assert len(gc) == len(want.items()[0])
 
 
+@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 10), (20, 6), (18, 14), (17, 5)])
+def test_exchange_kernels_fill_compact_rebuild(log2_slots, log2_bucket):
+    """the three launches of the multi-GPU exchange: per-bucket fills, bucket-ordered compaction into a padded gather
+    buffer, and the rebuild of the table from all parts (own one included, old slots ignored)"""
+    cfg = synth.SynthConfig(n_pairs=2500 if log2_slots > 17 else 60, n_barcodes=20, n_genomes=3, genome_len=20_000, fragment=8_000, seed=43)
+    s = synth.generate(cfg, device=DEV)
+    cut = s.n_words // 3 + 2
+    parts = [kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket).count(s, a, b)
+             for a, b in ((0, cut), (cut, s.n_words), (cut, s.n_words))]
+    fills = torch.stack([t.bucket_fill() for t in parts])
+    assert all(torch.equal(f, t.bucket_counts()) for f, t in zip(fills, parts))
+    nb, world = parts[0].n_buckets, len(parts)
+    cap = int(fills.sum(1).max()) + 7                           # padding of the gather buffer is never read
+    seg = torch.zeros((world, nb + 1), dtype=torch.int64, device=DEV)
+    seg[:, 1:] = torch.cumsum(fills, 1)
+    buf = torch.full((world * cap,), -1, dtype=torch.int64, device=DEV)
+    for r, t in enumerate(parts):
+        t.compact_into(buf[r * cap:(r + 1) * cap], seg[r].contiguous())
+        got = buf[r * cap:r * cap + int(fills[r].sum())]
+        assert torch.equal(torch.sort(got).values, torch.sort(t.compact()).values)
+        # bucket by bucket: the segment of bucket b holds exactly that bucket's occupied slots
+        b = nb // 2
+        seg_b = got[int(seg[r, b]):int(seg[r, b + 1])]
+        assert torch.equal(torch.sort(seg_b).values, torch.sort(t.data.view(nb, -1)[b][t.data.view(nb, -1)[b] != 0]).values)
+    seg += torch.arange(world, device=DEV)[:, None] * cap
+    out = kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket)
+    out.data.fill_(0x7FFF_FFFF_FFFF)                            # garbage: a rebuild must not read the old slots
+    out.rebuild_from(buf, seg)
+    want = kmer.KmerTable.with_slots(21, DEV, log2_slots, 0).count(s).count(s, cut, s.n_words)
+    assert all(np.array_equal(x, y) for x, y in zip(out.items(), want.items()))
+    # same result as the accumulate-into-own-table form
+    parts[0].merge_parts([(t.compact(), t.bucket_counts()) for t in parts[1:]])
+    assert all(np.array_equal(x, y) for x, y in zip(out.items(), parts[0].items()))
+
+
 def test_bucket_overflow_is_reported():
     cfg = synth.SynthConfig(n_pairs=4000, n_barcodes=16, n_genomes=2, genome_len=300_000, fragment=60_000, seed=77)
     s = synth.generate(cfg, device=DEV)
