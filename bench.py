@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--barcodes", type=int, default=0, help="barcodes per GPU (default pairs/200)")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="pairs in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-defer", action="store_true", help="N > 1: write every rank's own table and compact it (instead of the deferred count)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     return ap.parse_args()
 
@@ -132,9 +133,18 @@ def main():
     stream = synth.generate(cfg, device=dev, chunk_pairs=1 << 17, with_names=False)
     rows = stream.rows(MIN_LEN)
     plan = kmer.Plan(rows, dev)
-    # distinct 21-mers: <= 128 M genomic + ~21 per substitution error; sized for the union over ranks at load <= 0.5
-    distinct_hint = int(130e6 + 0.7e8 * world * args.pairs / 10e6) if args.pairs >= 1_000_000 else stream.n_chars
-    table = kmer.KmerTable.alloc(K_ABD, dev, "hash", distinct_hint=distinct_hint)
+    # table sized from HyperLogLog sketches, outside the timed region: the elementwise maximum of the ranks' sketches is the
+    # sketch of the union, so every rank allocates the same table (geometry of the union) at load <= 0.6
+    regs = kmer.distinct_sketch(stream, K_ABD)
+    local_distinct = kmer.sketch_estimate(regs)
+    if world > 1:
+        union = regs if args.backend == "nccl" else regs.cpu()
+        dist.all_reduce(union, op=dist.ReduceOp.MAX)
+        regs = union
+    table = kmer.KmerTable.alloc(K_ABD, dev, "hash", distinct_hint=max(1 << 14, int(1.05 * kmer.sketch_estimate(regs))), load=0.6)
+    # N > 1: a rank's own keys are 2^g times sparser than the union and are counted in deferred form (entries + fills for
+    # the exchange; the rank's own sparse table is never written)
+    defer = pdist.deferred_group_for(table, int(1.1 * local_distinct)) if world > 1 and not args.no_defer else None
     tnf = torch.zeros((len(rows), kmer.tnf_ncols(K_TNF)), dtype=torch.int32, device=dev)
     abd = torch.zeros((len(rows), VSIZE), dtype=torch.int32, device=dev)
     torch.manual_seed(2021)
@@ -149,7 +159,7 @@ def main():
         e[0].record()
         table.reset()                   # bucketed tables are overwritten slice by slice: no 4 GB clear
 
-        table.count(stream, check=False, rows=plan)
+        table.count(stream, check=False, rows=plan, deferred_group=defer if defer is not None and table.can_defer(stream.n_words) else None)
         e[1].record()
         pdist.exchange_table(table, check=False)
         e[2].record()

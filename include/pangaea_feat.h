@@ -206,6 +206,18 @@ int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg, int n_part
  *   pg_kmer_rebuild_bucketed  as pg_kmer_merge_bucketed, but the table is REBUILT from the parts alone (they include
  *                             this rank's own compacted table): the old slots are neither read nor need be initialised */
 int pg_table_bucket_fill(const pg_table *t, int64_t *fill, void *stream);
+/* Counting for the exchange without materialising this rank's table: `t` has the geometry of the union over all ranks
+ * (the records are partitioned the way the final lookups need them), 2^group_log2 adjacent buckets are counted together
+ * in one LDS table (a rank's share of the keys is that much sparser), and only the occupied entries and fill[b] are
+ * produced -- t->data is NOT written.  The entries stay in the workspace until pg_deferred_gather copies bucket b's to
+ * out[seg[b] ..] (seg = exclusive scan of fill).  Needs more than 256 buckets; the row-tagged records for
+ * pg_abundance_from_records are left behind exactly as by pg_kmer_count_bucketed. */
+#define PG_DEFERRED_MAX_GROUP_LOG2 3
+int pg_kmer_count_deferred(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                           const pg_table *t, int group_log2, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
+                           int64_t *fill, uint32_t *status, void *stream);
+int pg_deferred_gather(const pg_table *t, const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                       const int64_t *fill, const int64_t *seg, uint64_t *out, void *stream);
 int pg_table_compact(const pg_table *t, const int64_t *seg, uint64_t *out, void *stream);
 int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
                              uint32_t *status, void *stream);

@@ -682,6 +682,76 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
     // records are read as aligned 16-byte pairs: pair index q covers records 2q, 2q+1 of the buffer
     const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
     const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
+    // software pipeline: the loads of the next batch are in flight while this batch is resolved in LDS
+    const int64_t stride = (int64_t)BIG_BLOCK * (CNT_BATCH / 2);
+    ulonglong2 nxt[CNT_BATCH / 2];
+#pragma unroll
+    for (int j = 0; j < CNT_BATCH / 2; ++j) {
+        const int64_t q = q0 + (int64_t)j * BIG_BLOCK + threadIdx.x;
+        nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
+    }
+    for (int64_t base = q0; base < q1; base += stride) {
+        uint64_t rr[CNT_BATCH];
+        bool live[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            const ulonglong2 v = nxt[j];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            rr[2 * j] = live[2 * j] ? v.x & REC_KEY_MASK : 0ull;
+            rr[2 * j + 1] = live[2 * j + 1] ? v.y & REC_KEY_MASK : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + stride + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
+        }
+        uint32_t ss[CNT_BATCH];
+        unsigned long long first[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            ss[j] = (uint32_t)(mix64(rr[j]) >> hsh) & smask;
+            first[j] = live[j] ? tab[ss[j]] : 0ull;
+        }
+        // resolved one by one, written out by hand: an unrolled loop around the probe loop is not unrolled by hipcc and
+        // would push the batch arrays into scratch
+#define PG_RESOLVE(J) full |= !lds_insert(tab, smask, limit, rr[J], live[J], ss[J], first[J]);
+        PG_RESOLVE(0) PG_RESOLVE(1) PG_RESOLVE(2) PG_RESOLVE(3) PG_RESOLVE(4) PG_RESOLVE(5) PG_RESOLVE(6) PG_RESOLVE(7)
+#undef PG_RESOLVE
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+}
+
+// B for the multi-GPU path: the rank's table is never materialised.  The table descriptor has the geometry of the UNION
+// over all ranks (so that the records are partitioned the way the final lookups need them), but one rank's share of the
+// keys is 2^g times sparser: a workgroup therefore counts 2^g adjacent final buckets together in one LDS table of the
+// usual size (hash bits after the group's), and instead of a 2^log2_bucket-slot image per final bucket it writes only
+// the occupied entries, split by final bucket, to scratch[off[b] ..] (a bucket has no more distinct keys than records)
+// and their number to fill[b] -- exactly what the exchange sends.  The LDS rebuild after the all-gather writes the table.
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                         HashView t, int g, uint64_t *__restrict__ scratch,
+                                                                         long long *__restrict__ fill, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ uint32_t qcnt[1 << PG_DEFERRED_MAX_GROUP_LOG2];
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = 64 - (t.log2_slots - g);                        // slot inside the group's table
+    const int bsh = 64 - (t.log2_slots - t.log2_bucket);            // final bucket id
+    const uint32_t qmask = (1u << g) - 1u;
+    const int64_t b0 = (int64_t)blockIdx.x << g;
+    const int64_t r0 = (int64_t)off[b0], r1 = (int64_t)off[b0 + (1 << g)];
+    if (threadIdx.x <= qmask) qcnt[threadIdx.x] = 0;
+    if (r0 == r1) { if (threadIdx.x <= qmask) fill[b0 + threadIdx.x] = 0; return; }
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = 0ull;
+    __syncthreads();
+    bool full = false;
+    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
+    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
     for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
         uint64_t rr[CNT_BATCH];
         bool live[CNT_BATCH];
@@ -702,15 +772,34 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
             ss[j] = (uint32_t)(mix64(rr[j]) >> hsh) & smask;
             first[j] = live[j] ? tab[ss[j]] : 0ull;
         }
-        // resolved one by one, written out by hand: an unrolled loop around the probe loop is not unrolled by hipcc and
-        // would push the batch arrays into scratch
 #define PG_RESOLVE(J) full |= !lds_insert(tab, smask, limit, rr[J], live[J], ss[J], first[J]);
         PG_RESOLVE(0) PG_RESOLVE(1) PG_RESOLVE(2) PG_RESOLVE(3) PG_RESOLVE(4) PG_RESOLVE(5) PG_RESOLVE(6) PG_RESOLVE(7)
 #undef PG_RESOLVE
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const unsigned long long v = tab[i];
+        if (v) {
+            const uint32_t q = (uint32_t)(mix64(v >> HASH_CBITS) >> bsh) & qmask;
+            scratch[off[b0 + q] + atomicAdd(&qcnt[q], 1u)] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x <= qmask) fill[b0 + threadIdx.x] = (long long)qcnt[threadIdx.x];
+}
+
+// the deferred entries of bucket b, scratch[off[b] .. off[b] + fill[b]), to out[seg[b] ..]: one wavefront per bucket
+__global__ __launch_bounds__(BLOCK) void deferred_gather_kernel(const uint64_t *__restrict__ scratch, const unsigned long long *__restrict__ off,
+                                                                const long long *__restrict__ fill, const long long *__restrict__ seg,
+                                                                int64_t n_buckets, uint64_t *__restrict__ out)
+{
+    const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (b >= n_buckets) return;
+    const uint64_t *src = scratch + off[b];
+    uint64_t *dst = out + seg[b];
+    const long long n = fill[b];
+    for (long long i = threadIdx.x & 63; i < n; i += 64) dst[i] = src[i];
 }
 
 // Bucket-wise merge of other tables into this one: the compacted tables of the other ranks arrive bucket by bucket
@@ -720,6 +809,25 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
 //   seg    : [n_parts][n_buckets + 1] offsets into `pairs` (absolute)
 // rebuild != 0: the slice is built from the parts alone (they include this rank's own compacted table), so the old
 // slice is neither read nor assumed to be initialised.
+__device__ __forceinline__ bool lds_merge(unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code, uint32_t add,
+                                          uint32_t s, unsigned long long cur)
+{
+    for (uint32_t tries = 0; tries < limit; ++tries) {
+        for (;;) {
+            if (cur != 0 && (cur >> HASH_CBITS) != code) break;
+            const uint32_t have = (uint32_t)(cur & HASH_CMASK);
+            const uint32_t sum = have + add > HASH_SAT ? HASH_SAT : have + add;
+            const unsigned long long old = atomicCAS(&tab[s], cur, (unsigned long long)((code << HASH_CBITS) | sum));
+            if (old == cur) return true;
+            cur = old;
+        }
+        s = (s + 1) & smask;
+        cur = tab[s];
+    }
+    return false;
+}
+
+constexpr int MERGE_BATCH = 4;
 __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
                                                                  int n_parts, HashView t, uint32_t *status, int rebuild)
 {
@@ -738,27 +846,28 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t 
     bool full = false;
     for (int p = 0; p < n_parts; ++p) {
         const int64_t a = seg[p * (n_buckets + 1) + blockIdx.x], b = seg[p * (n_buckets + 1) + blockIdx.x + 1];
-        for (int64_t i = a + threadIdx.x; i < b; i += BIG_BLOCK) {
-            const uint64_t e = pairs[i];
-            const uint64_t code = e >> HASH_CBITS;
-            uint32_t add = (uint32_t)(e & HASH_CMASK);
-            if (add > HASH_SAT) add = HASH_SAT;
-            uint32_t s = (uint32_t)(mix64(code) >> hsh) & smask;
-            bool done = false;
-            for (uint32_t tries = 0; tries < limit && !done; ++tries) {
-                unsigned long long cur = tab[s];
-                for (;;) {
-                    if (cur != 0 && (cur >> HASH_CBITS) != code) break;
-                    const uint32_t have = (uint32_t)(cur & HASH_CMASK);
-                    const uint32_t sum = have + add > HASH_SAT ? HASH_SAT : have + add;
-                    const unsigned long long want = (code << HASH_CBITS) | sum;
-                    const unsigned long long old = atomicCAS(&tab[s], cur, want);
-                    if (old == cur) { done = true; break; }
-                    cur = old;
-                }
-                s = (s + 1) & smask;
+        for (int64_t base = a; base < b; base += (int64_t)BIG_BLOCK * MERGE_BATCH) {
+            uint64_t e[MERGE_BATCH];
+#pragma unroll
+            for (int j = 0; j < MERGE_BATCH; ++j) {                  // a part's whole segment of this bucket is usually one batch
+                const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+                e[j] = i < b ? pairs[i] : 0ull;
             }
-            full |= !done;
+            uint32_t ss[MERGE_BATCH];
+            unsigned long long first[MERGE_BATCH];
+#pragma unroll
+            for (int j = 0; j < MERGE_BATCH; ++j) {
+                ss[j] = (uint32_t)(mix64(e[j] >> HASH_CBITS) >> hsh) & smask;
+                first[j] = e[j] ? tab[ss[j]] : 0ull;
+            }
+#define PG_MERGE(J)                                                                                                         \
+            if (e[J]) {                                                                                                     \
+                uint32_t add = (uint32_t)(e[J] & HASH_CMASK);                                                               \
+                if (add > HASH_SAT) add = HASH_SAT;                                                                         \
+                full |= !lds_merge(tab, smask, limit, e[J] >> HASH_CBITS, add, ss[J], first[J]);                            \
+            }
+            PG_MERGE(0) PG_MERGE(1) PG_MERGE(2) PG_MERGE(3)
+#undef PG_MERGE
         }
     }
     if (full) atomicOr(status, 1u);
@@ -1253,9 +1362,50 @@ extern "C" int64_t pg_kmer_count_workspace_bytes(int64_t n_words, const pg_table
     return (int64_t)p.total;
 }
 
+namespace {
+int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                        const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
+                        uint32_t *status, void *stream, int deferred_group, int64_t *fill);
+}
+
 extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
                                       const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
                                       uint32_t *status, void *stream)
+{
+    return count_bucketed_impl(codes, valid, word_begin, word_end, t, accumulate, rows, workspace, workspace_bytes, status, stream, -1, nullptr);
+}
+
+extern "C" int pg_kmer_count_deferred(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                                      const pg_table *t, int group_log2, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
+                                      int64_t *fill, uint32_t *status, void *stream)
+{
+    if (group_log2 < 0 || group_log2 > PG_DEFERRED_MAX_GROUP_LOG2) return pg_fail(PG_EINVAL, "pg_kmer_count_deferred: group_log2 %d not in [0,%d]", group_log2, PG_DEFERRED_MAX_GROUP_LOG2);
+    if (!fill) return pg_fail(PG_EINVAL, "pg_kmer_count_deferred: null fill array");
+    return count_bucketed_impl(codes, valid, word_begin, word_end, t, 0, rows, workspace, workspace_bytes, status, stream, group_log2, fill);
+}
+
+extern "C" int pg_deferred_gather(const pg_table *t, const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                                  const int64_t *fill, const int64_t *seg, uint64_t *out, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!count_workspace || !fill || !seg || !out) return pg_fail(PG_EINVAL, "pg_deferred_gather: null argument");
+    BucketPlan p;
+    if ((rc = plan_buckets(t, n_words_counted, &p))) return rc;
+    if (!p.bits2) return pg_fail(PG_EINVAL, "pg_deferred_gather: the deferred form needs more than 256 buckets");
+    if ((int64_t)p.total > count_workspace_bytes) return pg_fail(PG_EINVAL, "pg_deferred_gather: count workspace does not match n_words_counted");
+    const char *ws = (const char *)count_workspace;
+    const int64_t nb = (int64_t)1 << p.bits;
+    hipLaunchKernelGGL(deferred_gather_kernel, dim3((unsigned)((nb + WAVES - 1) / WAVES)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint64_t *)(ws + p.bufa_off), (const unsigned long long *)(ws + p.off_off), (const long long *)fill,
+                       (const long long *)seg, nb, out);
+    return check_launch("pg_deferred_gather");
+}
+
+namespace {
+int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                        const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
+                        uint32_t *status, void *stream, int deferred_group, int64_t *fill)
 {
     if (!codes || !valid || !workspace || !status) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: null argument");
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: bad word range");
@@ -1268,8 +1418,16 @@ extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *val
     if ((int64_t)p.total > workspace_bytes)
         return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)p.total);
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: workspace must be 256-byte aligned");
-    if (word_end == word_begin) return PG_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (deferred_group >= 0) {
+        if (!p.bits2) return pg_fail(PG_EINVAL, "pg_kmer_count_deferred: the deferred form needs more than 256 buckets");
+        if (deferred_group > p.bits2) return pg_fail(PG_EINVAL, "pg_kmer_count_deferred: group_log2 %d exceeds the second-pass bits %d", deferred_group, p.bits2);
+        if (word_end == word_begin) {
+            if (hipMemsetAsync(fill, 0, sizeof(int64_t) << p.bits, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_kmer_count_deferred: memset failed");
+            return PG_OK;
+        }
+    }
+    if (word_end == word_begin) return PG_OK;
     char *ws = (char *)workspace;
     auto *hist = (unsigned long long *)(ws + p.hist_off);
     auto *off = (unsigned long long *)(ws + p.off_off);
@@ -1321,11 +1479,19 @@ extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *val
                            p.bits2, (const unsigned long long *)nullptr, tiles_x, bufb, (const unsigned long long *)off, cur2, 0, 0,
                            p.bits2, 64 - p.bits);
     }
+    if (deferred_group >= 0) {
+        // B, deferred: groups of final buckets counted in LDS, occupied entries + fills only (bufa is free after A2)
+        if ((rc = raise_lds_limit((const void *)bucket_count_compact_kernel, slice_lds, "pg_kmer_count_deferred"))) return rc;
+        hipLaunchKernelGGL(bucket_count_compact_kernel, dim3((unsigned)(nb >> deferred_group)), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)bufb,
+                           (const unsigned long long *)off, view_of(t), deferred_group, bufa, (long long *)fill, status);
+        return check_launch("pg_kmer_count_deferred");
+    }
     // B: count every bucket inside LDS and write its slice of the table
     hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)(p.bits2 ? bufb : bufa),
                        (const unsigned long long *)off, view_of(t), accumulate ? 1 : 0, status);
     return check_launch("pg_kmer_count_bucketed");
 }
+}  // namespace
 
 extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t, uint32_t *status, void *stream)
 {

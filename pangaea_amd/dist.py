@@ -130,9 +130,65 @@ def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
     return [o[:s].to(home) for o, s in zip(out, sizes)]
 
 
+def deferred_group_for(table: KmerTable, local_distinct: int) -> int | None:
+    """g for ``table.count(deferred_group=g)``: how many times sparser this rank's keys are than the union the table is
+    sized for (as a power of two), or None where the deferred form does not apply"""
+    if not (table.kind == "hash" and table._bucketed() and table.log2_slots - table.log2_bucket > 8):
+        return None
+    local_log2 = max(1, (int(local_distinct / 0.45) - 1).bit_length())        # slots this rank alone would need
+    return max(0, table.log2_slots - local_log2)
+
+
+def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_log2_slots: int = 36) -> KmerTable:
+    """the global table of all ranks' streams, on every rank: the distributed form of ``kmer.count_kmers``.
+
+    The ranks' HyperLogLog sketches are combined with an all-reduce(MAX) -- the sketch of the union -- so every rank
+    allocates the same table, sized for the union; hash tables are then counted in deferred form where that applies
+    (the rank's own sparse table is never written), exchanged once and rebuilt.  A full table (every rank sees the same
+    status after the rebuild) is re-done with four times the slots on all ranks."""
+    from . import _lib, kmer
+    kind = KmerTable.default_kind(k)
+    if kind == "dense":
+        return exchange_table(KmerTable.alloc(k, stream.device, kind).count(stream), group)
+    regs = kmer.distinct_sketch(stream, k)
+    local = kmer.sketch_estimate(regs)
+    union = _staged(regs.clone(), group)
+    dist.all_reduce(union, op=dist.ReduceOp.MAX, group=group)
+    total = max(1 << 13, int(1.05 * kmer.sketch_estimate(union)))
+    table = KmerTable.alloc(k, stream.device, kind, total, load=0.6)      # measured: fewer, fuller buckets beat a sparser table
+    def any_full() -> bool:
+        # the same answer on every rank, so that all regrow together (a group table in LDS can be full on one rank only);
+        # nothing between two collectives may raise on one rank alone
+        flag = (table.status[:1] != 0).to(torch.int32)
+        flag = _staged(flag, group)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        return int(flag.item()) != 0
+
+    while True:
+        g = deferred_group_for(table, int(1.1 * local)) if kind == "hash" else None
+        if g is not None and table.can_defer(stream.n_words):
+            table.count(stream, rows=rows, deferred_group=g, check=False)
+        else:
+            table.count(stream, rows=rows, check=False)
+        full = any_full()
+        if not full:
+            exchange_table(table, group, check=False)
+            full = any_full()
+        if not full:
+            return table
+        if table.log2_slots >= max_log2_slots:
+            raise _lib.PangaeaError(_lib.PG_ETABLEFULL, f"hash table with 2^{table.log2_slots} slots is full")
+        log2 = min(max_log2_slots, table.log2_slots + 2)
+        wide = table.kind == "wide"
+        del table
+        table = KmerTable.wide_with_slots(k, stream.device, log2) if wide else KmerTable.with_slots(k, stream.device, log2)
+
+
 def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTable:
     """turn per-rank partial tables into the global table on every rank (the path's only collective)"""
     if not is_distributed():
+        if table.pending:
+            raise RuntimeError("a deferred count needs a process group to exchange with")
         return table
     if table.kind == "dense":
         data = _staged(table.data, group)
@@ -166,7 +222,9 @@ def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTabl
         # (padded to the longest part; the padding is never read).  The table is
         # then rebuilt bucket by bucket inside LDS from all parts, the own one included -- the sparse slices are read
         # once (to compact) and written once (the merged image), and nothing is concatenated or scanned by torch.
-        fill = table.bucket_fill()
+        # (a deferred count -- KmerTable.count(deferred_group=g) -- has produced fills and entries already and never
+        # wrote its sparse table: the compaction is then a gather out of the count's workspace)
+        fill = table.deferred_fill() if table.pending else table.bucket_fill()
         nb = table.n_buckets
         fills = torch.empty((world, nb), dtype=torch.int64, device=fill.device)
         _all_gather_flat(fills.view(-1), fill, me, group)
@@ -176,7 +234,7 @@ def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTabl
         seg[:, 1:] = ends
         buf = torch.empty(world * cap, dtype=torch.int64, device=fill.device)
         mine = torch.empty(cap, dtype=torch.int64, device=fill.device)
-        table.compact_into(mine, seg[me].contiguous())
+        (table.deferred_compact_into if table.pending else table.compact_into)(mine, seg[me].contiguous())
         _all_gather_flat(buf, mine, me, group)
         seg += torch.arange(world, device=fill.device, dtype=torch.int64)[:, None] * cap
         table.rebuild_from(buf, seg, check=False)

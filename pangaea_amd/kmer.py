@@ -50,6 +50,7 @@ class KmerTable:
         self._workspace = None
         self._shuffle_ws = None
         self._records = None             # (plan, n_words) while the workspace holds the row-tagged records of ONE count
+        self._deferred = None            # (fill, n_words) after a deferred count: entries wait in the workspace, slots unwritten
 
     # ------------------------------------------------------------------ construction
 
@@ -147,6 +148,7 @@ class KmerTable:
         self.status.zero_()
         self._empty = True
         self._records = None
+        self._deferred = None
         return self
 
     def _workspace_for(self, n_words: int) -> torch.Tensor:
@@ -156,16 +158,44 @@ class KmerTable:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
 
+    def can_defer(self, n_words: int) -> bool:
+        """may ``count(..., deferred_group=g)`` be used for a fresh count of ``n_words`` words?"""
+        step = int(self.WORKSPACE_BUDGET // (2 * 8 * 32))
+        return self._bucketed() and self._empty and self.log2_slots - self.log2_bucket > 8 and n_words <= step
+
     def count(self, stream: ReadStream, word_begin: int = 0, word_end: int | None = None, check: bool = True,
-              rows: "Plan | None" = None) -> "KmerTable":
+              rows: "Plan | None" = None, deferred_group: int | None = None) -> "KmerTable":
         """add the k-mers ending in words [word_begin, word_end) of the stream (asynchronous unless ``check``).
         With ``rows`` (a Plan of this stream's rows) a bucketed table also keeps the row-tagged partition records, which
-        lets ``features`` build the abundance rows by shuffle instead of by table lookups."""
+        lets ``features`` build the abundance rows by shuffle instead of by table lookups.
+
+        ``deferred_group`` = g (multi-GPU, ``can_defer``): this table has the geometry of the union over all ranks and
+        is NOT written; 2^g adjacent buckets are counted together in LDS and only their occupied entries and the
+        per-bucket fills are kept, for ``dist.exchange_table`` to gather and to rebuild the table from.  Until then the
+        table holds no counts (``pending``)."""
         _require_gpu(stream.codes, "the read stream")
         if stream.device != self.device:
             raise ValueError("stream and table are on different devices")
         word_end = stream.n_words if word_end is None else word_end
         L = _lib.load()
+        if deferred_group is not None:
+            if not self.can_defer(word_end - word_begin):
+                raise ValueError("deferred counting needs a fresh bucketed table with more than 256 buckets and a single pass")
+            g = max(0, min(int(deferred_group), _lib.DEFERRED_MAX_GROUP_LOG2, self.log2_slots - self.log2_bucket - 8))
+            keep = rows if (rows is not None and rows.shuffle_ok) else None
+            ws = self._workspace_for(word_end - word_begin)
+            fill = torch.empty(self.n_buckets, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.pg_kmer_count_deferred(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end, self.desc(), g,
+                                                    C.byref(keep.rows_desc) if keep is not None else None, ws.data_ptr(), ws.numel(),
+                                                    fill.data_ptr(), self.status.data_ptr(), _stream_ptr(self.device)))
+            self._empty = False
+            self._deferred = (fill, word_end - word_begin)
+            self._records = (keep, word_end - word_begin) if keep is not None else None
+            if check:
+                self.check_status()
+            return self
+        self._deferred = None
         with torch.cuda.device(self.device):
             if self.kind == "hash" and self.log2_bucket:
                 # pieces bounded by the scratch budget: two record buffers of 8 B per character
@@ -216,6 +246,7 @@ class KmerTable:
 
     def merge(self, pairs: torch.Tensor, check: bool = True) -> "KmerTable":
         """add (code << 22 | count) pairs, e.g. the compacted table of another GPU"""
+        self._require_counts()
         if self.kind != "hash":
             raise ValueError("merge() is for hash tables; dense tables are summed with all_reduce")
         pairs = pairs.to(self.device, torch.int64).contiguous()
@@ -235,6 +266,7 @@ class KmerTable:
 
     def bucket_counts(self) -> torch.Tensor:
         """occupied slots per bucket, int64 [n_buckets] -- the segment lengths of ``compact()`` (slot order = bucket order)"""
+        self._require_counts()
         if self.kind != "hash":
             raise ValueError("bucket_counts() is for hash tables")
         return (self.data.view(self.n_buckets, -1) != 0).sum(dim=1)
@@ -242,6 +274,7 @@ class KmerTable:
     def merge_parts(self, parts, check: bool = True) -> "KmerTable":
         """add other tables of the SAME geometry, each given as (compact(), bucket_counts()); bucket by bucket inside
         LDS when the buckets are LDS-sized, else with global atomics"""
+        self._require_counts()
         parts = [(p.to(self.device, torch.int64), c.to(self.device, torch.int64)) for p, c in parts if p.numel()]
         if not parts:
             return self
@@ -274,6 +307,7 @@ class KmerTable:
 
     def bucket_fill(self) -> torch.Tensor:
         """``bucket_counts()`` by one kernel pass over the table (int64 [n_buckets], on the device)"""
+        self._require_counts()
         if not self._bucketed():
             raise ValueError("bucket_fill() is for bucketed hash tables")
         if self._empty:
@@ -287,12 +321,34 @@ class KmerTable:
     def compact_into(self, out: torch.Tensor, seg: torch.Tensor) -> None:
         """occupied slots, bucket after bucket, into ``out`` at the offsets ``seg`` (int64 [n_buckets + 1], the exclusive
         scan of ``bucket_fill()``); order inside a bucket is unspecified"""
+        self._require_counts()
         if not self._bucketed():
             raise ValueError("compact_into() is for bucketed hash tables")
         _require_gpu(out, "the output")
         assert out.dtype == torch.int64 and out.is_contiguous() and seg.dtype == torch.int64 and seg.numel() == self.n_buckets + 1
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().pg_table_compact(self.desc(), seg.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
+
+    def _require_counts(self) -> None:
+        if self._deferred is not None:
+            raise RuntimeError("this table was counted in deferred form and holds no counts until dist.exchange_table / rebuild_from")
+
+    @property
+    def pending(self) -> bool:
+        """counted in deferred form: the slots hold nothing until ``rebuild_from`` (``dist.exchange_table``)"""
+        return self._deferred is not None
+
+    def deferred_fill(self) -> torch.Tensor:
+        return self._deferred[0]
+
+    def deferred_compact_into(self, out: torch.Tensor, seg: torch.Tensor) -> None:
+        """the deferred count's entries, bucket after bucket, into ``out`` at the offsets ``seg`` (as ``compact_into``)"""
+        fill, n_words = self._deferred
+        _require_gpu(out, "the output")
+        assert out.dtype == torch.int64 and out.is_contiguous() and seg.dtype == torch.int64 and seg.numel() == self.n_buckets + 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_deferred_gather(self.desc(), self._workspace.data_ptr(), self._workspace.numel(), n_words,
+                                                      fill.data_ptr(), seg.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
 
     def rebuild_from(self, pairs: torch.Tensor, seg: torch.Tensor, check: bool = True) -> "KmerTable":
         """replace the table by the merge of ``seg.shape[0]`` bucket-ordered compacted tables of this geometry laid out in
@@ -302,6 +358,7 @@ class KmerTable:
         _require_gpu(pairs, "the pairs")
         assert pairs.dtype == torch.int64 and seg.dtype == torch.int64 and seg.is_contiguous() and seg.shape[1] == self.n_buckets + 1
         self._empty = False                 # (the row-tagged records of this rank's count stay valid: the geometry is the same)
+        self._deferred = None
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().pg_kmer_rebuild_bucketed(pairs.data_ptr(), seg.data_ptr(), int(seg.shape[0]), self.desc(),
                                                             self.status.data_ptr(), _stream_ptr(self.device)))
@@ -311,6 +368,7 @@ class KmerTable:
 
     def compact(self) -> torch.Tensor:
         """occupied slots of a hash table as an int64 vector (slot format)"""
+        self._require_counts()
         if self.kind != "hash":
             raise ValueError("compact() is for hash tables")
         step = 1 << 30                       # torch's masked select overflows its 32-bit indexing at 2^31 elements
@@ -319,6 +377,7 @@ class KmerTable:
         return torch.cat([c[c != 0] for c in self.data.split(step)])
 
     def occupancy(self) -> float:
+        self._require_counts()
         if self.kind == "wide":
             return float(torch.count_nonzero(self._wide_parts()[0]).item()) / (1 << self.log2_slots)
         if self.kind != "hash":
@@ -327,6 +386,7 @@ class KmerTable:
 
     def items(self):
         """(codes uint64, counts uint64) sorted by code -- host copies, for tests"""
+        self._require_counts()
         if self.kind == "dense":
             t = self.data.cpu().numpy().view(np.uint32)
             codes = np.nonzero(t)[0].astype(np.uint64)
@@ -344,8 +404,9 @@ class KmerTable:
         return codes[order], counts[order]
 
 
-def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None) -> int:
-    """HyperLogLog estimate (4096 registers, ~1.6 % standard error) of the number of distinct canonical k-mers"""
+def distinct_sketch(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None) -> torch.Tensor:
+    """HyperLogLog registers (int32 [4096], on the device) of the stream's canonical k-mers.  The elementwise maximum of
+    two sketches is the sketch of the union -- how the ranks of a multi-GPU job size their common table."""
     _require_gpu(stream.codes, "the read stream")
     dev = stream.device
     regs = torch.zeros(_lib.HLL_REGISTERS, dtype=torch.int32, device=dev)
@@ -353,6 +414,11 @@ def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end:
     with torch.cuda.device(dev):
         _lib.check(_lib.load().pg_kmer_distinct_sketch(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end, k,
                                                        regs.data_ptr(), _stream_ptr(dev)))
+    return regs
+
+
+def sketch_estimate(regs: torch.Tensor) -> int:
+    """cardinality estimate of a HyperLogLog sketch (~1.6 % standard error at 4096 registers)"""
     r = regs.cpu().numpy().astype(np.float64)
     m = float(len(r))
     est = (0.7213 / (1.0 + 1.079 / m)) * m * m / np.sum(np.exp2(-r))
@@ -360,6 +426,11 @@ def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end:
     if est <= 2.5 * m and zeros:
         est = m * math.log(m / zeros)                      # linear counting for small cardinalities
     return int(est)
+
+
+def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None) -> int:
+    """HyperLogLog estimate of the number of distinct canonical k-mers"""
+    return sketch_estimate(distinct_sketch(stream, k, word_begin, word_end))
 
 
 def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hint: int | None = None,
@@ -471,6 +542,7 @@ def features(stream: ReadStream, rows: Rows | Plan, k_tnf: int | None = 4, table
         tnf = out_tnf.zero_() if out_tnf is not None else torch.zeros((n, tnf_ncols(k_tnf)), dtype=torch.int32, device=dev)
     shuffle = table is not None and table.has_records_for(plan, vsize)
     if table is not None:
+        table._require_counts()
         if table.device != dev:
             raise ValueError("stream and table are on different devices")
         if shuffle:                 # every row is overwritten: no zero fill

@@ -300,6 +300,63 @@ def test_exchange_kernels_fill_compact_rebuild(log2_slots, log2_bucket):
     assert all(np.array_equal(x, y) for x, y in zip(out.items(), parts[0].items()))
 
 
+@pytest.mark.parametrize("log2_slots,log2_bucket,g", [(20, 10, 0), (20, 10, 1), (21, 9, 3), (22, 12, 2), (19, 10, 1)])
+def test_deferred_count_gather_rebuild_equals_direct_count(log2_slots, log2_bucket, g):
+    """multi-GPU counting form: the table (union geometry) is not written; groups of 2^g buckets are counted in LDS, the
+    entries are gathered bucket by bucket and the table is rebuilt from them -- same table as counting into it directly,
+    and the row-tagged records left behind still answer the abundance rows by shuffle"""
+    cfg = synth.SynthConfig(n_pairs=2500, n_barcodes=20, n_genomes=3, genome_len=20_000, fragment=8_000, n_rate=0.05, seed=47)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    want = kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket).count(s)
+    t = kmer.KmerTable.with_slots(21, DEV, log2_slots, log2_bucket)
+    t.data.fill_(0x7FFF_FFFF_FFFF)                               # the slots are neither read nor written until the rebuild
+    t._empty = True
+    assert t.can_defer(s.n_words)
+    t.count(s, rows=plan, deferred_group=g)
+    assert t.pending and int((t.data != 0x7FFF_FFFF_FFFF).sum()) == 0
+    with pytest.raises(RuntimeError, match="deferred"):
+        t.items()
+    with pytest.raises(RuntimeError, match="deferred"):
+        kmer.features(s, plan, k_tnf=None, table=t)
+    fill = t.deferred_fill()
+    assert torch.equal(fill, want.bucket_counts())
+    seg = torch.zeros((2, t.n_buckets + 1), dtype=torch.int64, device=DEV)
+    seg[:, 1:] = torch.cumsum(fill, 0)
+    cap = int(fill.sum()) + 3
+    buf = torch.full((2 * cap,), -1, dtype=torch.int64, device=DEV)
+    t.deferred_compact_into(buf[:cap], seg[0].contiguous())
+    assert torch.equal(torch.sort(buf[:cap - 3]).values, torch.sort(want.compact()).values)
+    # "two ranks" with the same shard: every count doubles
+    buf[cap:2 * cap - 3] = buf[:cap - 3]
+    seg[1] += cap
+    t.rebuild_from(buf, seg)
+    assert not t.pending
+    wc, wn = want.items()
+    gc, gn = t.items()
+    assert np.array_equal(gc, wc) and np.array_equal(gn, 2 * wn)
+    # K3 by shuffle from the records of the deferred count, against the rebuilt table
+    assert t.has_records_for(plan, 64)
+    _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=2, vsize=64)
+    _, abd2 = kmer.features(s, rows, k_tnf=None, table=t, window=2, vsize=64)
+    assert torch.equal(abd, abd2)
+    doubled = kmer.KmerTable.with_slots(21, DEV, log2_slots, 0).count(s).count(s)
+    _, abd3 = kmer.features(s, rows, k_tnf=None, table=doubled, window=2, vsize=64)
+    assert torch.equal(abd, abd3)
+
+
+def test_deferred_count_reports_a_full_group_table():
+    cfg = synth.SynthConfig(n_pairs=4000, n_barcodes=16, n_genomes=2, genome_len=300_000, fragment=60_000, seed=77)
+    s = synth.generate(cfg, device=DEV)
+    t = kmer.KmerTable.with_slots(21, DEV, 21, 9)              # fine as a table, but 8 buckets' keys do not fit one LDS table
+    t.count(s)
+    t.reset()
+    with pytest.raises(_lib.PangaeaError) as e:
+        t.count(s, deferred_group=3)
+    assert e.value.code == _lib.PG_ETABLEFULL
+
+
 def test_bucket_overflow_is_reported():
     cfg = synth.SynthConfig(n_pairs=4000, n_barcodes=16, n_genomes=2, genome_len=300_000, fragment=60_000, seed=77)
     s = synth.generate(cfg, device=DEV)
