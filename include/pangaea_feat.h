@@ -119,10 +119,12 @@ int pg_tnf_colmap(int k, uint16_t *colmap /* [4^k] host */, uint32_t *col_code /
  * of count_kmer.cpp:139-170.  Two table forms:
  *   PG_TABLE_DENSE  k <= 16: uint32_t counts[4^k], indexed by the canonical code.
  *   PG_TABLE_HASH   k <= 21: uint64_t slots[2^log2_slots], open addressing, linear probing;
- *                   slot = (canonical code << 22) | count, 0 = empty.  The count field stops
- *                   growing at PG_HASH_COUNT_SAT (2^21), far above any vector_size*window, so every
- *                   histogram bin is exact.  A key's home slot is the top log2_slots bits of
- *                   murmur3's 64-bit finaliser of its code.  With log2_bucket_slots = b > 0 the table
+ *                   slot = (key << 22) | count, 0 = empty, where key = pg_key42(canonical code) is a
+ *                   BIJECTION of the 42-bit codes onto themselves that mixes like a hash (below): a k-mer is
+ *                   hashed once and its key then serves as bucket id (top bits), slot index (the bits
+ *                   under them) and identity.  The count field stops growing at PG_HASH_COUNT_SAT (2^21),
+ *                   far above any vector_size*window, so every histogram bin is exact.  A key's home slot
+ *                   is its top log2_slots bits.  With log2_bucket_slots = b > 0 the table
  *                   is split into buckets of 2^b consecutive slots and probing wraps inside the
  *                   bucket (b = 0: one bucket = the whole table); pg_kmer_count_bucketed needs
  *                   b <= PG_BUCKET_MAX_LOG2_SLOTS so that one bucket fits in LDS.
@@ -137,6 +139,10 @@ enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3 };
 #define PG_DENSE_MAX_K 16
 #define PG_HASH_MAX_K 21
 #define PG_WIDE_MAX_K 31
+/* pg_key42: x ^= x >> 21; x = x * M1 mod 2^42; x ^= x >> 21; x = x * M2 mod 2^42; x ^= x >> 21  (every step invertible:
+ * the xorshifts are involutions on 42 bits, the multipliers are odd) */
+#define PG_KEY42_M1 0x3d7ed558ccdULL
+#define PG_KEY42_M2 0x1fe1a85ec53ULL
 #define PG_HASH_COUNT_BITS 22
 #define PG_HASH_COUNT_SAT (1u << 21)
 #define PG_BUCKET_MAX_LOG2_SLOTS 14   /* 2^14 slots x 8 B = 128 KiB of the CU's 160 KiB LDS */

@@ -24,6 +24,8 @@ WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
 SHUFFLE_MAX_VSIZE = 512
 DEFERRED_MAX_GROUP_LOG2 = 3
+KEY42_M1 = 0x3d7ed558ccd          # pg_key42 (include/pangaea_feat.h)
+KEY42_M2 = 0x1fe1a85ec53
 HLL_REGISTERS = 4096
 MAX_ROWS = (1 << 22) - 2
 

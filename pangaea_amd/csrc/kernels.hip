@@ -52,14 +52,31 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     return x;
 }
 
-// hash table as the kernels see it: 2^log2_slots slots in buckets of 2^log2_bucket slots; a key's home slot is the
-// top log2_slots bits of mix64(code), probing is linear and wraps inside the bucket.  Slots are never freed, so a
-// lookup may stop at the first empty slot.
+// Packed hash tables (k <= 21) do not store the canonical code but key42(code): a BIJECTION of the 42-bit codes onto
+// themselves with the avalanche of a hash (two xorshift-multiply rounds modulo 2^42; every step is invertible, the
+// inverse is in pangaea_amd/kmer.py).  A k-mer is hashed ONCE, where it leaves the read stream; from then on every
+// consumer takes its digit, bucket and slot straight from the bits of the key -- bucket = top bits, slot = the bits
+// below -- and the key alone identifies the k-mer, in partition records, in table slots and between ranks.
+constexpr int KEY_BITS = 42;
+constexpr uint64_t KEY_MASK = (1ull << KEY_BITS) - 1;
+static_assert(2 * PG_HASH_MAX_K == KEY_BITS, "the packed table keys cover exactly the codes of the largest k");
+__device__ __forceinline__ uint64_t key42(uint64_t x)
+{
+    x ^= x >> 21; x = (x * PG_KEY42_M1) & KEY_MASK;
+    x ^= x >> 21; x = (x * PG_KEY42_M2) & KEY_MASK;
+    x ^= x >> 21;
+    return x;
+}
+
+// hash table as the kernels see it: 2^log2_slots slots in buckets of 2^log2_bucket slots; a key's home slot is its top
+// log2_slots bits (packed form) / the top bits of mix64(code) (wide form), probing is linear and wraps inside the
+// bucket.  Slots are never freed, so a lookup may stop at the first empty slot.
 struct HashView {
     uint64_t *slots;
     int log2_slots;
     int log2_bucket;
-    __device__ __forceinline__ uint64_t home(uint64_t code) const { return mix64(code) >> (64 - log2_slots); }
+    __device__ __forceinline__ uint64_t home_wide(uint64_t code) const { return mix64(code) >> (64 - log2_slots); }
+    __device__ __forceinline__ uint64_t home_key(uint64_t key) const { return key >> (KEY_BITS - log2_slots); }
     __device__ __forceinline__ uint64_t next(uint64_t s) const
     {
         const uint64_t bm = (1ull << log2_bucket) - 1;
@@ -126,7 +143,7 @@ __device__ __forceinline__ Word load_word(const uint64_t *__restrict__ codes, co
 
 __device__ __forceinline__ void dense_add(uint32_t *table, uint32_t code) { atomicAdd(&table[code], 1u); }
 
-// slot = (code << 22) | count ; 0 = empty.  Keys never change once written, so a stale (cached)
+// slot = (key << 22) | count, key = key42(code) ; 0 = empty.  Keys never change once written, so a stale (cached)
 // read can only show "empty", and the compare-and-swap then returns the real occupant.
 __device__ __forceinline__ void hash_add_from(const HashView &t, uint64_t s, uint64_t cur, uint64_t code, uint32_t *status)
 {
@@ -168,7 +185,7 @@ __device__ __forceinline__ void wide_add(const HashView &t, uint64_t code, uint3
 {
     const uint32_t limit = t.limit();
     const uint64_t key1 = code + 1;
-    uint64_t s = t.home(code);
+    uint64_t s = t.home_wide(code);
     for (uint32_t i = 0; i < limit; ++i) {
         uint64_t cur = t.slots[s];
         if (cur == 0) {
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
             KT canon[8];
             uint64_t cur[8];
             uint64_t hh[8];
+            uint64_t kk[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = b * 8 + u;
@@ -231,7 +249,8 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
                     } else if (TK == TK_WIDE) {
                         wide_add(t, (uint64_t)canon[u], 1u, status);
                     } else {                       // issue the first probe of the whole batch before resolving any
-                        hh[u] = t.home((uint64_t)canon[u]);
+                        kk[u] = key42((uint64_t)canon[u]);
+                        hh[u] = t.home_key(kk[u]);
                         cur[u] = t.slots[hh[u]];
                     }
                 }
@@ -239,13 +258,13 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
             if (TK == TK_HASH) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if ((x.ok >> (b * 8 + u)) & 1) hash_add_from(t, hh[u], cur[u], (uint64_t)canon[u], status);
+                    if ((x.ok >> (b * 8 + u)) & 1) hash_add_from(t, hh[u], cur[u], kk[u], status);
             }
         }
     }
 }
 
-// merge (code,count) pairs of another table; counts saturate at SAT exactly (CAS loop; not a hot path)
+// merge (key,count) pairs of another table (slot format); counts saturate at SAT exactly (CAS loop; not a hot path)
 __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, HashView t, uint32_t *status)
 {
     const uint32_t limit = t.limit();
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__res
         const uint64_t code = p >> HASH_CBITS;
         uint32_t add = (uint32_t)(p & HASH_CMASK);
         if (add > HASH_SAT) add = HASH_SAT;
-        uint64_t s = t.home(code);
+        uint64_t s = t.home_key(code);
         bool done = false;
         for (uint32_t tries = 0; tries < limit && !done; ++tries) {
             uint64_t cur = __hip_atomic_load(&t.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -351,7 +370,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_hist_kernel(const uint64_t *
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *coarse = lds + n_bins;                                // [256]
     for (int i = threadIdx.x; i < n_bins; i += BIG_BLOCK) lds[i] = 0;
-    const int sh = 64 - bits, sh1 = 64 - bits1;
+    const int sh = KEY_BITS - bits, sh1 = KEY_BITS - bits1;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         if (threadIdx.x < 256) coarse[threadIdx.x] = 0;
         __syncthreads();
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_hist_kernel(const uint64_t *
             for (int j = 0; j < 32; ++j) {
                 r.push((uint32_t)(x.cw >> (2 * j)) & 3u);
                 if ((x.ok >> j) & 1) {
-                    const uint64_t h = mix64(r.canon());
+                    const uint64_t h = key42(r.canon());
                     const uint32_t bin = (uint32_t)(h >> sh) - bin_base;
                     if (bin < (uint32_t)n_bins) atomicAdd(&lds[bin], 1u);
                     if (chunk_hist) atomicAdd(&coarse[h >> sh1], 1u);
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
     __shared__ uint64_t buf[A1_TILE];
     __shared__ StreamLds L;
     const int n_dig = 1 << bits1;
-    const int dsh = 64 - bits1;
+    const int dsh = KEY_BITS - bits1;
     const int64_t n_tiles = (word_end - word_begin + A1_TILE_WORDS - 1) / A1_TILE_WORDS;
     const int half = threadIdx.x & 1;                               // which 16 characters of the word
     const int64_t chunk = blockIdx.x;
@@ -530,9 +549,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
                             re = r < n_rows ? row_end[r] : INT64_MAX;
                         }
                         const uint64_t row = pos >= rs ? (uint64_t)r : (uint64_t)ROW_NONE;
-                        const uint64_t code = rl.canon();
-                        const uint32_t d = (uint32_t)(mix64(code) >> dsh);
-                        rec[j] = code | (row << REC_KEY_BITS);
+                        const uint64_t key = key42(rl.canon());
+                        const uint32_t d = (uint32_t)(key >> dsh);
+                        rec[j] = key | (row << REC_KEY_BITS);
                         dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
                     }
                 }
@@ -565,7 +584,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
         const uint32_t total = L.start[BLOCK];
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {
             const uint64_t r = buf[i];
-            const uint32_t d = (uint32_t)(mix64(r & REC_KEY_MASK) >> dsh);
+            const uint32_t d = (uint32_t)((r & REC_KEY_MASK) >> dsh);
             rec_out[L.gbase[d] + (i - L.start[d])] = r;
         }
         __syncthreads();
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
 
 // Generic record scatter pass (A2, S2a, S2b).  Region = blockIdx.x / tiles_x; its input records are
 //   [in_begin[region << in_shift], in_cnt ? begin + in_cnt[region] : in_end[region << in_shift]).
-// Digit: DIG_HASH -> (mix64(key) >> dshift) & mask;  DIG_ROW -> (word >> dshift) & mask of a 32-bit (row, bin) word.
+// Digit: DIG_HASH -> (key >> dshift) & mask of a (key, row) record;  DIG_ROW -> (word >> dshift) & mask of a 32-bit (row, bin) word.
 // Destination of digit d: out[obase[(base + d) << oshift] + cursor[base + d] ...], base = flat ? 0 : region << dbits.
 enum { DIG_HASH = 0, DIG_ROW = 1 };
 template <typename REC, int DIG, int REC_PER_LANE>
@@ -597,7 +616,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
     const int64_t r1 = in_cnt ? r0 + (int64_t)in_cnt[region] : (int64_t)in_end[region << in_shift];
     const int64_t n_tiles = (r1 - r0 + TILE1 - 1) / TILE1;
     auto digit_of = [&](REC r) -> uint32_t {
-        if (DIG == DIG_HASH) return (uint32_t)(mix64((uint64_t)r & REC_KEY_MASK) >> dshift) & dmask;
+        if (DIG == DIG_HASH) return (uint32_t)(((uint64_t)r & REC_KEY_MASK) >> dshift) & dmask;
         return ((uint32_t)r >> dshift) & dmask;
     };
     for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
@@ -672,7 +691,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = t.limit();
-    const int hsh = 64 - t.log2_slots;
+    const int hsh = KEY_BITS - t.log2_slots;
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
     if (r0 == r1 && accumulate) return;                         // nothing to add, slice stays as it is
@@ -711,7 +730,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
         unsigned long long first[CNT_BATCH];
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
-            ss[j] = (uint32_t)(mix64(rr[j]) >> hsh) & smask;
+            ss[j] = (uint32_t)(rr[j] >> hsh) & smask;
             first[j] = live[j] ? tab[ss[j]] : 0ull;
         }
         // resolved one by one, written out by hand: an unrolled loop around the probe loop is not unrolled by hipcc and
@@ -740,8 +759,8 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact_kernel(const u
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = t.limit();
-    const int hsh = 64 - (t.log2_slots - g);                        // slot inside the group's table
-    const int bsh = 64 - (t.log2_slots - t.log2_bucket);            // final bucket id
+    const int hsh = KEY_BITS - (t.log2_slots - g);                  // slot inside the group's table
+    const int bsh = KEY_BITS - (t.log2_slots - t.log2_bucket);      // final bucket id
     const uint32_t qmask = (1u << g) - 1u;
     const int64_t b0 = (int64_t)blockIdx.x << g;
     const int64_t r0 = (int64_t)off[b0], r1 = (int64_t)off[b0 + (1 << g)];
@@ -769,7 +788,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact_kernel(const u
         unsigned long long first[CNT_BATCH];
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
-            ss[j] = (uint32_t)(mix64(rr[j]) >> hsh) & smask;
+            ss[j] = (uint32_t)(rr[j] >> hsh) & smask;
             first[j] = live[j] ? tab[ss[j]] : 0ull;
         }
 #define PG_RESOLVE(J) full |= !lds_insert(tab, smask, limit, rr[J], live[J], ss[J], first[J]);
@@ -781,7 +800,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact_kernel(const u
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
         const unsigned long long v = tab[i];
         if (v) {
-            const uint32_t q = (uint32_t)(mix64(v >> HASH_CBITS) >> bsh) & qmask;
+            const uint32_t q = (uint32_t)((v >> HASH_CBITS) >> bsh) & qmask;
             scratch[off[b0 + q] + atomicAdd(&qcnt[q], 1u)] = v;
         }
     }
@@ -835,7 +854,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t 
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = t.limit();
-    const int hsh = 64 - t.log2_slots;
+    const int hsh = KEY_BITS - t.log2_slots;
     const int64_t n_buckets = (int64_t)1 << (t.log2_slots - t.log2_bucket);
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     int64_t total = 0;
@@ -857,7 +876,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t 
             unsigned long long first[MERGE_BATCH];
 #pragma unroll
             for (int j = 0; j < MERGE_BATCH; ++j) {
-                ss[j] = (uint32_t)(mix64(e[j] >> HASH_CBITS) >> hsh) & smask;
+                ss[j] = (uint32_t)((e[j] >> HASH_CBITS) >> hsh) & smask;
                 first[j] = e[j] ? tab[ss[j]] : 0ull;
             }
 #define PG_MERGE(J)                                                                                                         \
@@ -951,7 +970,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup_kernel(const uint64_t
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = t.limit();
-    const int hsh = 64 - t.log2_slots;
+    const int hsh = KEY_BITS - t.log2_slots;
     const uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
     if (threadIdx.x == 0) emitted = 0;
@@ -979,7 +998,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup_kernel(const uint64_t
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
             live[j] = live[j] && (uint32_t)(rr[j] >> REC_KEY_BITS) != ROW_NONE;
-            ss[j] = (uint32_t)(mix64(rr[j] & REC_KEY_MASK) >> hsh) & smask;
+            ss[j] = (uint32_t)((rr[j] & REC_KEY_MASK) >> hsh) & smask;
             first[j] = live[j] ? tab[ss[j]] : 0ull;
         }
 #define PG_EMIT(J)                                                                                                          \
@@ -1102,6 +1121,7 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
             KT canon[8];
             uint64_t cur[8];
             uint64_t hh[8];
+            uint64_t key8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = b * 8 + u;
@@ -1114,7 +1134,8 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                         if (TK == TK_DENSE) {
                             cur[u] = dense[(uint32_t)canon[u]];
                         } else {
-                            hh[u] = t.home((uint64_t)canon[u]);
+                            key8[u] = TK == TK_WIDE ? (uint64_t)canon[u] : key42((uint64_t)canon[u]);
+                            hh[u] = TK == TK_WIDE ? t.home_wide(key8[u]) : t.home_key(key8[u]);
                             // each table line is used once per launch: keep it out of the way of the stream (measured -2 %)
                             cur[u] = __builtin_nontemporal_load(&t.slots[hh[u]]);
                         }
@@ -1132,9 +1153,9 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                             cnt = (uint32_t)cur[u];
                             found = cnt != 0;       // absent from the table <=> never counted
                         } else if (TK == TK_WIDE) {
-                            cnt = wide_probe(t, hh[u], cur[u], (uint64_t)canon[u], &found);
+                            cnt = wide_probe(t, hh[u], cur[u], key8[u], &found);
                         } else {
-                            cnt = hash_probe(t, hh[u], cur[u], (uint64_t)canon[u], &found);
+                            cnt = hash_probe(t, hh[u], cur[u], key8[u], &found);
                         }
                         if (found) {
                             uint32_t bin = cnt / window;
@@ -1477,7 +1498,7 @@ int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t wo
         hipLaunchKernelGGL((scatter_records_kernel<uint64_t, DIG_HASH, RPL64>), dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s,
                            (const uint64_t *)bufa, (const unsigned long long *)off, (const unsigned long long *)(off + ((size_t)1 << p.bits2)),
                            p.bits2, (const unsigned long long *)nullptr, tiles_x, bufb, (const unsigned long long *)off, cur2, 0, 0,
-                           p.bits2, 64 - p.bits);
+                           p.bits2, KEY_BITS - p.bits);
     }
     if (deferred_group >= 0) {
         // B, deferred: groups of final buckets counted in LDS, occupied entries + fills only (bufa is free after A2)

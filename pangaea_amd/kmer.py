@@ -32,7 +32,7 @@ class KmerTable:
     """exact multiplicity of every canonical k-mer over every read of the input.
 
     ``dense``: int32 tensor of 4^k counters (k <= 16).  ``hash``: int64 tensor of 2^log2_slots slots,
-    slot = (code << 22) | count, 0 = empty (k <= 21), optionally split into buckets of 2^log2_bucket slots
+    slot = (key42(code) << 22) | count, 0 = empty (k <= 21), optionally split into buckets of 2^log2_bucket slots
     (probing wraps inside a bucket); bucketed tables are built by the partition + LDS-count pipeline
     (``pg_kmer_count_bucketed``), unbucketed ones by one global atomic per occurrence (``pg_kmer_count``).
     ``wide`` (22 <= k <= 31, the rest of the reference's range): 2^log2_slots int64 keys (code + 1) followed by as
@@ -125,7 +125,8 @@ class KmerTable:
             table.data[codes.to(table.device)] = counts.to(table.device, torch.int32)
         else:
             sat = torch.clamp(counts, max=_lib.HASH_COUNT_SAT)
-            table.merge(((codes << _lib.HASH_COUNT_BITS) | sat)[sat > 0])
+            keys = torch.from_numpy(key42(codes.numpy().view(np.uint64)).view(np.int64))
+            table.merge(((keys << _lib.HASH_COUNT_BITS) | sat)[sat > 0])
         return table
 
     @property
@@ -245,7 +246,7 @@ class KmerTable:
             raise _lib.PangaeaError(_lib.PG_ETABLEFULL, f"hash table with 2^{self.log2_slots} slots is full")
 
     def merge(self, pairs: torch.Tensor, check: bool = True) -> "KmerTable":
-        """add (code << 22 | count) pairs, e.g. the compacted table of another GPU"""
+        """add (key << 22 | count) pairs (slot format, key = key42(code)), e.g. the compacted table of another GPU"""
         self._require_counts()
         if self.kind != "hash":
             raise ValueError("merge() is for hash tables; dense tables are summed with all_reduce")
@@ -399,9 +400,32 @@ class KmerTable:
             order = np.argsort(codes)
             return codes[order], counts[order]
         s = self.compact().cpu().numpy().view(np.uint64)
-        codes, counts = s >> np.uint64(_lib.HASH_COUNT_BITS), s & np.uint64((1 << _lib.HASH_COUNT_BITS) - 1)
+        codes, counts = key42_inverse(s >> np.uint64(_lib.HASH_COUNT_BITS)), s & np.uint64((1 << _lib.HASH_COUNT_BITS) - 1)
         order = np.argsort(codes)
         return codes[order], counts[order]
+
+
+_KEY_MASK = np.uint64((1 << 42) - 1)
+
+
+def key42(codes: np.ndarray) -> np.ndarray:
+    """the slot key of canonical codes (uint64 < 2^42): the library's pg_key42, a bijection on 42 bits"""
+    x = np.asarray(codes, dtype=np.uint64).copy()
+    for m in (_lib.KEY42_M1, _lib.KEY42_M2):
+        x ^= x >> np.uint64(21)
+        x = (x * np.uint64(m)) & _KEY_MASK
+    x ^= x >> np.uint64(21)
+    return x
+
+
+def key42_inverse(keys: np.ndarray) -> np.ndarray:
+    """canonical codes of slot keys: the xorshifts are involutions on 42 bits, the odd multipliers have inverses mod 2^42"""
+    x = np.asarray(keys, dtype=np.uint64).copy()
+    for m in (_lib.KEY42_M2, _lib.KEY42_M1):
+        x ^= x >> np.uint64(21)
+        x = (x * np.uint64(pow(m, -1, 1 << 42))) & _KEY_MASK
+    x ^= x >> np.uint64(21)
+    return x
 
 
 def distinct_sketch(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None) -> torch.Tensor:
