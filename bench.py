@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--barcodes", type=int, default=0, help="barcodes per GPU (default pairs/200)")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="pairs in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-dist", type=int, default=0, metavar="N",
+                    help="one GPU: run the N-rank code path (deferred count, exchange over a one-rank RCCL group, table sized for N shards) -- not a result")
     ap.add_argument("--no-defer", action="store_true", help="N > 1: write every rank's own table and compact it (instead of the deferred count)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     return ap.parse_args()
@@ -116,6 +118,11 @@ def main():
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    multi = world > 1 or args.rehearse_dist > 1
+    if args.rehearse_dist > 1 and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29599")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -137,14 +144,19 @@ def main():
     # sketch of the union, so every rank allocates the same table (geometry of the union) at load <= 0.6
     regs = kmer.distinct_sketch(stream, K_ABD)
     local_distinct = kmer.sketch_estimate(regs)
-    if world > 1:
+    if multi:
         union = regs if args.backend == "nccl" else regs.cpu()
         dist.all_reduce(union, op=dist.ReduceOp.MAX)
         regs = union
+    for r in range(1, args.rehearse_dist if world == 1 else 0):           # rehearsal: the sketches of the other shards
+        other = synth.generate(synth.SynthConfig(n_pairs=args.pairs, n_barcodes=n_bc, read_len=READ_LEN, seed=2022, first_pair=r * args.pairs),
+                               device=dev, chunk_pairs=1 << 17, with_names=False)
+        regs = torch.maximum(regs, kmer.distinct_sketch(other, K_ABD).to(regs.device))
+        del other
     table = kmer.KmerTable.alloc(K_ABD, dev, "hash", distinct_hint=max(1 << 14, int(1.05 * kmer.sketch_estimate(regs))), load=0.6)
     # N > 1: a rank's own keys are 2^g times sparser than the union and are counted in deferred form (entries + fills for
     # the exchange; the rank's own sparse table is never written)
-    defer = pdist.deferred_group_for(table, int(1.1 * local_distinct)) if world > 1 and not args.no_defer else None
+    defer = pdist.deferred_group_for(table, int(1.1 * local_distinct)) if multi and not args.no_defer else None
     tnf = torch.zeros((len(rows), kmer.tnf_ncols(K_TNF)), dtype=torch.int32, device=dev)
     abd = torch.zeros((len(rows), VSIZE), dtype=torch.int32, device=dev)
     torch.manual_seed(2021)
@@ -152,7 +164,7 @@ def main():
     vae.network.eval()
     names = np.array(rows.names, dtype=object)
 
-    ev = {k: [] for k in (("kmer_count", "exchange", "features") if world > 1 else ("kmer_count", "features"))}
+    ev = {k: [] for k in (("kmer_count", "exchange", "features") if multi else ("kmer_count", "features"))}
 
     def step(timed: bool):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -161,7 +173,10 @@ def main():
 
         table.count(stream, check=False, rows=plan, deferred_group=defer if defer is not None and table.can_defer(stream.n_words) else None)
         e[1].record()
-        pdist.exchange_table(table, check=False)
+        if world > 1:
+            pdist.exchange_table(table, check=False)
+        elif multi:
+            pdist._exchange_bucketed(table)         # rehearsal: the same launches and collectives in a one-rank group
         e[2].record()
         kmer.features(stream, plan, k_tnf=K_TNF, table=table, window=WINDOW, vsize=VSIZE, out_tnf=tnf, out_abd=abd)
         e[3].record()
@@ -170,7 +185,7 @@ def main():
         if timed:
             ev["kmer_count"].append((e[0], e[1]))
             ev["features"].append((e[2], e[3]))
-            if world > 1:
+            if multi:
                 ev["exchange"].append((e[1], e[2]))
         return mu
 
@@ -224,7 +239,8 @@ def main():
             "config": {"workload": f"synthetic {args.pairs} x 150 bp read pairs and {n_bc} barcodes per GPU, k=21 hash table "
                                    f"(2^{table.log2_slots} slots), TNF k=4 + abundance V=400 W=10, L1-normalise, VAE 536-512-512-32 encode",
                        "pairs_per_gpu": args.pairs, "barcodes_per_gpu": n_bc, "rows_per_gpu": len(rows),
-                       "parallelism": f"run-sharded x{world}, bucket-ordered table compaction, one all-gather, LDS rebuild ({args.backend})" if world > 1 else "single GPU",
+                       "parallelism": (f"run-sharded x{world}, deferred count, range-wise table all-gather overlapped with LDS rebuilds ({args.backend})" if world > 1
+                                       else f"REHEARSAL of the {args.rehearse_dist}-rank path on one GPU (one-rank RCCL group)" if multi else "single GPU"),
                        "input": "packed reads resident in HBM", "table_load": table_load,
                        "table_buckets": table.n_buckets, "bucket_slots": 1 << table.log2_bucket if table.log2_bucket else None},
             "kernel_ms": kern_ms,
@@ -241,6 +257,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if multi:
         dist.destroy_process_group()
 
 

@@ -227,6 +227,11 @@ int pg_deferred_gather(const pg_table *t, const void *count_workspace, int64_t c
 int pg_table_compact(const pg_table *t, const int64_t *seg, uint64_t *out, void *stream);
 int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
                              uint32_t *status, void *stream);
+/* the same for buckets [bucket_begin, bucket_end) only -- seg then has (bucket_end - bucket_begin + 1) entries per part,
+ * entry j for bucket bucket_begin + j -- so that the rebuild of one range can run while the all-gather of the next is
+ * still in flight */
+int pg_kmer_rebuild_bucketed_range(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
+                                   int64_t bucket_begin, int64_t bucket_end, uint32_t *status, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Per-run feature rows (device).  One launch fills both matrices.

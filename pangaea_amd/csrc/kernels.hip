@@ -847,16 +847,19 @@ __device__ __forceinline__ bool lds_merge(unsigned long long *tab, uint32_t smas
 }
 
 constexpr int MERGE_BATCH = 4;
+// The launch covers buckets [bucket_base, bucket_base + gridDim.x); seg has n_seg + 1 entries per part, entry j for
+// bucket bucket_base + j (a whole-table launch: base 0, n_seg = number of buckets).
 __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
-                                                                 int n_parts, HashView t, uint32_t *status, int rebuild)
+                                                                 int n_parts, HashView t, uint32_t *status, int rebuild,
+                                                                 int64_t bucket_base, int64_t n_seg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = t.limit();
     const int hsh = KEY_BITS - t.log2_slots;
-    const int64_t n_buckets = (int64_t)1 << (t.log2_slots - t.log2_bucket);
-    uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const int64_t n_buckets = n_seg;                                // row stride of seg is n_seg + 1
+    uint64_t *slice = t.slots + ((uint64_t)(bucket_base + blockIdx.x) << t.log2_bucket);
     int64_t total = 0;
     for (int p = 0; p < n_parts; ++p) total += seg[p * (n_buckets + 1) + blockIdx.x + 1] - seg[p * (n_buckets + 1) + blockIdx.x];
     if (total == 0 && !rebuild) return;
@@ -1549,11 +1552,12 @@ extern "C" int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg,
     const size_t lds = (size_t)8 << t->log2_bucket_slots;
     if ((rc = raise_lds_limit((const void *)bucket_merge_kernel, lds, "pg_kmer_merge_bucketed"))) return rc;
     hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
-                       n_parts, view_of(t), status, 0);
+                       n_parts, view_of(t), status, 0, (int64_t)0, (int64_t)1 << bits);
     return check_launch("pg_kmer_merge_bucketed");
 }
 
-extern "C" int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t, uint32_t *status, void *stream)
+extern "C" int pg_kmer_rebuild_bucketed_range(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
+                                              int64_t bucket_begin, int64_t bucket_end, uint32_t *status, void *stream)
 {
     int rc = check_table(t);
     if (rc) return rc;
@@ -1562,11 +1566,21 @@ extern "C" int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *se
     if (n_parts < 1 || !pairs || !seg || !status) return pg_fail(PG_EINVAL, "pg_kmer_rebuild_bucketed: bad arguments");
     const int bits = t->log2_slots - t->log2_bucket_slots;
     if (bits < 0 || bits > 30) return pg_fail(PG_EINVAL, "pg_kmer_rebuild_bucketed: bad bucket geometry");
+    if (bucket_begin < 0 || bucket_end < bucket_begin || bucket_end > ((int64_t)1 << bits))
+        return pg_fail(PG_EINVAL, "pg_kmer_rebuild_bucketed: bucket range [%lld,%lld) outside the table", (long long)bucket_begin, (long long)bucket_end);
+    if (bucket_end == bucket_begin) return PG_OK;
     const size_t lds = (size_t)8 << t->log2_bucket_slots;
     if ((rc = raise_lds_limit((const void *)bucket_merge_kernel, lds, "pg_kmer_rebuild_bucketed"))) return rc;
-    hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
-                       n_parts, view_of(t), status, 1);
+    hipLaunchKernelGGL(bucket_merge_kernel, dim3((unsigned)(bucket_end - bucket_begin)), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs,
+                       (const long long *)seg, n_parts, view_of(t), status, 1, bucket_begin, bucket_end - bucket_begin);
     return check_launch("pg_kmer_rebuild_bucketed");
+}
+
+extern "C" int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t, uint32_t *status, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    return pg_kmer_rebuild_bucketed_range(pairs, seg, n_parts, t, 0, (int64_t)1 << (t->log2_slots - t->log2_bucket_slots), status, stream);
 }
 
 static int check_bucketed(const pg_table *t, const char *who)

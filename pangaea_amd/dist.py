@@ -100,17 +100,22 @@ def _staged(t: torch.Tensor, group=None) -> torch.Tensor:
     return t.cpu() if t.is_cuda and dist.get_backend(group) == "gloo" else t
 
 
-def _all_gather_flat(out: torch.Tensor, mine: torch.Tensor, rank: int, group=None) -> None:
-    """all-gather of equal-sized contiguous vectors into one flat buffer (RCCL: one collective, no list copies);
-    gloo: staged through the host"""
+EXCHANGE_RANGES = 4          # bucket ranges of the pipelined table exchange
+
+
+def _all_gather_flat(out: torch.Tensor, mine: torch.Tensor, group=None, async_op: bool = False):
+    """all-gather of equal-sized contiguous vectors into one flat buffer (RCCL: one collective, no list copies; with
+    ``async_op`` the work handle is returned and the caller's stream waits on it only when told to);
+    gloo: staged through the host, synchronously"""
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out, mine, group=group)
-        return
+        return dist.all_gather_into_tensor(out, mine, group=group, async_op=async_op) if async_op else \
+            dist.all_gather_into_tensor(out, mine, group=group)
     n = mine.numel()
     host = [torch.empty(n, dtype=out.dtype) for _ in range(dist.get_world_size(group))]
     dist.all_gather(host, mine.cpu().contiguous(), group=group)
     for r, h in enumerate(host):
         out[r * n:(r + 1) * n].copy_(h)
+    return None
 
 
 def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
@@ -184,6 +189,46 @@ def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_l
         table = KmerTable.wide_with_slots(k, stream.device, log2) if wide else KmerTable.with_slots(k, stream.device, log2)
 
 
+def _exchange_bucketed(table: KmerTable, group=None) -> None:
+    """the exchange of a bucketed hash table (also callable in a one-rank group, which a one-GPU box can hold over RCCL)"""
+    me = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    # Every rank built its table with the same geometry.  Per-bucket fills are exchanged first (8 B per bucket); they give
+    # the segment offsets of every rank's bucket-ordered compaction.  The compactions are gathered (padded to the longest
+    # part; the padding is never read) and the table is rebuilt bucket by bucket inside LDS from all parts, the own one
+    # included -- the sparse slices are read once (to compact) and written once (the merged image); nothing is
+    # concatenated or scanned by torch.  A deferred count (KmerTable.count(deferred_group=g)) has its fills and entries
+    # already and never wrote its sparse table: the compaction is then a gather out of the count's workspace.
+    fill = table.deferred_fill() if table.pending else table.bucket_fill()
+    nb = table.n_buckets
+    dev = fill.device
+    fills = torch.empty((world, nb), dtype=torch.int64, device=dev)
+    _all_gather_flat(fills.view(-1), fill, group)
+    seg = torch.zeros((world, nb + 1), dtype=torch.int64, device=dev)          # every part's offsets, from its own start
+    seg[:, 1:] = torch.cumsum(fills, dim=1)
+    # the gather is cut into bucket ranges so that the rebuild of one range runs while the next is still in flight
+    # (the collectives queue on RCCL's stream, the rebuilds on the compute stream, each waiting for its own range only)
+    n_ranges = EXCHANGE_RANGES if nb >= 64 * EXCHANGE_RANGES else 1
+    cuts = [nb * c // n_ranges for c in range(n_ranges + 1)]
+    at = seg[:, cuts]                                                            # [world, n_ranges + 1]
+    sizes = at[:, 1:] - at[:, :-1]
+    host = torch.cat([sizes.max(dim=0).values, at[me]]).cpu().tolist()          # the step's one host sync
+    caps, mine_at = [max(int(c), 1) for c in host[:n_ranges]], host[n_ranges:]
+    mine = torch.empty(int(mine_at[-1]) + max(caps), dtype=torch.int64, device=dev)   # slack: a range is sent padded
+    (table.deferred_compact_into if table.pending else table.compact_into)(mine, seg[me].contiguous())
+    bufs, works = [], []
+    for c in range(n_ranges):
+        buf = torch.empty(world * caps[c], dtype=torch.int64, device=dev)
+        works.append(_all_gather_flat(buf, mine[int(mine_at[c]):int(mine_at[c]) + caps[c]], group, async_op=True))
+        bufs.append(buf)
+    lanes = torch.arange(world, device=dev, dtype=torch.int64)[:, None]
+    for c in range(n_ranges):
+        seg_c = (seg[:, cuts[c]:cuts[c + 1] + 1] - at[:, c:c + 1] + lanes * caps[c]).contiguous()
+        if works[c] is not None:
+            works[c].wait()
+        table.rebuild_from(bufs[c], seg_c, check=False, buckets=(cuts[c], cuts[c + 1]))
+
+
 def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTable:
     """turn per-rank partial tables into the global table on every rank (the path's only collective)"""
     if not is_distributed():
@@ -217,27 +262,7 @@ def exchange_table(table: KmerTable, group=None, check: bool = True) -> KmerTabl
             table.check_status()
         return table
     if table._bucketed():
-        # every rank built its table with the same geometry.  Per-bucket fills are exchanged first (8 B per bucket); they
-        # give the segment offsets of every rank's bucket-ordered compaction; the compactions are gathered into ONE buffer
-        # (padded to the longest part; the padding is never read).  The table is
-        # then rebuilt bucket by bucket inside LDS from all parts, the own one included -- the sparse slices are read
-        # once (to compact) and written once (the merged image), and nothing is concatenated or scanned by torch.
-        # (a deferred count -- KmerTable.count(deferred_group=g) -- has produced fills and entries already and never
-        # wrote its sparse table: the compaction is then a gather out of the count's workspace)
-        fill = table.deferred_fill() if table.pending else table.bucket_fill()
-        nb = table.n_buckets
-        fills = torch.empty((world, nb), dtype=torch.int64, device=fill.device)
-        _all_gather_flat(fills.view(-1), fill, me, group)
-        ends = torch.cumsum(fills, dim=1)
-        cap = max(int(ends[:, -1].max().item()), 1)
-        seg = torch.zeros((world, nb + 1), dtype=torch.int64, device=fill.device)
-        seg[:, 1:] = ends
-        buf = torch.empty(world * cap, dtype=torch.int64, device=fill.device)
-        mine = torch.empty(cap, dtype=torch.int64, device=fill.device)
-        (table.deferred_compact_into if table.pending else table.compact_into)(mine, seg[me].contiguous())
-        _all_gather_flat(buf, mine, me, group)
-        seg += torch.arange(world, device=fill.device, dtype=torch.int64)[:, None] * cap
-        table.rebuild_from(buf, seg, check=False)
+        _exchange_bucketed(table, group)
     else:
         parts = gather_pairs(table.compact(), group)
         for r, pairs in enumerate(parts):

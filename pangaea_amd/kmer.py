@@ -351,18 +351,22 @@ class KmerTable:
             _lib.check(_lib.load().pg_deferred_gather(self.desc(), self._workspace.data_ptr(), self._workspace.numel(), n_words,
                                                       fill.data_ptr(), seg.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
 
-    def rebuild_from(self, pairs: torch.Tensor, seg: torch.Tensor, check: bool = True) -> "KmerTable":
+    def rebuild_from(self, pairs: torch.Tensor, seg: torch.Tensor, check: bool = True, buckets: tuple | None = None) -> "KmerTable":
         """replace the table by the merge of ``seg.shape[0]`` bucket-ordered compacted tables of this geometry laid out in
-        ``pairs`` (``seg`` int64 [n_parts, n_buckets + 1], absolute offsets): one workgroup per bucket, inside LDS"""
+        ``pairs`` (``seg`` int64 [n_parts, n_buckets + 1], absolute offsets): one workgroup per bucket, inside LDS.
+        ``buckets`` = (begin, end) rebuilds that bucket range only (``seg`` then [n_parts, end - begin + 1]); the table
+        holds counts again once every range has been rebuilt -- the caller's business."""
         if not self._bucketed():
             raise ValueError("rebuild_from() is for bucketed hash tables")
         _require_gpu(pairs, "the pairs")
-        assert pairs.dtype == torch.int64 and seg.dtype == torch.int64 and seg.is_contiguous() and seg.shape[1] == self.n_buckets + 1
-        self._empty = False                 # (the row-tagged records of this rank's count stay valid: the geometry is the same)
-        self._deferred = None
+        b0, b1 = buckets if buckets is not None else (0, self.n_buckets)
+        assert pairs.dtype == torch.int64 and seg.dtype == torch.int64 and seg.is_contiguous() and seg.shape[1] == b1 - b0 + 1
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().pg_kmer_rebuild_bucketed(pairs.data_ptr(), seg.data_ptr(), int(seg.shape[0]), self.desc(),
-                                                            self.status.data_ptr(), _stream_ptr(self.device)))
+            _lib.check(_lib.load().pg_kmer_rebuild_bucketed_range(pairs.data_ptr(), seg.data_ptr(), int(seg.shape[0]), self.desc(), b0, b1,
+                                                                  self.status.data_ptr(), _stream_ptr(self.device)))
+        if buckets is None or b1 == self.n_buckets:
+            self._empty = False             # (the row-tagged records of this rank's count stay valid: the geometry is the same)
+            self._deferred = None
         if check:
             self.check_status()
         return self

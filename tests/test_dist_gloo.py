@@ -158,13 +158,26 @@ def _rccl_worker(rank, world, port):
         # the collectives of the exchange as RCCL sees them (a one-rank group is all a one-GPU box can hold)
         mine = torch.arange(1000, dtype=torch.int64, device="cuda") * 3
         out = torch.empty(1000, dtype=torch.int64, device="cuda")
-        pdist._all_gather_flat(out, mine, rank)
+        pdist._all_gather_flat(out, mine)
         assert torch.equal(out, mine)
         parts = pdist.gather_pairs(mine)
         assert len(parts) == 1 and torch.equal(parts[0], mine)
         t = torch.ones(8, dtype=torch.int32, device="cuda")
         dist.all_reduce(t)
         assert int(t.sum()) == 8
+        work = pdist._all_gather_flat(out.zero_(), mine, async_op=True)
+        work.wait()
+        assert torch.equal(out, mine)
+        # the whole bucketed exchange over RCCL (fills, range-wise asynchronous gathers, LDS rebuilds), deferred and direct
+        cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=24, n_genomes=3, genome_len=20_000, fragment=8_000, seed=51)
+        s = synth.generate(cfg, device="cuda:0")
+        want = kmer.KmerTable.with_slots(21, "cuda:0", 20, 0).count(s).items()
+        for deferred in (False, True):
+            table = kmer.KmerTable.with_slots(21, "cuda:0", 20, 10)
+            table.count(s, deferred_group=1) if deferred else table.count(s)
+            pdist._exchange_bucketed(table)
+            table.check_status()
+            assert not table.pending and all(np.array_equal(x, y) for x, y in zip(table.items(), want))
     finally:
         dist.destroy_process_group()
 
@@ -172,3 +185,40 @@ def _rccl_worker(rank, world, port):
 @pytest.mark.gpu
 def test_rccl_collectives_of_the_exchange_run():
     _spawn(_rccl_worker, 1)
+
+
+def _exchange_worker(rank, world, port, outdir, deferred):
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=24, n_genomes=3, genome_len=20_000, fragment=8_000, seed=51)
+        s = synth.generate(cfg, device="cuda:0")
+        cut = (s.n_words // 2 + 7) if world == 2 else s.n_words
+        w0, w1 = (0, cut) if rank == 0 else (cut, s.n_words)
+        table = kmer.KmerTable.with_slots(21, "cuda:0", 20, 10)              # 1024 buckets: exchanged in four ranges
+        assert table.n_buckets >= 64 * pdist.EXCHANGE_RANGES
+        if deferred:
+            table.count(s, w0, w1, deferred_group=1)
+            assert table.pending
+        else:
+            table.count(s, w0, w1)
+        pdist.exchange_table(table)
+        assert not table.pending
+        c, n = table.items()
+        np.savez(os.path.join(outdir, f"t{rank}.npz"), c=c, n=n)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deferred", [False, True])
+def test_two_ranks_exchange_in_bucket_ranges(tmp_path, deferred):
+    """each rank counts half of a stream (directly / in deferred form); after the exchange -- fills, compaction, four
+    range-wise gathers and LDS rebuilds -- both hold the table of the whole stream"""
+    _spawn(_exchange_worker, 2, str(tmp_path), deferred)
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=24, n_genomes=3, genome_len=20_000, fragment=8_000, seed=51)
+    s = synth.generate(cfg, device="cuda:0")
+    want = kmer.KmerTable.with_slots(21, "cuda:0", 20, 0).count(s).items()
+    for r in range(2):
+        got = np.load(str(tmp_path / f"t{r}.npz"))
+        assert np.array_equal(got["c"], want[0]) and np.array_equal(got["n"], want[1])
