@@ -332,6 +332,8 @@ __global__ __launch_bounds__(BIG_BLOCK) void distinct_sketch_kernel(const uint64
 
 constexpr int RPL64 = 16, RPL32 = 32; // record scatter passes: 8-byte / 4-byte records a lane keeps in registers
 constexpr int MAX_FAN_BITS = 9;       // <= 512-way scatter per pass
+constexpr int WIDE_FAN_BITS = 10;     // the one-pass row shuffle: 1024 row groups (65536 rows), 64 words per lane
+constexpr int RPL32_WIDE = 64;
 constexpr int REC_KEY_BITS = 42;
 constexpr uint64_t REC_KEY_MASK = (1ull << REC_KEY_BITS) - 1;
 constexpr uint32_t ROW_NONE = (1u << (64 - REC_KEY_BITS)) - 1;
@@ -446,20 +448,26 @@ __global__ __launch_bounds__(BIG_BLOCK) void scan_kernel(const unsigned long lon
     for (int64_t i = a; i < b; ++i) { off[i] = run; run += hist[i]; }
 }
 
-// LDS bookkeeping shared by the scatter passes
-struct ScatterLds {
-    uint32_t start[(1 << MAX_FAN_BITS) + 1];
-    unsigned long long gbase[1 << MAX_FAN_BITS];                    // its first half doubles as the digit counters until the scan
+// LDS bookkeeping shared by the scatter passes (<= 2^FAN_BITS digits)
+template <int FAN_BITS> struct ScatterLds {
+    uint32_t start[(1 << FAN_BITS) + 1];
+    unsigned long long gbase[1 << FAN_BITS];                        // its first half doubles as the digit counters until the scan
     uint32_t wave_tot[WAVES];
     __device__ __forceinline__ uint32_t *cnt() { return reinterpret_cast<uint32_t *>(gbase); }
 };
 
-// exclusive scan of L.cnt[0..n_dig) into L.start[0..n_dig] (n_dig <= 512: two entries per lane); all lanes call
-__device__ __forceinline__ void scatter_scan(ScatterLds &L, int n_dig)
+// exclusive scan of L.cnt[0..n_dig) into L.start[0..n_dig] (PER = 2^FAN_BITS / BLOCK consecutive entries per lane); all lanes call
+template <int FAN_BITS> __device__ __forceinline__ void scatter_scan(ScatterLds<FAN_BITS> &L, int n_dig)
 {
-    const int i0 = 2 * threadIdx.x, i1 = i0 + 1;
-    const uint32_t a = i0 < n_dig ? L.cnt()[i0] : 0, b = i1 < n_dig ? L.cnt()[i1] : 0;
-    const uint32_t v = a + b;
+    constexpr int PER = (1 << FAN_BITS) / BLOCK > 0 ? (1 << FAN_BITS) / BLOCK : 1;
+    uint32_t e[PER];
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = PER * (int)threadIdx.x + j;
+        e[j] = i < n_dig ? L.cnt()[i] : 0;
+        v += e[j];
+    }
     uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -470,9 +478,13 @@ __device__ __forceinline__ void scatter_scan(ScatterLds &L, int n_dig)
     __syncthreads();
     uint32_t before = 0;
     for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += L.wave_tot[wv];
-    const uint32_t excl = before + incl - v;
-    if (i0 < n_dig) L.start[i0] = excl;
-    if (i1 < n_dig) L.start[i1] = excl + a;
+    uint32_t run = before + incl - v;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = PER * (int)threadIdx.x + j;
+        if (i < n_dig) L.start[i] = run;
+        run += e[j];
+    }
     if (threadIdx.x == BLOCK - 1) L.start[n_dig] = before + incl;
     __syncthreads();
 }
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
 // Digit: DIG_HASH -> (key >> dshift) & mask of a (key, row) record;  DIG_ROW -> (word >> dshift) & mask of a 32-bit (row, bin) word.
 // Destination of digit d: out[obase[(base + d) << oshift] + cursor[base + d] ...], base = flat ? 0 : region << dbits.
 enum { DIG_HASH = 0, DIG_ROW = 1 };
-template <typename REC, int DIG, int REC_PER_LANE>
+template <typename REC, int DIG, int REC_PER_LANE, int FAN_BITS>
 __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__restrict__ rec_in,
                                                                 const unsigned long long *__restrict__ in_begin,
                                                                 const unsigned long long *__restrict__ in_end, int in_shift,
@@ -607,7 +619,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
 {
     constexpr int TILE1 = BLOCK * REC_PER_LANE;
     __shared__ REC buf[TILE1];
-    __shared__ ScatterLds L;
+    __shared__ ScatterLds<FAN_BITS> L;
     const int n_dig = 1 << dbits;
     const uint32_t dmask = (uint32_t)n_dig - 1u;
     const int64_t region = blockIdx.x / tiles_x;
@@ -1308,6 +1320,7 @@ int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, Shuf
     p->gbits = 0;
     while (((int64_t)1 << p->gbits) < p->n_groups) ++p->gbits;
     p->gb1 = p->gbits < 8 ? p->gbits : 8;
+    if (p->gbits == WIDE_FAN_BITS && !getenv("PG_S2_TWO_PASS")) p->gb1 = WIDE_FAN_BITS;    // <= 65536 rows: one pass
     p->gb2 = p->gbits - p->gb1;
     if (p->gb2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many rows for two scatter passes");
     p->n_groups_padded = (int64_t)1 << p->gbits;
@@ -1498,7 +1511,7 @@ int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t wo
     // A2: every region -> its 2^bits2 final buckets
     if (p.bits2) {
         const int tiles_x = 96;
-        hipLaunchKernelGGL((scatter_records_kernel<uint64_t, DIG_HASH, RPL64>), dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((scatter_records_kernel<uint64_t, DIG_HASH, RPL64, MAX_FAN_BITS>), dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s,
                            (const uint64_t *)bufa, (const unsigned long long *)off, (const unsigned long long *)(off + ((size_t)1 << p.bits2)),
                            p.bits2, (const unsigned long long *)nullptr, tiles_x, bufb, (const unsigned long long *)off, cur2, 0, 0,
                            p.bits2, KEY_BITS - p.bits);
@@ -1677,7 +1690,12 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     // per-bucket offsets, unlike the stream pass, because a bucket's few tiles would be serialised in one workgroup)
     {
         const int tiles_x = 4;
-        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32>), dim3((unsigned)(tiles_x * nb)), dim3(BLOCK), 0, s,
+        if (sp.gb1 > MAX_FAN_BITS)         // all row groups in ONE pass: bigger tiles keep the runs per group at 64 B
+            hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32_WIDE, WIDE_FAN_BITS>), dim3((unsigned)(tiles_x * nb)), dim3(BLOCK), 0, s,
+                               (const uint32_t *)words_e, off, (const unsigned long long *)emit_end, 0, (const unsigned long long *)nullptr, tiles_x,
+                               words_a, (const unsigned long long *)goff, gcur1, sp.gb2, 1, sp.gb1, gshift + sp.gb2);
+        else
+        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32, MAX_FAN_BITS>), dim3((unsigned)(tiles_x * nb)), dim3(BLOCK), 0, s,
                            (const uint32_t *)words_e, off, (const unsigned long long *)emit_end, 0, (const unsigned long long *)nullptr, tiles_x,
                            words_a, (const unsigned long long *)goff, gcur1, sp.gb2, 1, sp.gb1, gshift + sp.gb2);
     }
@@ -1685,7 +1703,7 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     const uint32_t *final_words = words_a;
     if (sp.gb2) {
         const int tiles_x = 64;
-        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32>), dim3((unsigned)(tiles_x << sp.gb1)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32, MAX_FAN_BITS>), dim3((unsigned)(tiles_x << sp.gb1)), dim3(BLOCK), 0, s,
                            (const uint32_t *)words_a, (const unsigned long long *)goff, (const unsigned long long *)nullptr, sp.gb2,
                            (const unsigned long long *)gcur1, tiles_x, words_b, (const unsigned long long *)goff, gcur2, 0, 0, sp.gb2, gshift);
         gcnt = gcur2;
