@@ -330,7 +330,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void distinct_sketch_kernel(const uint64
 //
 // occurrence record = canonical code (low 42 bits) | row id << 42 (22 bits, ROW_NONE = not inside any row)
 
-constexpr int RPL64 = 16, RPL32 = 32; // record scatter passes: 8-byte / 4-byte records a lane keeps in registers
+constexpr int RPL64 = 32, RPL32 = 32; // record scatter passes: 8-byte / 4-byte records a lane keeps in registers
 constexpr int MAX_FAN_BITS = 9;       // <= 512-way scatter per pass
 constexpr int WIDE_FAN_BITS = 10;     // the one-pass row shuffle: 1024 row groups (65536 rows), 64 words per lane
 constexpr int RPL32_WIDE = 64;
@@ -339,7 +339,7 @@ constexpr uint64_t REC_KEY_MASK = (1ull << REC_KEY_BITS) - 1;
 constexpr uint32_t ROW_NONE = (1u << (64 - REC_KEY_BITS)) - 1;
 constexpr int GROUP_ROWS_LOG2 = 6;    // rows per LDS row-histogram group (64 x 512 bins x 4 B = 128 KiB at most)
 
-constexpr int TILE_WORDS = 128;       // words per stream tile of the first scatter pass (= A1_TILE_WORDS)
+constexpr int TILE_WORDS = 256;       // words per stream tile of the first scatter pass (= A1_TILE_WORDS)
 // first row whose end lies beyond the first character of each stream tile (rows sorted, disjoint)
 __global__ __launch_bounds__(BLOCK) void tile_rows_kernel(const int64_t *__restrict__ row_end, int64_t n_rows, int64_t word_begin,
                                                           int64_t n_tiles, int32_t *__restrict__ tile_row)
@@ -494,7 +494,8 @@ template <int FAN_BITS> __device__ __forceinline__ void scatter_scan(ScatterLds<
 // records) is then laid out digit-sorted in LDS and every digit's run is appended to its region with one global cursor
 // add, so HBM receives contiguous runs.  36 KiB of LDS per workgroup: four workgroups (16 waves) per CU.
 // With rows given, every record also carries the index of the row its k-mer ends in (ROW_NONE outside all rows).
-constexpr int A1_CHARS = 16;
+constexpr int A1_CHARS = 32;            // characters per lane: 16 (two lanes share a word) or 32
+constexpr int A1_LANES_PER_WORD = 32 / A1_CHARS;
 constexpr int A1_TILE_WORDS = BLOCK * A1_CHARS / 32;
 static_assert(A1_TILE_WORDS == TILE_WORDS, "tile_rows_kernel and scatter_stream_kernel must agree on the tile size");
 constexpr int A1_TILE = BLOCK * A1_CHARS;
@@ -505,7 +506,7 @@ struct StreamLds {
     unsigned long long cur[256];                                    // running write offsets of this chunk, per digit
     uint32_t wave_tot[WAVES];
 };
-static_assert(CHUNK_WORDS % (BLOCK * 16 / 32) == 0, "a chunk is a whole number of stream tiles");
+static_assert(CHUNK_WORDS % A1_TILE_WORDS == 0, "a chunk is a whole number of stream tiles");
 __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                                int64_t word_begin, int64_t word_end, int k, int bits1,
                                                                const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end,
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
     const int n_dig = 1 << bits1;
     const int dsh = KEY_BITS - bits1;
     const int64_t n_tiles = (word_end - word_begin + A1_TILE_WORDS - 1) / A1_TILE_WORDS;
-    const int half = threadIdx.x & 1;                               // which 16 characters of the word
+    const int half = threadIdx.x % A1_LANES_PER_WORD;               // which A1_CHARS characters of the word
     const int64_t chunk = blockIdx.x;
     constexpr int TILES_PER_CHUNK = CHUNK_WORDS / A1_TILE_WORDS;
     const int64_t slot = (int64_t)(((__int128)chunk * chunk_stride) % n_chunks);
@@ -531,10 +532,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
         uint64_t rec[A1_CHARS];
         uint32_t dr[A1_CHARS];                                      // digit << 16 | rank inside the digit
         uint32_t ok = 0;
-        const int64_t w = word_begin + tile * A1_TILE_WORDS + (threadIdx.x >> 1);
+        const int64_t w = word_begin + tile * A1_TILE_WORDS + (threadIdx.x / A1_LANES_PER_WORD);
         if (w < word_end) {
             const Word x = load_word(codes, valid, w, k);
-            ok = (x.ok >> (A1_CHARS * half)) & 0xffffu;
+            ok = (uint32_t)(((uint64_t)x.ok >> (A1_CHARS * half)) & ((1ull << A1_CHARS) - 1ull));
             if (ok) {
                 // row bookkeeping: r = first row that can still contain a position >= the current one
                 int64_t r = n_rows, rs = INT64_MAX, re = INT64_MAX;
@@ -549,10 +550,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
                 // pre-roll the k-1 characters before the lane's first one: word positions c in [first-(k-1), first)
                 for (int c = A1_CHARS * half - (k - 1); c < A1_CHARS * half; ++c)
                     rl.push((uint32_t)((c < 0 ? x.pw >> (2 * (c + 32)) : x.cw >> (2 * c)) & 3u));
-                const uint32_t mine = (uint32_t)(x.cw >> (2 * A1_CHARS * half));
+                const uint64_t mine = x.cw >> (2 * A1_CHARS * half);
 #pragma unroll
                 for (int j = 0; j < A1_CHARS; ++j) {
-                    rl.push((mine >> (2 * j)) & 3u);
+                    rl.push((uint32_t)(mine >> (2 * j)) & 3u);
                     if ((ok >> j) & 1) {
                         const int64_t pos = pos0 + j;
                         while (pos >= re) {                         // rows are at least one character long: terminates
