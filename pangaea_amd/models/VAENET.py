@@ -117,11 +117,11 @@ class VAENET:
     @torch.no_grad()
     def _validate(self, loader) -> float:
         self.network.eval()
-        losses = []
+        losses = []                     # kept on the device: one host sync per validation pass, not one per batch
         for batch in loader:
             abd, tnf = self._to_dev(batch)
-            losses.append(self.unlabeled_loss(self.network(abd, tnf))["total"].item())
-        return float(np.average(losses))
+            losses.append(self.unlabeled_loss(self.network(abd, tnf))["total"])
+        return float(torch.stack(losses).double().mean().item()) if losses else float("nan")
 
     # ------------------------------------------------------------------ train (VAENET.py:31-149)
 
@@ -136,10 +136,13 @@ class VAENET:
             hist = {"total": [], "abd_rec": [], "tnf_rec": [], "kl_loss": []}
 
             def report(epoch, batch, val):
+                # the running losses stay on the device until they are printed (the reference calls .item() four times per
+                # batch, VAENET.py:70-76: on a GPU that is four pipeline drains per step)
+                avg = {k: float(torch.stack(v).double().mean().item()) if v else float("nan") for k, v in hist.items()}
                 logging.info(
-                    f"epoch {epoch}/{self.num_epochs} batch {batch + 1}/{len(train_loader)}: train {np.average(hist['total']):.8f} "
-                    f"abd {np.average(hist['abd_rec']):.8f} tnf {np.average(hist['tnf_rec']):.8f} "
-                    f"kl {np.average(hist['kl_loss']):.8f} | test {val:.8f}")
+                    f"epoch {epoch}/{self.num_epochs} batch {batch + 1}/{len(train_loader)}: train {avg['total']:.8f} "
+                    f"abd {avg['abd_rec']:.8f} tnf {avg['tnf_rec']:.8f} "
+                    f"kl {avg['kl_loss']:.8f} | test {val:.8f}")
                 for v in hist.values():
                     v.clear()
 
@@ -151,7 +154,7 @@ class VAENET:
                     abd, tnf = self._to_dev(data)
                     losses = self.unlabeled_loss(self.network(abd, tnf))
                     for key in hist:
-                        hist[key].append(losses[key].item())
+                        hist[key].append(losses[key].detach())
                     losses["total"].backward()
                     opt.step()
                     if (batch + 1) % 100 == 0:          # validation + early stopping every 100 batches
