@@ -38,7 +38,9 @@ def weighted_batches(data, batch_size: int, num_samples: int | None = None, repl
 
     def draw():
         # torch.as_tensor(weights, dtype=double) / sum -- WeightedRandomSampler stores float64 weights
-        return np.random.choice(range(0, n), size=num_samples, p=w / w.sum(), replace=replacement)
+        # (an int first argument draws exactly what ``range(0, n)`` draws -- "as if it were np.arange(n)" -- without
+        # materialising a million-element Python range first)
+        return np.random.choice(n, size=num_samples, p=w / w.sum(), replace=replacement)
 
     return DeviceBatches(data, batch_size, draw, num_samples)
 

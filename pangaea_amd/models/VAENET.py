@@ -111,6 +111,52 @@ class VAENET:
             out[a:a + batch_rows] = self.network.emebdding(abd[a:a + batch_rows], tnf[a:a + batch_rows])
         return out
 
+    # ------------------------------------------------------------------ hipGraph capture of the two launch-bound loops
+    #
+    # A training step is ~90 small kernels (two 512-wide hidden layers on 2048 rows: forward, backward, Adam), a
+    # validation forward ~25: the GPU finishes them faster than the host can launch them.  Once the first batches have
+    # run eagerly, the step is captured into a HIP graph with static input buffers and replayed per batch (same kernels,
+    # same order; BatchNorm statistics, dropout masks and epsilon advance inside the graph).  Batches of another size
+    # (the last one of an epoch) run eagerly.  PG_TRAIN_GRAPH=0 turns the capture off.
+
+    def _graph_ok(self) -> bool:
+        return self.cuda and os.environ.get("PG_TRAIN_GRAPH", "1") != "0"
+
+    def _capture_train_step(self, opt, abd, tnf, side):
+        static_abd, static_tnf = abd.clone(), tnf.clone()
+        self.network.train()
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):      # the stream the eager warm-up steps ran on (their AccumulateGrad nodes)
+            losses = self.unlabeled_loss(self.network(static_abd, static_tnf))
+            losses["total"].backward()
+            opt.step()
+            vec = torch.stack([losses[k].detach() for k in ("total", "abd_rec", "tnf_rec", "kl_loss")])
+
+        def step(a, t):
+            static_abd.copy_(a); static_tnf.copy_(t)
+            graph.replay()
+            v = vec.clone()
+            return {"total": v[0], "abd_rec": v[1], "tnf_rec": v[2], "kl_loss": v[3]}
+        step.rows = int(abd.shape[0])
+        step.keep = (graph, static_abd, static_tnf, vec)
+        return step
+
+    def _capture_val_step(self, abd, tnf):
+        static_abd, static_tnf = abd.clone(), tnf.clone()
+        self.network.eval()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            total = self.unlabeled_loss(self.network(static_abd, static_tnf))["total"]
+
+        def step(a, t):
+            static_abd.copy_(a); static_tnf.copy_(t)
+            graph.replay()
+            return total.clone()
+        step.rows = int(abd.shape[0])
+        step.keep = (graph, static_abd, static_tnf, total)
+        return step
+
     def _to_dev(self, batch):
         return torch.as_tensor(batch["abd"]).to(self.device), torch.as_tensor(batch["tnf"]).to(self.device)
 
@@ -118,9 +164,18 @@ class VAENET:
     def _validate(self, loader) -> float:
         self.network.eval()
         losses = []                     # kept on the device: one host sync per validation pass, not one per batch
+        seen = 0
         for batch in loader:
             abd, tnf = self._to_dev(batch)
+            graphed = getattr(self, "_val_step", None)
+            if graphed is not None and graphed.rows == abd.shape[0]:
+                losses.append(graphed(abd, tnf))
+                continue
             losses.append(self.unlabeled_loss(self.network(abd, tnf))["total"])
+            seen += 1
+            if graphed is None and seen == 3 and self._graph_ok():      # warmed up: capture the forward for the rest
+                torch.cuda.synchronize()
+                self._val_step = self._capture_val_step(abd, tnf)
         return float(torch.stack(losses).double().mean().item()) if losses else float("nan")
 
     # ------------------------------------------------------------------ train (VAENET.py:31-149)
@@ -132,7 +187,10 @@ class VAENET:
         early = EarlyStopping(patience=patience, delta=1e-6, path=train_model)
         if not os.path.exists(train_model):
             logging.info("train start")
-            opt = torch.optim.Adam(self.network.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+            opt = torch.optim.Adam(self.network.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay,
+                                   capturable=self._graph_ok())
+            self._val_step = None
+            train_step, eager_steps, side = None, 0, None
             hist = {"total": [], "abd_rec": [], "tnf_rec": [], "kl_loss": []}
 
             def report(epoch, batch, val):
@@ -150,13 +208,36 @@ class VAENET:
                 batch = -1
                 for batch, data in enumerate(train_loader):
                     self.network.train()
-                    opt.zero_grad()
                     abd, tnf = self._to_dev(data)
-                    losses = self.unlabeled_loss(self.network(abd, tnf))
-                    for key in hist:
-                        hist[key].append(losses[key].detach())
-                    losses["total"].backward()
-                    opt.step()
+                    if train_step is not None and train_step.rows == abd.shape[0]:
+                        losses = train_step(abd, tnf)
+                        for key in hist:
+                            hist[key].append(losses[key])
+                    elif self._graph_ok() and train_step is None:
+                        # warm-up steps (real ones) on the side stream the graph will be captured on
+                        if side is None:
+                            side = torch.cuda.Stream()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            opt.zero_grad(set_to_none=True)
+                            losses = self.unlabeled_loss(self.network(abd, tnf))
+                            for key in hist:
+                                hist[key].append(losses[key].detach())
+                            losses["total"].backward()
+                            opt.step()
+                        torch.cuda.current_stream().wait_stream(side)
+                        del losses                      # nothing may keep the eager autograd graph alive across the capture
+                        eager_steps += 1
+                        if eager_steps == 3:
+                            torch.cuda.synchronize()
+                            train_step = self._capture_train_step(opt, abd, tnf, side)
+                    else:
+                        opt.zero_grad()
+                        losses = self.unlabeled_loss(self.network(abd, tnf))
+                        for key in hist:
+                            hist[key].append(losses[key].detach())
+                        losses["total"].backward()
+                        opt.step()
                     if (batch + 1) % 100 == 0:          # validation + early stopping every 100 batches
                         val = self._validate(val_loader)
                         report(epoch, batch, val)

@@ -110,3 +110,34 @@ def test_sampler_draws_are_the_reference_draws():
     got = np.concatenate([b["bc"] for b in weighted_batches(D(), 2, num_samples=3, replacement=False)])
     np.random.seed(8)
     assert list(got) == list(np.random.choice(range(5), size=3, p=w / w.sum(), replace=False))
+
+
+@pytest.mark.gpu
+def test_graph_captured_training_learns_like_the_eager_loop(tmp_path, monkeypatch):
+    """the hipGraph replay of the training step and of the validation forward is the same computation as the eager loop:
+    same files, same checkpoint keys, a validation loss in the same place (dropout masks and epsilon differ by design)"""
+    rs = np.random.RandomState(1)
+    n, k = 4096, 6
+    proto_a, proto_t = rs.rand(k, 400) ** 4, rs.rand(k, 136) + 0.2
+    which = rs.randint(0, k, n)
+    abd, tnf = rs.poisson(proto_a[which] * 300), rs.poisson(proto_t[which] * 400)
+    names = np.array([f"b{i}" for i in range(n)], dtype=object)
+    finals = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PG_TRAIN_GRAPH", mode)
+        data = Data(names, abd, tnf, device="cuda:0")
+        np.random.seed(2021); torch.manual_seed(2021)
+        loaders = (weighted_batches(data, 256), weighted_batches(data, 256, num_samples=int(n * 0.7), replacement=False), shuffled_batches(data, 256))
+        vae = VAENET(400, 136, 32, k, 6, True, 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+        model = tmp_path / f"vae{mode}"
+        model.mkdir()
+        vae.train(*loaders, str(model), 50)
+        assert (vae._val_step is not None) == (mode == "1")
+        np.random.seed(7)
+        finals[mode] = vae._validate(weighted_batches(data, 256, num_samples=2048, replacement=False))
+        latent = np.load(model / "latent.npz")["arr_0"]
+        assert latent.shape == (n, 32) and np.isfinite(latent).all()
+        state = {k2: v.cpu().numpy() for k2, v in torch.load(model / "train_model.pk", map_location="cpu").items()}
+        want = oracle.vae_embedding(state, data.abd, data.tnf)
+        assert np.abs(latent - want).max() <= 1e-5 * np.abs(want).max()
+    assert abs(finals["1"] - finals["0"]) <= 0.1 * abs(finals["0"]), finals
