@@ -67,16 +67,33 @@ def write_csv_gz(path: str, names, mat: np.ndarray) -> None:
     _lib.check(_lib.load().pg_write_csv_gz(path.encode(), blob, mat.ctypes.data, mat.shape[0], mat.shape[1] if mat.ndim == 2 else 0))
 
 
+def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | None) -> ReadStream:
+    """this rank's host stream: from the packed-stream cache when one is given and is newer than the reads, else from the
+    FASTQ file(s) (and the cache is written for the next pass)"""
+    cache = None
+    if stream_cache:
+        rank = torch.distributed.get_rank() if world > 1 else 0
+        cache = f"{stream_cache}.r{rank}of{world}.pgstream"
+        newest = max(os.path.getmtime(p) for p in (reads1, reads2) if p)
+        if os.path.exists(cache) and os.path.getmtime(cache) >= newest:
+            logging.info(f"packed read stream from {cache}")
+            return ReadStream.load(cache)
+    part = pdist.ingest_shard(reads1, reads2) if world > 1 else ReadStream.from_fastq(reads1, reads2)
+    if cache:
+        part.save(cache)
+    return part
+
+
 def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window: int, vsize: int, min_len: int,
-                     device=None, want_tnf: bool = True, want_abd: bool = True, table: KmerTable | None = None):
+                     device=None, want_tnf: bool = True, want_abd: bool = True, table: KmerTable | None = None,
+                     stream_cache: str | None = None):
     """(names, tnf int32 ndarray or None, abd int32 ndarray or None) of a barcode-sorted FASTQ, on the GPU.
     Under an initialised ``torch.distributed`` group every rank takes a contiguous range of runs, the table is
     exchanged once, and the rows are gathered so every rank returns the full matrices."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     world = torch.distributed.get_world_size() if pdist.is_distributed() else 1
-    part = pdist.ingest_shard(reads1, reads2) if world > 1 else ReadStream.from_fastq(reads1, reads2)
-    stream = part.to(device)
+    stream = _ingest(reads1, reads2, world, stream_cache).to(device)
     rows = stream.rows(min_len)
     plan = Plan(rows, device)
     if want_abd and table is None:
@@ -130,8 +147,11 @@ class Feature:
         if self._cache is None:
             r1, r2 = self._inputs()
             logging.info("GPU feature pass: ingest + k-mer table + TNF/abundance rows")
+            # PANGAEA_STREAM_CACHE=1 keeps the packed read stream next to the feature caches (1.features/reads.*.pgstream)
+            cache = os.path.join(self.feature_dir, "reads") if os.environ.get("PANGAEA_STREAM_CACHE", "0") not in ("", "0") else None
             self._cache = compute_features(r1, r2, int(self.kmer), int(self.tnf_k), int(self.ws), int(self.vs), int(self.minl),
-                                           device=getattr(self.args, "device", None), want_tnf=want_tnf, want_abd=want_abd)
+                                           device=getattr(self.args, "device", None), want_tnf=want_tnf, want_abd=want_abd,
+                                           stream_cache=cache)
         return self._cache
 
     # ------------------------------------------------------------------ the reference's public methods

@@ -7,6 +7,7 @@ validity for every character of ``read1 N read2 N ...`` in file order, plus the 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -122,6 +123,50 @@ class ReadStream:
         valid = np.zeros(nw, dtype=np.int32)
         _lib.check(L.pg_pack_ascii(text, len(text), codes.ctypes.data, valid.ctypes.data))
         return cls(torch.from_numpy(codes), torch.from_numpy(valid), len(text), off, [n for n, _ in runs]).to(device)
+
+    # ------------------------------------------------------------------ packed-stream cache
+
+    _MAGIC = b"PGSTRM1\0"
+
+    def save(self, path: str) -> None:
+        """write the packed stream and its runs to ``path``: a second pass over the same reads (another k, a restart, the
+        other ranks of a job) then costs a file read at memcpy speed instead of a FASTQ parse.  Layout, little endian:
+        magic, int64 x 7 (n_chars, n_words, n_runs, n_pairs, n_unpaired, names_bytes, mode_bytes), mode, run_off,
+        NUL-terminated names, zero padding to 4096, codes (8 B/word), valid (4 B/word)."""
+        codes = self.codes.cpu().numpy()
+        valid = self.valid.cpu().numpy()
+        names = b"".join(n.encode() + b"\0" for n in self.run_names)
+        mode = self.mode.encode()
+        head = np.array([self.n_chars, codes.size, len(self.run_names), self.n_pairs, self.n_unpaired, len(names), len(mode)], dtype="<i8")
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(self._MAGIC); f.write(head.tobytes()); f.write(mode)
+            f.write(np.ascontiguousarray(self.run_off, dtype="<i8").tobytes()); f.write(names)
+            f.write(b"\0" * (-f.tell() % 4096))
+            codes.astype("<i8", copy=False).tofile(f)
+            valid.astype("<i4", copy=False).tofile(f)
+        os.replace(tmp, path)
+
+    @classmethod
+    def load(cls, path: str, device: str | torch.device = "cpu") -> "ReadStream":
+        """a stream written by ``save`` (the arrays are memory-mapped: only what is copied to the device is read)"""
+        with open(path, "rb") as f:
+            if f.read(8) != cls._MAGIC:
+                raise ValueError(f"{path} is not a packed read stream")
+            n_chars, n_words, n_runs, n_pairs, n_unpaired, names_bytes, mode_bytes = (int(v) for v in np.frombuffer(f.read(56), dtype="<i8"))
+            mode = f.read(mode_bytes).decode()
+            run_off = np.frombuffer(f.read(8 * (n_runs + 1)), dtype="<i8").astype(np.int64)
+            names = f.read(names_bytes).split(b"\0")[:-1] if names_bytes else []
+            at = f.tell() + (-f.tell() % 4096)
+        if len(names) != n_runs or os.path.getsize(path) != at + 12 * n_words or n_words != words_for(n_chars):
+            raise ValueError(f"{path} is truncated or inconsistent")
+        codes = np.memmap(path, dtype="<i8", mode="r", offset=at, shape=(n_words,))
+        valid = np.memmap(path, dtype="<i4", mode="r", offset=at + 8 * n_words, shape=(n_words,))
+        device = torch.device(device)
+        if device.type == "cpu":
+            codes, valid = np.array(codes), np.array(valid)
+        return cls(torch.from_numpy(codes).to(device), torch.from_numpy(valid).to(device), n_chars, run_off, [n.decode() for n in names],
+                   n_pairs, n_unpaired, mode)
 
     def to(self, device) -> "ReadStream":
         device = torch.device(device)

@@ -268,3 +268,26 @@ def test_sharded_ingest_large_file_and_errors(tmp_path):
         ReadStream.count_newlines(gz, 0, 2)
     with pytest.raises(RuntimeError, match="cannot open"):
         ReadStream.count_newlines(str(tmp_path / "missing.fq"), 0, 2)
+
+
+def test_packed_stream_cache_round_trip(tmp_path):
+    """ReadStream.save / load: the packed stream, its runs and counters come back identical (arrays memory-mapped)"""
+    for name, r2 in (("tenx_mixed.fq", None), ("stlfr.fq", None), ("pair_R1.fq", "pair_R2.fq")):
+        s = ReadStream.from_fastq(os.path.join(GOLDEN, name), os.path.join(GOLDEN, r2) if r2 else None)
+        path = str(tmp_path / (name + ".pgstream"))
+        s.save(path)
+        t = ReadStream.load(path)
+        assert np.array_equal(s.codes.numpy(), t.codes.numpy()) and np.array_equal(s.valid.numpy(), t.valid.numpy())
+        assert np.array_equal(s.run_off, t.run_off) and s.run_names == t.run_names
+        assert (s.n_chars, s.n_pairs, s.n_unpaired, s.mode) == (t.n_chars, t.n_pairs, t.n_unpaired, t.mode)
+        assert t.decode() == s.decode()
+    empty = ReadStream.from_runs([])
+    empty.save(str(tmp_path / "e.pgstream"))
+    assert ReadStream.load(str(tmp_path / "e.pgstream")).n_chars == 0
+    with open(path, "r+b") as f:
+        f.truncate(os.path.getsize(path) - 5)
+    with pytest.raises(ValueError, match="truncated"):
+        ReadStream.load(path)
+    open(path, "wb").write(b"@r1\nACGT\n")
+    with pytest.raises(ValueError, match="not a packed read stream"):
+        ReadStream.load(path)

@@ -116,3 +116,26 @@ def test_stlfr_and_hybrid_style_inputs(style, k, clusters, tmp_path):
         assert names[0] == "1_1_1"
     else:
         assert names[0] == "lr_0000000"
+
+
+def test_packed_stream_cache_feeds_a_second_pass(tmp_path, monkeypatch):
+    """PANGAEA_STREAM_CACHE=1: the first pass leaves the packed read stream next to the feature caches; a second pass with
+    other parameters (here another k) reads it instead of parsing the FASTQ again, and gives the reference's rows"""
+    from pangaea_amd.feature import Feature
+    from pangaea_amd.reads import ReadStream
+    monkeypatch.setenv("PANGAEA_STREAM_CACHE", "1")
+    args = _args(tmp_path, interleaved_reads=os.path.join(GOLDEN, "tenx_clean.fq.gz"))
+    names, abd, tnf = Feature(args, ROOT).extract_features()
+    cache = os.path.join(args.output, "1.features", "reads.r0of1.pgstream")
+    assert os.path.isfile(cache)
+    calls = []
+    real = ReadStream.from_fastq.__func__
+    monkeypatch.setattr(ReadStream, "from_fastq", classmethod(lambda cls, *a, **k: calls.append(a) or real(cls, *a, **k)))
+    args21 = _args(tmp_path, interleaved_reads=os.path.join(GOLDEN, "tenx_clean.fq.gz"), kmer=21, window_size=1, vector_size=6,
+                   min_length=1000, tnf_kmer=5)
+    n2, a2, t2 = Feature(args21, ROOT).extract_features()
+    assert calls == []                                               # no FASTQ parse
+    ref_a = pd.read_csv(os.path.join(GOLDEN, "tenx_clean.abd.k21.w1.v6.l1000.csv"), header=None)
+    ref_t = pd.read_csv(os.path.join(GOLDEN, "tenx_clean.tnf.k5.l1000.csv"), header=None)
+    assert (n2 == ref_a[0].to_numpy()).all()
+    assert np.array_equal(t2, ref_t.drop(columns=0).to_numpy()) and np.array_equal(a2, ref_a.drop(columns=0).to_numpy())
