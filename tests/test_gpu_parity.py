@@ -501,3 +501,21 @@ def test_randomized_configurations(seed):
         assert np.array_equal(tnf.cpu().numpy(), otnf) and np.array_equal(abd.cpu().numpy(), oabd)
     else:
         assert tuple(abd.shape) == (0, vsize)
+
+
+@pytest.mark.parametrize("n_barcodes,force_two", [(70_000, False), (40_000, True), (40_000, False)])
+def test_row_shuffle_one_pass_and_two_pass_forms(n_barcodes, force_two, monkeypatch):
+    """up to 65536 rows the (row, bin) words go to their row groups in one 1024-way pass, beyond that in two; both forms
+    (the second also forced on a smaller row set) give the lookup kernel's matrix"""
+    if force_two:
+        monkeypatch.setenv("PG_S2_TWO_PASS", "1")
+    cfg = synth.SynthConfig(n_pairs=4 * n_barcodes, n_barcodes=n_barcodes, n_genomes=4, genome_len=200_000, fragment=20_000, unbarcoded=0.0, seed=61)
+    s = synth.generate(cfg, device=DEV, with_names=True)
+    rows = s.rows(600)
+    assert len(rows) > (65536 if n_barcodes > 65536 else 32768)
+    plan = kmer.Plan(rows, DEV)
+    table = kmer.count_kmers(s, 21, rows=plan)
+    assert table.has_records_for(plan, 400)
+    _, abd = kmer.features(s, plan, k_tnf=None, table=table, window=3, vsize=400)
+    _, abd2 = kmer.features(s, rows, k_tnf=None, table=table, window=3, vsize=400)
+    assert torch.equal(abd, abd2) and int(abd.sum()) > 0
