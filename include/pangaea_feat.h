@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+#define PG_ABI_VERSION 2   /* 2: packed hash slots are keyed by pg_key42(code); exchange and sharded-ingest entry points */
 #define PG_CHARS_PER_WORD 32
 #define PG_WORD_ALIGN 256 /* stream arrays are padded to a multiple of this many words */
 

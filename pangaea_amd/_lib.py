@@ -22,6 +22,7 @@ HASH_COUNT_SAT = 1 << 21
 TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
+ABI_VERSION = 2
 SHUFFLE_MAX_VSIZE = 512
 DEFERRED_MAX_GROUP_LOG2 = 3
 KEY42_M1 = 0x3d7ed558ccd          # pg_key42 (include/pangaea_feat.h)
@@ -109,8 +110,8 @@ def load() -> C.CDLL:
     for name, (res, args) in sig.items():
         fn = getattr(L, name)           # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
-    if L.pg_abi_version() != 1:
-        raise RuntimeError(f"{LIB_PATH}: ABI version {L.pg_abi_version()} != 1")
+    if L.pg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {L.pg_abi_version()} != {ABI_VERSION}")
     _LIB = L
     return L
 
