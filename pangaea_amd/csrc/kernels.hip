@@ -757,6 +757,90 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
 }
 
+// B with a split LDS table (buckets >= 2^11, i.e. the key's bits below the bucket id fit 31 bits): tags[] = those bits
+// | 0x80000000, counts[] = plain uint32 -- the same 128 KiB, but every LDS operation is 4 bytes wide and the increment is a
+// 32-bit add with no saturation test (a bucket has < 2^32 records; counts are clamped to SAT when the slots are packed).
+__device__ __forceinline__ bool lds_insert32(uint32_t *tags, uint32_t *cnts, uint32_t smask, uint32_t limit, uint32_t tag, bool live,
+                                             uint32_t s, uint32_t cur)
+{
+    if (!live) return true;
+    for (uint32_t i = 0; i < limit; ++i) {
+        if (cur == 0) {
+            cur = atomicCAS(&tags[s], 0u, tag);
+            if (cur == 0) cur = tag;
+        }
+        if (cur == tag) { atomicAdd(&cnts[s], 1u); return true; }
+        s = (s + 1) & smask;
+        cur = tags[s];
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_count32_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                   HashView t, int accumulate, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    uint32_t *tags = reinterpret_cast<uint32_t *>(tab), *cnts = tags + n_slots;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = KEY_BITS - t.log2_slots;
+    const int tag_bits = KEY_BITS - (t.log2_slots - t.log2_bucket);  // <= 31
+    const uint32_t tag_mask = (1u << tag_bits) - 1u;
+    uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    if (r0 == r1 && accumulate) return;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint64_t v = accumulate ? slice[i] : 0ull;
+        tags[i] = v ? ((uint32_t)(v >> HASH_CBITS) & tag_mask) | 0x80000000u : 0u;
+        cnts[i] = (uint32_t)(v & HASH_CMASK);
+    }
+    __syncthreads();
+    bool full = false;
+    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
+    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
+    const int64_t stride = (int64_t)BIG_BLOCK * (CNT_BATCH / 2);
+    ulonglong2 nxt[CNT_BATCH / 2];
+#pragma unroll
+    for (int j = 0; j < CNT_BATCH / 2; ++j) {
+        const int64_t q = q0 + (int64_t)j * BIG_BLOCK + threadIdx.x;
+        nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
+    }
+    for (int64_t base = q0; base < q1; base += stride) {
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH];
+        bool live[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            const ulonglong2 v = nxt[j];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
+            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
+            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
+            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
+            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
+        }
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + stride + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
+        }
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
+#define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
+        PG_RESOLVE(0) PG_RESOLVE(1) PG_RESOLVE(2) PG_RESOLVE(3) PG_RESOLVE(4) PG_RESOLVE(5) PG_RESOLVE(6) PG_RESOLVE(7)
+#undef PG_RESOLVE
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    const uint64_t high = (uint64_t)blockIdx.x << tag_bits;         // the bucket id is the key's top bits
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint32_t tg = tags[i], c = cnts[i];
+        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
+    }
+}
+
 // B for the multi-GPU path: the rank's table is never materialised.  The table descriptor has the geometry of the UNION
 // over all ranks (so that the records are partitioned the way the final lookups need them), but one rank's share of the
 // keys is 2^g times sparser: a workgroup therefore counts 2^g adjacent final buckets together in one LDS table of the
@@ -1525,6 +1609,11 @@ int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t wo
         return check_launch("pg_kmer_count_deferred");
     }
     // B: count every bucket inside LDS and write its slice of the table
+    if (KEY_BITS - p.bits <= 31 && !getenv("PG_B64")) {
+        if ((rc = raise_lds_limit((const void *)bucket_count32_kernel, slice_lds, "pg_kmer_count_bucketed"))) return rc;
+        hipLaunchKernelGGL(bucket_count32_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)(p.bits2 ? bufb : bufa),
+                           (const unsigned long long *)off, view_of(t), accumulate ? 1 : 0, status);
+    } else
     hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)(p.bits2 ? bufb : bufa),
                        (const unsigned long long *)off, view_of(t), accumulate ? 1 : 0, status);
     return check_launch("pg_kmer_count_bucketed");
