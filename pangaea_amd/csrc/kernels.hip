@@ -905,6 +905,67 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact_kernel(const u
     if (threadIdx.x <= qmask) fill[b0 + threadIdx.x] = (long long)qcnt[threadIdx.x];
 }
 
+// the same with the split 32-bit LDS table (the key's bits below the GROUP id fit 31 bits)
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact32_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                           HashView t, int g, uint64_t *__restrict__ scratch,
+                                                                           long long *__restrict__ fill, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ uint32_t qcnt[1 << PG_DEFERRED_MAX_GROUP_LOG2];
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    uint32_t *tags = reinterpret_cast<uint32_t *>(tab), *cnts = tags + n_slots;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = KEY_BITS - (t.log2_slots - g);                  // slot inside the group's table
+    const int tag_bits = KEY_BITS - (t.log2_slots - t.log2_bucket - g);   // key bits below the group id, <= 31
+    const uint32_t tag_mask = (1u << tag_bits) - 1u;
+    const uint32_t qmask = (1u << g) - 1u;
+    const int64_t b0 = (int64_t)blockIdx.x << g;
+    const int64_t r0 = (int64_t)off[b0], r1 = (int64_t)off[b0 + (1 << g)];
+    if (threadIdx.x <= qmask) qcnt[threadIdx.x] = 0;
+    if (r0 == r1) { if (threadIdx.x <= qmask) fill[b0 + threadIdx.x] = 0; return; }
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) { tags[i] = 0u; cnts[i] = 0u; }
+    __syncthreads();
+    bool full = false;
+    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
+    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
+    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH];
+        bool live[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            ulonglong2 v = make_ulonglong2(0ull, 0ull);
+            if (q < q1) v = rec2[q];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
+            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
+            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
+            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
+            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
+        }
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
+#define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
+        PG_RESOLVE(0) PG_RESOLVE(1) PG_RESOLVE(2) PG_RESOLVE(3) PG_RESOLVE(4) PG_RESOLVE(5) PG_RESOLVE(6) PG_RESOLVE(7)
+#undef PG_RESOLVE
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    const uint64_t high = (uint64_t)blockIdx.x << tag_bits;         // the group id is the key's top bits
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint32_t tg = tags[i];
+        if (tg) {
+            const uint32_t c = cnts[i];
+            const uint32_t q = ((tg & tag_mask) >> (tag_bits - g)) & qmask;          // the final bucket inside the group
+            scratch[off[b0 + q] + atomicAdd(&qcnt[q], 1u)] = ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x <= qmask) fill[b0 + threadIdx.x] = (long long)qcnt[threadIdx.x];
+}
+
 // the deferred entries of bucket b, scratch[off[b] .. off[b] + fill[b]), to out[seg[b] ..]: one wavefront per bucket
 __global__ __launch_bounds__(BLOCK) void deferred_gather_kernel(const uint64_t *__restrict__ scratch, const unsigned long long *__restrict__ off,
                                                                 const long long *__restrict__ fill, const long long *__restrict__ seg,
@@ -992,6 +1053,74 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t 
     if (full) atomicOr(status, 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+}
+
+// the merge / rebuild with the split 32-bit LDS table: an entry adds its count with ONE 32-bit LDS add (no CAS loop; the sum
+// of all parts' counts stays far below 2^32 and is clamped to SAT when the slots are packed -- the exact saturating sum)
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_merge32_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
+                                                                   int n_parts, HashView t, uint32_t *status, int rebuild,
+                                                                   int64_t bucket_base, int64_t n_seg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    uint32_t *tags = reinterpret_cast<uint32_t *>(tab), *cnts = tags + n_slots;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = KEY_BITS - t.log2_slots;
+    const int tag_bits = KEY_BITS - (t.log2_slots - t.log2_bucket);
+    const uint32_t tag_mask = (1u << tag_bits) - 1u;
+    const int64_t bucket = bucket_base + blockIdx.x;
+    uint64_t *slice = t.slots + ((uint64_t)bucket << t.log2_bucket);
+    int64_t total = 0;
+    for (int p = 0; p < n_parts; ++p) total += seg[p * (n_seg + 1) + blockIdx.x + 1] - seg[p * (n_seg + 1) + blockIdx.x];
+    if (total == 0 && !rebuild) return;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint64_t v = rebuild ? 0ull : slice[i];
+        tags[i] = v ? ((uint32_t)(v >> HASH_CBITS) & tag_mask) | 0x80000000u : 0u;
+        cnts[i] = (uint32_t)(v & HASH_CMASK);
+    }
+    __syncthreads();
+    bool full = false;
+    for (int p = 0; p < n_parts; ++p) {
+        const int64_t a = seg[p * (n_seg + 1) + blockIdx.x], b = seg[p * (n_seg + 1) + blockIdx.x + 1];
+        for (int64_t base = a; base < b; base += (int64_t)BIG_BLOCK * MERGE_BATCH) {
+            uint64_t e[MERGE_BATCH];
+#pragma unroll
+            for (int j = 0; j < MERGE_BATCH; ++j) {
+                const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+                e[j] = i < b ? pairs[i] : 0ull;
+            }
+            uint32_t ss[MERGE_BATCH], first[MERGE_BATCH];
+#pragma unroll
+            for (int j = 0; j < MERGE_BATCH; ++j) {
+                ss[j] = (uint32_t)((e[j] >> HASH_CBITS) >> hsh) & smask;
+                first[j] = e[j] ? tags[ss[j]] : 0u;
+            }
+#define PG_MERGE(J)                                                                                                         \
+            if (e[J]) {                                                                                                     \
+                const uint32_t tg = ((uint32_t)(e[J] >> HASH_CBITS) & tag_mask) | 0x80000000u;                              \
+                uint32_t add = (uint32_t)(e[J] & HASH_CMASK);                                                               \
+                if (add > HASH_SAT) add = HASH_SAT;                                                                         \
+                uint32_t sl = ss[J], cur = first[J];                                                                        \
+                bool done = false;                                                                                          \
+                for (uint32_t tries = 0; tries < limit && !done; ++tries) {                                                 \
+                    if (cur == 0) { cur = atomicCAS(&tags[sl], 0u, tg); if (cur == 0) cur = tg; }                           \
+                    if (cur == tg) { atomicAdd(&cnts[sl], add); done = true; }                                              \
+                    else { sl = (sl + 1) & smask; cur = tags[sl]; }                                                         \
+                }                                                                                                           \
+                full |= !done;                                                                                              \
+            }
+            PG_MERGE(0) PG_MERGE(1) PG_MERGE(2) PG_MERGE(3)
+#undef PG_MERGE
+        }
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    const uint64_t high = (uint64_t)bucket << tag_bits;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint32_t tg = tags[i], c = cnts[i];
+        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
+    }
 }
 
 // occupied slots of every bucket: the segment lengths of a bucket-ordered compaction (one workgroup per bucket)
@@ -1603,8 +1732,11 @@ int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t wo
     }
     if (deferred_group >= 0) {
         // B, deferred: groups of final buckets counted in LDS, occupied entries + fills only (bufa is free after A2)
-        if ((rc = raise_lds_limit((const void *)bucket_count_compact_kernel, slice_lds, "pg_kmer_count_deferred"))) return rc;
-        hipLaunchKernelGGL(bucket_count_compact_kernel, dim3((unsigned)(nb >> deferred_group)), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)bufb,
+        const bool split32 = KEY_BITS - (p.bits - deferred_group) <= 31 && !getenv("PG_B64");
+        const void *fn = split32 ? (const void *)bucket_count_compact32_kernel : (const void *)bucket_count_compact_kernel;
+        if ((rc = raise_lds_limit(fn, slice_lds, "pg_kmer_count_deferred"))) return rc;
+        hipLaunchKernelGGL(split32 ? bucket_count_compact32_kernel : bucket_count_compact_kernel, dim3((unsigned)(nb >> deferred_group)),
+                           dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)bufb,
                            (const unsigned long long *)off, view_of(t), deferred_group, bufa, (long long *)fill, status);
         return check_launch("pg_kmer_count_deferred");
     }
@@ -1653,8 +1785,9 @@ extern "C" int pg_kmer_merge_bucketed(const uint64_t *pairs, const int64_t *seg,
     const int bits = t->log2_slots - t->log2_bucket_slots;
     if (bits < 0 || bits > 30) return pg_fail(PG_EINVAL, "pg_kmer_merge_bucketed: bad bucket geometry");
     const size_t lds = (size_t)8 << t->log2_bucket_slots;
-    if ((rc = raise_lds_limit((const void *)bucket_merge_kernel, lds, "pg_kmer_merge_bucketed"))) return rc;
-    hipLaunchKernelGGL(bucket_merge_kernel, dim3(1u << bits), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
+    const bool split32 = KEY_BITS - bits <= 31 && !getenv("PG_B64");
+    if ((rc = raise_lds_limit(split32 ? (const void *)bucket_merge32_kernel : (const void *)bucket_merge_kernel, lds, "pg_kmer_merge_bucketed"))) return rc;
+    hipLaunchKernelGGL(split32 ? bucket_merge32_kernel : bucket_merge_kernel, dim3(1u << bits), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs, (const long long *)seg,
                        n_parts, view_of(t), status, 0, (int64_t)0, (int64_t)1 << bits);
     return check_launch("pg_kmer_merge_bucketed");
 }
@@ -1673,8 +1806,10 @@ extern "C" int pg_kmer_rebuild_bucketed_range(const uint64_t *pairs, const int64
         return pg_fail(PG_EINVAL, "pg_kmer_rebuild_bucketed: bucket range [%lld,%lld) outside the table", (long long)bucket_begin, (long long)bucket_end);
     if (bucket_end == bucket_begin) return PG_OK;
     const size_t lds = (size_t)8 << t->log2_bucket_slots;
-    if ((rc = raise_lds_limit((const void *)bucket_merge_kernel, lds, "pg_kmer_rebuild_bucketed"))) return rc;
-    hipLaunchKernelGGL(bucket_merge_kernel, dim3((unsigned)(bucket_end - bucket_begin)), dim3(BIG_BLOCK), lds, (hipStream_t)stream, pairs,
+    const bool split32 = KEY_BITS - bits <= 31 && !getenv("PG_B64");
+    if ((rc = raise_lds_limit(split32 ? (const void *)bucket_merge32_kernel : (const void *)bucket_merge_kernel, lds, "pg_kmer_rebuild_bucketed"))) return rc;
+    hipLaunchKernelGGL(split32 ? bucket_merge32_kernel : bucket_merge_kernel, dim3((unsigned)(bucket_end - bucket_begin)), dim3(BIG_BLOCK), lds,
+                       (hipStream_t)stream, pairs,
                        (const long long *)seg, n_parts, view_of(t), status, 1, bucket_begin, bucket_end - bucket_begin);
     return check_launch("pg_kmer_rebuild_bucketed");
 }

@@ -245,7 +245,7 @@ def test_bucketed_counter_equals_direct_counter(log2_slots, log2_bucket):
     assert np.array_equal(gc, wc) and np.array_equal(gn, wn)
 
 
-@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 10), (20, 6), (18, 14), (18, 0)])
+@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 10), (20, 6), (18, 14), (18, 0), (22, 10), (25, 14)])
 def test_merging_tables_bucket_by_bucket(log2_slots, log2_bucket):
     """tables of two halves of a stream (same geometry) merge into the table of the whole, through the LDS bucket merge
     (or global atomics for the unbucketed form) -- what the multi-GPU exchange does after its all-gather"""
@@ -265,7 +265,7 @@ def test_merging_tables_bucket_by_bucket(log2_slots, log2_bucket):
     assert len(gc) == len(want.items()[0])
 
 
-@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 10), (20, 6), (18, 14), (17, 5)])
+@pytest.mark.parametrize("log2_slots,log2_bucket", [(18, 10), (20, 6), (18, 14), (17, 5), (22, 10), (25, 14)])
 def test_exchange_kernels_fill_compact_rebuild(log2_slots, log2_bucket):
     """the three launches of the multi-GPU exchange: per-bucket fills, bucket-ordered compaction into a padded gather
     buffer, and the rebuild of the table from all parts (own one included, old slots ignored)"""
@@ -300,7 +300,7 @@ def test_exchange_kernels_fill_compact_rebuild(log2_slots, log2_bucket):
     assert all(np.array_equal(x, y) for x, y in zip(out.items(), parts[0].items()))
 
 
-@pytest.mark.parametrize("log2_slots,log2_bucket,g", [(20, 10, 0), (20, 10, 1), (21, 9, 3), (22, 12, 2), (19, 10, 1)])
+@pytest.mark.parametrize("log2_slots,log2_bucket,g", [(20, 10, 0), (20, 10, 1), (21, 9, 3), (22, 12, 2), (19, 10, 1), (22, 10, 1), (23, 10, 2), (25, 14, 0), (25, 12, 3)])
 def test_deferred_count_gather_rebuild_equals_direct_count(log2_slots, log2_bucket, g):
     """multi-GPU counting form: the table (union geometry) is not written; groups of 2^g buckets are counted in LDS, the
     entries are gathered bucket by bucket and the table is rebuilt from them -- same table as counting into it directly,
