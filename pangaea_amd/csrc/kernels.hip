@@ -1252,6 +1252,88 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup_kernel(const uint64_t
     if (threadIdx.x == 0) emit_end[blockIdx.x] = (unsigned long long)r0 + emitted;
 }
 
+// S1 with a split LDS table (buckets >= 2^11): tags[] (the key's bits below the bucket id | 0x80000000) and, instead of the
+// counts, bins[] = count / window computed ONCE per slot while the slice is loaded (0xffff: bin >= vsize, never emitted).
+// A lookup is a 4-byte read and, on a hit, a 2-byte read; the division leaves the per-record path.
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup32_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                    HashView t, uint32_t window, uint32_t vsize, int vbits,
+                                                                    uint32_t *__restrict__ words, unsigned long long *__restrict__ emit_end)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ uint32_t emitted;
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    uint32_t *tags = reinterpret_cast<uint32_t *>(tab);
+    uint16_t *bins = reinterpret_cast<uint16_t *>(tags + n_slots);
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = KEY_BITS - t.log2_slots;
+    const int tag_bits = KEY_BITS - (t.log2_slots - t.log2_bucket);
+    const uint32_t tag_mask = (1u << tag_bits) - 1u;
+    const uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    if (threadIdx.x == 0) emitted = 0;
+    if (r0 == r1) { if (threadIdx.x == 0) emit_end[blockIdx.x] = (unsigned long long)r0; return; }
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint64_t v = slice[i];
+        const uint32_t bin = (uint32_t)(v & HASH_CMASK) / window;
+        tags[i] = v ? ((uint32_t)(v >> HASH_CBITS) & tag_mask) | 0x80000000u : 0u;
+        bins[i] = (uint16_t)(bin < vsize ? bin : 0xffffu);             // vsize <= PG_SHUFFLE_MAX_VSIZE = 512
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
+    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
+    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH], row[CNT_BATCH];
+        bool live[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            ulonglong2 v = make_ulonglong2(~0ull, ~0ull);            // a padding lane carries ROW_NONE
+            if (q < q1) v = rec2[q];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            row[2 * j] = (uint32_t)(v.x >> REC_KEY_BITS);
+            row[2 * j + 1] = (uint32_t)(v.y >> REC_KEY_BITS);
+            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
+            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
+            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
+            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
+            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
+        }
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            live[j] = live[j] && row[j] != ROW_NONE;
+            first[j] = live[j] ? tags[ss[j]] : 0u;
+        }
+#define PG_EMIT(J)                                                                                                          \
+        {                                                                                                                   \
+            uint32_t bin = 0xffffu;                                                                                         \
+            if (live[J]) {                                                                                                  \
+                uint32_t sl = ss[J], cur = first[J];                                                                        \
+                for (uint32_t i = 0; i < limit && cur != 0; ++i) {                                                          \
+                    if (cur == tg[J]) { bin = bins[sl]; break; }                                                            \
+                    sl = (sl + 1) & smask;                                                                                  \
+                    cur = tags[sl];                                                                                         \
+                }                                                                                                           \
+            }                                                                                                               \
+            const bool put = bin != 0xffffu;                                                                                \
+            const unsigned long long m = __ballot(put);                                                                     \
+            if (m) {                                                                                                        \
+                const int leader = __ffsll((long long)m) - 1;                                                               \
+                uint32_t at = 0;                                                                                            \
+                if ((int)lane == leader) at = atomicAdd(&emitted, (uint32_t)__popcll(m));                                   \
+                at = __shfl(at, leader);                                                                                    \
+                if (put) words[r0 + at + __popcll(m & ((1ull << lane) - 1ull))] = (row[J] << vbits) | bin;                  \
+            }                                                                                                               \
+        }
+        PG_EMIT(0) PG_EMIT(1) PG_EMIT(2) PG_EMIT(3) PG_EMIT(4) PG_EMIT(5) PG_EMIT(6) PG_EMIT(7)
+#undef PG_EMIT
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) emit_end[blockIdx.x] = (unsigned long long)r0 + emitted;
+}
+
 // capacity of every row group (64 rows): the rows' character counts bound their k-mer counts
 __global__ __launch_bounds__(BLOCK) void group_caps_kernel(const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end,
                                                            int64_t n_rows, int64_t n_groups_padded, unsigned long long *__restrict__ caps)
@@ -1909,6 +1991,11 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)caps, sp.n_groups_padded, goff);
     // S1: counts out of the LDS copies of the slices -> (row, bin) words, packed per bucket
     const int gshift = sp.vbits + GROUP_ROWS_LOG2;
+    if (KEY_BITS - p.bits <= 31 && !getenv("PG_B64")) {
+        if ((rc = raise_lds_limit((const void *)bucket_lookup32_kernel, slice_lds, "pg_abundance_from_records"))) return rc;
+        hipLaunchKernelGGL(bucket_lookup32_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, recs, off, view_of(t), (uint32_t)window, (uint32_t)vsize,
+                           sp.vbits, words_e, emit_end);
+    } else
     hipLaunchKernelGGL(bucket_lookup_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, recs, off, view_of(t), (uint32_t)window, (uint32_t)vsize, sp.vbits,
                        words_e, emit_end);
     // S2a: scatter the words by the first gb1 bits of their row group (global cursors: measured faster here than
