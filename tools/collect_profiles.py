@@ -28,8 +28,10 @@ KERNELS = [
     ("bucket_hist_kernel", "kmer_count", 2.0), ("scan_kernel", "kmer_count", 1.0), ("digit_scan_kernel", "kmer_count", 1.0),
     ("tile_rows_kernel", "kmer_count", 1.0), ("scatter_stream_kernel", "kmer_count", 1.0),
     ("scatter_records_kernel<unsigned long", "kmer_count", 2.0), ("bucket_count_kernel", "kmer_count", 2.0),
+    ("bucket_count32_kernel", "kmer_count", 2.0), ("bucket_count_compact32_kernel", "kmer_count", 2.0),
+    ("bucket_count_compact_kernel", "kmer_count", 2.0),
     ("kmer_count_kernel", "kmer_count", 1.0),
-    ("bucket_lookup_kernel", "features", 2.0), ("scatter_records_kernel<unsigned int", "features", 2.0),
+    ("bucket_lookup_kernel", "features", 2.0), ("bucket_lookup32_kernel", "features", 2.0), ("scatter_records_kernel<unsigned int", "features", 2.0),
     ("row_hist_kernel", "features", 2.0), ("group_caps_kernel", "features", 1.0),
     ("features_kernel<unsigned int, 0", "features", 2.0), ("features_kernel", "features", 1.0),
 ]
