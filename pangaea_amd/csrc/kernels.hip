@@ -585,7 +585,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
             for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += L.wave_tot[wv];
             L.start[threadIdx.x] = before + incl - v;
             if (threadIdx.x == BLOCK - 1) L.start[BLOCK] = before + incl;
-            if ((int)threadIdx.x < n_dig) { L.gbase[threadIdx.x] = L.cur[threadIdx.x]; L.cur[threadIdx.x] += v; }
+            // gbase[d] = (where the digit's run goes) - (where it starts in the tile): the copy-out adds the tile position
+            if ((int)threadIdx.x < n_dig) { L.gbase[threadIdx.x] = L.cur[threadIdx.x] - (before + incl - v); L.cur[threadIdx.x] += v; }
             __syncthreads();
         }
 #pragma unroll
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {
             const uint64_t r = buf[i];
             const uint32_t d = (uint32_t)((r & REC_KEY_MASK) >> dsh);
-            rec_out[L.gbase[d] + (i - L.start[d])] = r;
+            rec_out[L.gbase[d] + i] = r;
         }
         __syncthreads();
     }
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
         scatter_scan(L, n_dig);
         for (int d = threadIdx.x; d < n_dig; d += BLOCK) {          // cnt[] is gone (it shared gbase's storage): start[] has it
             const uint32_t c = L.start[d + 1] - L.start[d];
-            if (c) L.gbase[d] = obase[(base_index + d) << oshift] + atomicAdd(&cursor[base_index + d], (unsigned long long)c);
+            if (c) L.gbase[d] = obase[(base_index + d) << oshift] + atomicAdd(&cursor[base_index + d], (unsigned long long)c) - L.start[d];
         }
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {    // flat sweep: digit recomputed from the record
             const REC r = buf[i];
             const uint32_t d = digit_of(r);
-            rec_out[L.gbase[d] + (i - L.start[d])] = r;
+            rec_out[L.gbase[d] + i] = r;                            // gbase[d] = destination of the run - its start in the tile
         }
         __syncthreads();
     }
