@@ -224,6 +224,18 @@ int pg_kmer_count_deferred(const uint64_t *codes, const uint32_t *valid, int64_t
                            int64_t *fill, uint32_t *status, void *stream);
 int pg_deferred_gather(const pg_table *t, const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
                        const int64_t *fill, const int64_t *seg, uint64_t *out, void *stream);
+/* The 6-byte exchange format (tables of >= 2^11 buckets): inside its bucket an entry is a 4-byte tag (the key's bits
+ * below the bucket id) and a 2-byte count, sent in two planes; a count >= 0xffff sends 0xffff and its remainder as a whole
+ * 8-byte entry in `overflow` (merged afterwards with pg_kmer_merge; overflow_count is a device counter, status bit 1 is set
+ * when overflow_cap is too small).  tag_elem[b] / cnt_elem[b] = index of bucket b's first tag / count in the uint32 /
+ * uint16 view of `out`.  pg_kmer_rebuild_planes_range rebuilds buckets [bucket_begin, bucket_end) from the gathered
+ * planes: part p's tags at buf + p * part_stride_bytes, its counts 4 * cap bytes later, seg[p][j] = index of the first
+ * entry of bucket bucket_begin + j (bucket_end - bucket_begin + 1 entries per part). */
+int pg_deferred_gather_planes(const pg_table *t, const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                              const int64_t *fill, const int64_t *tag_elem, const int64_t *cnt_elem, void *out,
+                              uint64_t *overflow, uint64_t *overflow_count, int64_t overflow_cap, uint32_t *status, void *stream);
+int pg_kmer_rebuild_planes_range(const void *buf, int64_t part_stride_bytes, int64_t cap, const int64_t *seg, int n_parts,
+                                 const pg_table *t, int64_t bucket_begin, int64_t bucket_end, uint32_t *status, void *stream);
 int pg_table_compact(const pg_table *t, const int64_t *seg, uint64_t *out, void *stream);
 int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
                              uint32_t *status, void *stream);

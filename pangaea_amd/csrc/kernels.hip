@@ -980,6 +980,102 @@ __global__ __launch_bounds__(BLOCK) void deferred_gather_kernel(const uint64_t *
     for (long long i = threadIdx.x & 63; i < n; i += 64) dst[i] = src[i];
 }
 
+constexpr int MERGE_BATCH = 4;             // entries per lane in flight in the merge kernels
+
+// The exchange format: 6 bytes per entry instead of 8.  Inside bucket b a key is its bits below the bucket id (the tag, <= 31
+// bits for >= 2^11 buckets) and a count is almost always < 2^16, so an entry travels as a 4-byte tag and a 2-byte count in
+// two planes; a count >= 0xffff sends 0xffff there and the remainder as a full 8-byte entry in a (tiny) overflow list that
+// is merged afterwards -- sums are exact.  tag_elem[b] / cnt_elem[b]: where bucket b's first tag / count goes, in elements
+// of the uint32 / uint16 view of the send buffer.
+__global__ __launch_bounds__(BLOCK) void deferred_gather_planes_kernel(const uint64_t *__restrict__ scratch, const unsigned long long *__restrict__ off,
+                                                                       const long long *__restrict__ fill, const long long *__restrict__ tag_elem,
+                                                                       const long long *__restrict__ cnt_elem, int64_t n_buckets, uint32_t tag_mask,
+                                                                       uint32_t *__restrict__ out32, uint16_t *__restrict__ out16,
+                                                                       uint64_t *__restrict__ ovf, unsigned long long *__restrict__ ovf_count,
+                                                                       unsigned long long ovf_cap, uint32_t *status)
+{
+    const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (b >= n_buckets) return;
+    const uint64_t *src = scratch + off[b];
+    uint32_t *t32 = out32 + tag_elem[b];
+    uint16_t *c16 = out16 + cnt_elem[b];
+    const long long n = fill[b];
+    for (long long i = threadIdx.x & 63; i < n; i += 64) {
+        const uint64_t e = src[i];
+        const uint32_t c = (uint32_t)(e & HASH_CMASK);
+        t32[i] = (uint32_t)(e >> HASH_CBITS) & tag_mask;
+        c16[i] = (uint16_t)(c < 0xffffu ? c : 0xffffu);
+        if (c >= 0xffffu && c > 0xffffu) {                          // the remainder travels as a whole entry
+            const unsigned long long at = atomicAdd(ovf_count, 1ull);
+            if (at < ovf_cap) ovf[at] = (e & ~HASH_CMASK) | (uint64_t)(c - 0xffffu);
+            else atomicOr(status, 2u);
+        }
+    }
+}
+
+// rebuild of buckets [bucket_base, bucket_base + gridDim.x) from the gathered planes of n_parts ranks: part p's tags are at
+// buf + p * part_stride, its counts `cap` tags later; seg[p][j] = index of the first entry of bucket bucket_base + j
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_planes_kernel(const uint8_t *__restrict__ buf, int64_t part_stride, int64_t cap,
+                                                                        const long long *__restrict__ seg, int n_parts, HashView t,
+                                                                        uint32_t *status, int64_t bucket_base, int64_t n_seg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    uint32_t *tags = reinterpret_cast<uint32_t *>(tab), *cnts = tags + n_slots;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = KEY_BITS - t.log2_slots;
+    const int tag_bits = KEY_BITS - (t.log2_slots - t.log2_bucket);
+    const uint32_t tag_mask = (1u << tag_bits) - 1u;
+    const int64_t bucket = bucket_base + blockIdx.x;
+    uint64_t *slice = t.slots + ((uint64_t)bucket << t.log2_bucket);
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) { tags[i] = 0u; cnts[i] = 0u; }
+    __syncthreads();
+    bool full = false;
+    for (int p = 0; p < n_parts; ++p) {
+        const int64_t a = seg[p * (n_seg + 1) + blockIdx.x], b = seg[p * (n_seg + 1) + blockIdx.x + 1];
+        const uint32_t *pt = reinterpret_cast<const uint32_t *>(buf + p * part_stride);
+        const uint16_t *pc = reinterpret_cast<const uint16_t *>(buf + p * part_stride + 4 * cap);
+        for (int64_t base = a; base < b; base += (int64_t)BIG_BLOCK * MERGE_BATCH) {
+            uint32_t tg[MERGE_BATCH], add[MERGE_BATCH], ss[MERGE_BATCH], first[MERGE_BATCH];
+            bool live[MERGE_BATCH];
+#pragma unroll
+            for (int j = 0; j < MERGE_BATCH; ++j) {
+                const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+                live[j] = i < b;
+                tg[j] = live[j] ? pt[i] : 0u;
+                add[j] = live[j] ? (uint32_t)pc[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < MERGE_BATCH; ++j) {
+                ss[j] = (tg[j] >> hsh) & smask;                     // the slot index is the top bits of the tag
+                tg[j] = (tg[j] & tag_mask) | 0x80000000u;
+                first[j] = live[j] ? tags[ss[j]] : 0u;
+            }
+#define PG_MERGE(J)                                                                                                         \
+            if (live[J]) {                                                                                                  \
+                uint32_t sl = ss[J], cur = first[J];                                                                        \
+                bool done = false;                                                                                          \
+                for (uint32_t tries = 0; tries < limit && !done; ++tries) {                                                 \
+                    if (cur == 0) { cur = atomicCAS(&tags[sl], 0u, tg[J]); if (cur == 0) cur = tg[J]; }                     \
+                    if (cur == tg[J]) { atomicAdd(&cnts[sl], add[J]); done = true; }                                        \
+                    else { sl = (sl + 1) & smask; cur = tags[sl]; }                                                         \
+                }                                                                                                           \
+                full |= !done;                                                                                              \
+            }
+            PG_MERGE(0) PG_MERGE(1) PG_MERGE(2) PG_MERGE(3)
+#undef PG_MERGE
+        }
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    const uint64_t high = (uint64_t)bucket << tag_bits;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint32_t tg = tags[i], c = cnts[i];
+        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
+    }
+}
+
 // Bucket-wise merge of other tables into this one: the compacted tables of the other ranks arrive bucket by bucket
 // (a table's slots are laid out by bucket, so compaction keeps bucket order).  One workgroup per bucket loads its slice
 // into LDS, adds every foreign entry of that bucket (counts saturate exactly) and writes the slice back.
@@ -1005,7 +1101,6 @@ __device__ __forceinline__ bool lds_merge(unsigned long long *tab, uint32_t smas
     return false;
 }
 
-constexpr int MERGE_BATCH = 4;
 // The launch covers buckets [bucket_base, bucket_base + gridDim.x); seg has n_seg + 1 entries per part, entry j for
 // bucket bucket_base + j (a whole-table launch: base 0, n_seg = number of buckets).
 __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_kernel(const uint64_t *__restrict__ pairs, const long long *__restrict__ seg,
@@ -1734,6 +1829,49 @@ extern "C" int pg_deferred_gather(const pg_table *t, const void *count_workspace
                        (const uint64_t *)(ws + p.bufa_off), (const unsigned long long *)(ws + p.off_off), (const long long *)fill,
                        (const long long *)seg, nb, out);
     return check_launch("pg_deferred_gather");
+}
+
+extern "C" int pg_deferred_gather_planes(const pg_table *t, const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                                         const int64_t *fill, const int64_t *tag_elem, const int64_t *cnt_elem, void *out,
+                                         uint64_t *overflow, uint64_t *overflow_count, int64_t overflow_cap, uint32_t *status, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!count_workspace || !fill || !tag_elem || !cnt_elem || !out || !overflow || !overflow_count || !status)
+        return pg_fail(PG_EINVAL, "pg_deferred_gather_planes: null argument");
+    BucketPlan p;
+    if ((rc = plan_buckets(t, n_words_counted, &p))) return rc;
+    if (!p.bits2) return pg_fail(PG_EINVAL, "pg_deferred_gather_planes: the deferred form needs more than 256 buckets");
+    if (KEY_BITS - p.bits > 31) return pg_fail(PG_EINVAL, "pg_deferred_gather_planes: needs at least 2^11 buckets (tags of at most 31 bits)");
+    if ((int64_t)p.total > count_workspace_bytes) return pg_fail(PG_EINVAL, "pg_deferred_gather_planes: count workspace does not match n_words_counted");
+    const char *ws = (const char *)count_workspace;
+    const int64_t nb = (int64_t)1 << p.bits;
+    hipLaunchKernelGGL(deferred_gather_planes_kernel, dim3((unsigned)((nb + WAVES - 1) / WAVES)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint64_t *)(ws + p.bufa_off), (const unsigned long long *)(ws + p.off_off), (const long long *)fill,
+                       (const long long *)tag_elem, (const long long *)cnt_elem, nb, (uint32_t)((1u << (KEY_BITS - p.bits)) - 1u),
+                       (uint32_t *)out, (uint16_t *)out, overflow, (unsigned long long *)overflow_count, (unsigned long long)overflow_cap, status);
+    return check_launch("pg_deferred_gather_planes");
+}
+
+extern "C" int pg_kmer_rebuild_planes_range(const void *buf, int64_t part_stride_bytes, int64_t cap, const int64_t *seg, int n_parts,
+                                            const pg_table *t, int64_t bucket_begin, int64_t bucket_end, uint32_t *status, void *stream)
+{
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_HASH || t->log2_bucket_slots == 0 || t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS)
+        return pg_fail(PG_EINVAL, "pg_kmer_rebuild_planes_range: needs a bucketed hash table with LDS-sized buckets");
+    const int bits = t->log2_slots - t->log2_bucket_slots;
+    if (KEY_BITS - bits > 31) return pg_fail(PG_EINVAL, "pg_kmer_rebuild_planes_range: needs at least 2^11 buckets (tags of at most 31 bits)");
+    if (n_parts < 1 || !buf || !seg || !status || cap < 0 || part_stride_bytes < 6 * cap) return pg_fail(PG_EINVAL, "pg_kmer_rebuild_planes_range: bad arguments");
+    if (bucket_begin < 0 || bucket_end < bucket_begin || bucket_end > ((int64_t)1 << bits))
+        return pg_fail(PG_EINVAL, "pg_kmer_rebuild_planes_range: bucket range [%lld,%lld) outside the table", (long long)bucket_begin, (long long)bucket_end);
+    if (bucket_end == bucket_begin) return PG_OK;
+    const size_t lds = (size_t)8 << t->log2_bucket_slots;
+    if ((rc = raise_lds_limit((const void *)bucket_merge_planes_kernel, lds, "pg_kmer_rebuild_planes_range"))) return rc;
+    hipLaunchKernelGGL(bucket_merge_planes_kernel, dim3((unsigned)(bucket_end - bucket_begin)), dim3(BIG_BLOCK), lds, (hipStream_t)stream,
+                       (const uint8_t *)buf, part_stride_bytes, cap, (const long long *)seg, n_parts, view_of(t), status, bucket_begin,
+                       bucket_end - bucket_begin);
+    return check_launch("pg_kmer_rebuild_planes_range");
 }
 
 namespace {

@@ -189,6 +189,51 @@ def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_l
         table = KmerTable.wide_with_slots(k, stream.device, log2) if wide else KmerTable.with_slots(k, stream.device, log2)
 
 
+PLANES = True                # send deferred entries as 4-byte tags + 2-byte counts (6 B instead of 8 B per entry)
+
+
+def _exchange_planes(table: KmerTable, group, me: int, world: int, seg, cuts, at, sizes) -> None:
+    """the range-wise exchange in the 6-byte format: per bucket range every rank sends [tags uint32 x cap | counts uint16 x
+    cap] (cap = the longest part of that range, rounded to 8); counts >= 0xffff send their remainder in a small overflow
+    list of whole entries, merged at the end -- so the rebuilt counts are exact"""
+    dev = seg.device
+    n_ranges = len(cuts) - 1
+    nb = table.n_buckets
+    caps = [max(8, (int(c) + 7) // 8 * 8) for c in sizes.max(dim=0).values.cpu().tolist()]          # host sync: buffer sizes
+    stride = [6 * c for c in caps]                                   # bytes per rank and range (a multiple of 16)
+    base = [0]
+    for c in range(n_ranges):
+        base.append(base[-1] + stride[c])
+    # where bucket b's first tag / count goes, as elements of the uint32 / uint16 views of this rank's send buffer
+    which = torch.bucketize(torch.arange(nb, device=dev), torch.tensor(cuts[1:-1], device=dev, dtype=torch.int64), right=True)
+    j0 = seg[me, :-1] - at[me][which]
+    base_t = torch.tensor(base[:-1], device=dev, dtype=torch.int64)
+    caps_t = torch.tensor(caps, device=dev, dtype=torch.int64)
+    tag_elem = (base_t[which] // 4 + j0).contiguous()
+    cnt_elem = ((base_t[which] + 4 * caps_t[which]) // 2 + j0).contiguous()
+    mine = torch.empty(base[-1], dtype=torch.uint8, device=dev)
+    overflow = torch.empty(max(1 << 16, int(table.deferred_fill().numel())), dtype=torch.int64, device=dev)
+    n_over = torch.zeros(1, dtype=torch.int64, device=dev)
+    table.deferred_planes_into(mine, tag_elem, cnt_elem, overflow, n_over)
+    bufs, works = [], []
+    for c in range(n_ranges):
+        buf = torch.empty(world * stride[c], dtype=torch.uint8, device=dev)
+        works.append(_all_gather_flat(buf, mine[base[c]:base[c + 1]], group, async_op=True))
+        bufs.append(buf)
+    for c in range(n_ranges):
+        seg_c = (seg[:, cuts[c]:cuts[c + 1] + 1] - at[:, c:c + 1]).contiguous()
+        if works[c] is not None:
+            works[c].wait()
+        table.rebuild_from_planes(bufs[c], stride[c], caps[c], seg_c, (cuts[c], cuts[c + 1]))
+    # counts beyond 0xffff: their remainders, from every rank (this one included), as whole entries
+    n = int(n_over.item())
+    if n > overflow.numel():
+        raise RuntimeError(f"exchange overflow list too small ({n} entries)")
+    for part in gather_pairs(overflow[:n].contiguous(), group):
+        if part.numel():
+            table.merge(part, check=False)
+
+
 def _exchange_bucketed(table: KmerTable, group=None) -> None:
     """the exchange of a bucketed hash table (also callable in a one-rank group, which a one-GPU box can hold over RCCL)"""
     me = dist.get_rank(group)
@@ -212,6 +257,9 @@ def _exchange_bucketed(table: KmerTable, group=None) -> None:
     cuts = [nb * c // n_ranges for c in range(n_ranges + 1)]
     at = seg[:, cuts]                                                            # [world, n_ranges + 1]
     sizes = at[:, 1:] - at[:, :-1]
+    if table.pending and table.tag_bits <= 31 and PLANES:
+        _exchange_planes(table, group, me, world, seg, cuts, at, sizes)
+        return
     host = torch.cat([sizes.max(dim=0).values, at[me]]).cpu().tolist()          # the step's one host sync
     caps, mine_at = [max(int(c), 1) for c in host[:n_ranges]], host[n_ranges:]
     mine = torch.empty(int(mine_at[-1]) + max(caps), dtype=torch.int64, device=dev)   # slack: a range is sent padded

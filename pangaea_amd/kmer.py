@@ -351,6 +351,40 @@ class KmerTable:
             _lib.check(_lib.load().pg_deferred_gather(self.desc(), self._workspace.data_ptr(), self._workspace.numel(), n_words,
                                                       fill.data_ptr(), seg.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
 
+    @property
+    def tag_bits(self) -> int:
+        """bits of a key below its bucket id (the exchange sends entries as such tags when they fit 31 bits)"""
+        return 42 - (self.log2_slots - self.log2_bucket)
+
+    def deferred_planes_into(self, out: torch.Tensor, tag_elem: torch.Tensor, cnt_elem: torch.Tensor,
+                             overflow: torch.Tensor, overflow_count: torch.Tensor) -> None:
+        """the deferred count's entries in the 6-byte exchange format: bucket b's tags from element ``tag_elem[b]`` of the
+        uint32 view of ``out`` (a byte buffer), its counts from element ``cnt_elem[b]`` of the uint16 view; counts beyond
+        0xffff leave their remainder as whole entries in ``overflow`` (``overflow_count``: int64 device counter)"""
+        fill, n_words = self._deferred
+        _require_gpu(out, "the output")
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.data_ptr() % 16 == 0
+        assert tag_elem.dtype == cnt_elem.dtype == torch.int64 and tag_elem.numel() == cnt_elem.numel() == self.n_buckets
+        assert overflow.dtype == torch.int64 and overflow_count.dtype == torch.int64
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_deferred_gather_planes(self.desc(), self._workspace.data_ptr(), self._workspace.numel(), n_words,
+                                                             fill.data_ptr(), tag_elem.data_ptr(), cnt_elem.data_ptr(), out.data_ptr(),
+                                                             overflow.data_ptr(), overflow_count.data_ptr(), overflow.numel(),
+                                                             self.status.data_ptr(), _stream_ptr(self.device)))
+
+    def rebuild_from_planes(self, buf: torch.Tensor, part_stride: int, cap: int, seg: torch.Tensor, buckets: tuple) -> None:
+        """rebuild buckets ``[begin, end)`` from gathered 6-byte planes (``seg`` int64 [n_parts, end - begin + 1], indices
+        inside every part's range)"""
+        b0, b1 = buckets
+        _require_gpu(buf, "the gathered planes")
+        assert buf.dtype == torch.uint8 and seg.dtype == torch.int64 and seg.is_contiguous() and seg.shape[1] == b1 - b0 + 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_kmer_rebuild_planes_range(buf.data_ptr(), int(part_stride), int(cap), seg.data_ptr(), int(seg.shape[0]),
+                                                                self.desc(), b0, b1, self.status.data_ptr(), _stream_ptr(self.device)))
+        if b1 == self.n_buckets:
+            self._empty = False
+            self._deferred = None
+
     def rebuild_from(self, pairs: torch.Tensor, seg: torch.Tensor, check: bool = True, buckets: tuple | None = None) -> "KmerTable":
         """replace the table by the merge of ``seg.shape[0]`` bucket-ordered compacted tables of this geometry laid out in
         ``pairs`` (``seg`` int64 [n_parts, n_buckets + 1], absolute offsets): one workgroup per bucket, inside LDS.

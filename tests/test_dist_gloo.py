@@ -172,12 +172,21 @@ def _rccl_worker(rank, world, port):
         cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=24, n_genomes=3, genome_len=20_000, fragment=8_000, seed=51)
         s = synth.generate(cfg, device="cuda:0")
         want = kmer.KmerTable.with_slots(21, "cuda:0", 20, 0).count(s).items()
-        for deferred in (False, True):
-            table = kmer.KmerTable.with_slots(21, "cuda:0", 20, 10)
+        for deferred, log2_slots in ((False, 20), (True, 20), (True, 21)):       # 2^21 slots: 2048 buckets, the 6-byte format
+            table = kmer.KmerTable.with_slots(21, "cuda:0", log2_slots, 10)
             table.count(s, deferred_group=1) if deferred else table.count(s)
             pdist._exchange_bucketed(table)
             table.check_status()
             assert not table.pending and all(np.array_equal(x, y) for x, y in zip(table.items(), want))
+        # counts beyond 0xffff travel as 0xffff + a remainder in the overflow list: 3.1 M copies of one 21-mer
+        s2 = ReadStream.from_runs([("a", b"A" * 1_600_000 + b"N" + b"T" * 1_500_040 + b"N"), ("b", b"ACGT" * 600 + b"N")], device="cuda:0")
+        want2 = kmer.KmerTable.with_slots(21, "cuda:0", 21, 10).count(s2).items()
+        table = kmer.KmerTable.with_slots(21, "cuda:0", 21, 10)
+        table.count(s2, deferred_group=0)
+        pdist._exchange_bucketed(table)
+        table.check_status()
+        got2 = table.items()
+        assert np.array_equal(got2[0], want2[0]) and np.array_equal(got2[1], want2[1]) and got2[1].max() >= 1 << 21
     finally:
         dist.destroy_process_group()
 
@@ -195,8 +204,9 @@ def _exchange_worker(rank, world, port, outdir, deferred):
         s = synth.generate(cfg, device="cuda:0")
         cut = (s.n_words // 2 + 7) if world == 2 else s.n_words
         w0, w1 = (0, cut) if rank == 0 else (cut, s.n_words)
-        table = kmer.KmerTable.with_slots(21, "cuda:0", 20, 10)              # 1024 buckets: exchanged in four ranges
-        assert table.n_buckets >= 64 * pdist.EXCHANGE_RANGES
+        # 1024 / 2048 buckets: exchanged in four ranges; from 2^11 buckets on a deferred count travels in the 6-byte format
+        table = kmer.KmerTable.with_slots(21, "cuda:0", 21 if deferred == "planes" else 20, 10)
+        assert table.n_buckets >= 64 * pdist.EXCHANGE_RANGES and (table.tag_bits <= 31) == (deferred == "planes")
         if deferred:
             table.count(s, w0, w1, deferred_group=1)
             assert table.pending
@@ -211,7 +221,7 @@ def _exchange_worker(rank, world, port, outdir, deferred):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("deferred", [False, True])
+@pytest.mark.parametrize("deferred", [False, True, "planes"])
 def test_two_ranks_exchange_in_bucket_ranges(tmp_path, deferred):
     """each rank counts half of a stream (directly / in deferred form); after the exchange -- fills, compaction, four
     range-wise gathers and LDS rebuilds -- both hold the table of the whole stream"""

@@ -54,7 +54,11 @@ print(f"{world} shards x {args.pairs} pairs: ~{local / 1e6:.0f} M distinct per s
       f"({table.data.numel() * 8 / 1e9:.1f} GB, load {est / table.data.numel():.2f}), {nb} buckets, deferred groups of 2^{g}", flush=True)
 
 fills = torch.zeros((world, nb), dtype=torch.int64, device=dev)
+planes = table.tag_bits <= 31            # the 6-byte exchange format (4-byte tags + 2-byte counts)
 parts = []
+plane_parts = []
+overflow = torch.empty(1 << 20, dtype=torch.int64, device=dev)
+n_over = torch.zeros(1, dtype=torch.int64, device=dev)
 for r in reversed(range(world)):            # shard 0 last: its stream, plan and records stay for the timings below
     s = shard(r)
     rows = s.rows(2000)
@@ -65,6 +69,11 @@ for r in reversed(range(world)):            # shard 0 last: its stream, plan and
     part = torch.empty(int(fills[r].sum()), dtype=torch.int64, device=dev)
     table.deferred_compact_into(part, seg_r)
     parts.append((r, part))
+    if planes:
+        cap_r = (int(fills[r].sum()) + 7) // 8 * 8
+        pl = torch.empty(6 * cap_r, dtype=torch.uint8, device=dev)
+        table.deferred_planes_into(pl, seg_r[:-1].contiguous(), (seg_r[:-1] + 2 * cap_r).contiguous(), overflow, n_over)
+        plane_parts.append((r, cap_r, pl))
 cap = max(p.numel() for _, p in parts)
 buf = torch.empty(world * cap, dtype=torch.int64, device=dev)
 for r, p in parts:
@@ -83,6 +92,23 @@ timed("gather of the entries out of the workspace", lambda: table.deferred_compa
 timed(f"rebuild from {world} parts", lambda: table.rebuild_from(buf, seg, check=False), reps=2)
 table.check_status()
 print(f"  load of the rebuilt table {table.occupancy():.3f}")
+if planes:
+    want = torch.sort(table.compact()).values
+    cap6 = max(c for _, c, _ in plane_parts)
+    buf6 = torch.zeros(world * 6 * cap6, dtype=torch.uint8, device=dev)
+    for r, cap_r, pl in plane_parts:          # re-lay every part with the common cap (tags | counts)
+        buf6[r * 6 * cap6:r * 6 * cap6 + 4 * cap_r] = pl[:4 * cap_r]
+        buf6[r * 6 * cap6 + 4 * cap6:r * 6 * cap6 + 4 * cap6 + 2 * cap_r] = pl[4 * cap_r:]
+    del plane_parts
+    seg6 = (seg - torch.arange(world, device=dev)[:, None] * cap).contiguous()
+    mine6 = torch.empty(6 * cap6, dtype=torch.uint8, device=dev)
+    table.reset().count(s, check=False, rows=plan, deferred_group=g)
+    te, ce = seg6[0, :-1].contiguous(), (seg6[0, :-1] + 2 * cap6).contiguous()
+    timed("gather of the entries as 6-byte planes", lambda: table.deferred_planes_into(mine6, te, ce, overflow, n_over.zero_()))
+    timed(f"rebuild from {world} parts of 6-byte planes", lambda: table.rebuild_from_planes(buf6, 6 * cap6, cap6, seg6, (0, nb)), reps=2)
+    table.check_status()
+    print(f"  (6-byte payload: {6 * cap6 / 1e9:.2f} GB per rank, {6 * cap6 * (world - 1) / 1e9:.2f} GB received; overflow entries {int(n_over.item())}); "
+          f"same table as from 8-byte entries: {bool(torch.equal(torch.sort(table.compact()).values, want))}")
 tnf = torch.zeros((len(rows), kmer.tnf_ncols(4)), dtype=torch.int32, device=dev)
 abd = torch.zeros((len(rows), 400), dtype=torch.int32, device=dev)
 timed("K1 + K3 (records -> LDS lookups -> row shuffle)", lambda: kmer.features(s, plan, k_tnf=4, table=table, window=10, vsize=400, out_tnf=tnf, out_abd=abd))
