@@ -123,6 +123,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29599")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if args.rehearse_dist >= 4:
+            from pangaea_amd import dist as _pd
+            _pd.OWNER_MIN_WORLD = 1          # the owner-partitioned exchange (all-to-all + all-gather), as 4+ ranks run it
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":

@@ -236,6 +236,13 @@ int pg_deferred_gather_planes(const pg_table *t, const void *count_workspace, in
                               uint64_t *overflow, uint64_t *overflow_count, int64_t overflow_cap, uint32_t *status, void *stream);
 int pg_kmer_rebuild_planes_range(const void *buf, int64_t part_stride_bytes, int64_t cap, const int64_t *seg, int n_parts,
                                  const pg_table *t, int64_t bucket_begin, int64_t bucket_end, uint32_t *status, void *stream);
+/* For the owner-partitioned exchange (>= 4 ranks): a rank that has merged its own bucket range sends that range on.
+ * fill[j] = occupied slots of bucket bucket_begin + j; the compaction writes the range in the 6-byte format, tag_elem /
+ * cnt_elem indexed by j. */
+int pg_table_bucket_fill_range(const pg_table *t, int64_t bucket_begin, int64_t bucket_end, int64_t *fill, void *stream);
+int pg_table_compact_planes_range(const pg_table *t, int64_t bucket_begin, int64_t bucket_end, const int64_t *tag_elem,
+                                  const int64_t *cnt_elem, void *out, uint64_t *overflow, uint64_t *overflow_count,
+                                  int64_t overflow_cap, uint32_t *status, void *stream);
 int pg_table_compact(const pg_table *t, const int64_t *seg, uint64_t *out, void *stream);
 int pg_kmer_rebuild_bucketed(const uint64_t *pairs, const int64_t *seg, int n_parts, const pg_table *t,
                              uint32_t *status, void *stream);

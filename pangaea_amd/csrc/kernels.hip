@@ -1267,6 +1267,47 @@ __global__ __launch_bounds__(BLOCK) void table_compact_kernel(const uint64_t *__
     }
 }
 
+// the occupied slots of the launch's buckets (slots points at the first of them) in the 6-byte exchange format: bucket j's
+// tags from element tag_elem[j] of the uint32 view of the buffer, its counts from element cnt_elem[j] of the uint16 view;
+// remainders of counts >= 0xffff go to the overflow list as whole entries
+__global__ __launch_bounds__(BLOCK) void table_compact_planes_kernel(const uint64_t *__restrict__ slots, int log2_bucket,
+                                                                     const long long *__restrict__ tag_elem, const long long *__restrict__ cnt_elem,
+                                                                     uint32_t tag_mask, uint32_t *__restrict__ out32, uint16_t *__restrict__ out16,
+                                                                     uint64_t *__restrict__ ovf, unsigned long long *__restrict__ ovf_count,
+                                                                     unsigned long long ovf_cap, uint32_t *status)
+{
+    __shared__ uint32_t cursor;
+    if (threadIdx.x == 0) cursor = 0;
+    __syncthreads();
+    const uint64_t *slice = slots + ((uint64_t)blockIdx.x << log2_bucket);
+    uint32_t *t32 = out32 + tag_elem[blockIdx.x];
+    uint16_t *c16 = out16 + cnt_elem[blockIdx.x];
+    const uint32_t n = 1u << log2_bucket;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = 0; base < n; base += BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? slice[i] : 0ull;
+        const unsigned long long m = __ballot(v != 0);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t at = 0;
+            if ((int)lane == leader) at = atomicAdd(&cursor, (uint32_t)__popcll(m));
+            at = __shfl(at, leader);
+            if (v != 0) {
+                const uint32_t j = at + __popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t c = (uint32_t)(v & HASH_CMASK);
+                t32[j] = (uint32_t)(v >> HASH_CBITS) & tag_mask;
+                c16[j] = (uint16_t)(c < 0xffffu ? c : 0xffffu);
+                if (c > 0xffffu) {
+                    const unsigned long long o = atomicAdd(ovf_count, 1ull);
+                    if (o < ovf_cap) ovf[o] = (v & ~HASH_CMASK) | (uint64_t)(c - 0xffffu);
+                    else atomicOr(status, 2u);
+                }
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------- K3 by shuffle
 
 // count of one record's code in the LDS copy of its bucket slice, starting from an already fetched first slot
@@ -2059,6 +2100,37 @@ extern "C" int pg_table_bucket_fill(const pg_table *t, int64_t *fill, void *stre
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(1u << (t->log2_slots - t->log2_bucket_slots)), dim3(BLOCK), 0, (hipStream_t)stream,
                        (const uint64_t *)t->data, t->log2_bucket_slots, (long long *)fill);
     return check_launch("pg_table_bucket_fill");
+}
+
+extern "C" int pg_table_bucket_fill_range(const pg_table *t, int64_t bucket_begin, int64_t bucket_end, int64_t *fill, void *stream)
+{
+    int rc = check_bucketed(t, "pg_table_bucket_fill_range");
+    if (rc) return rc;
+    const int64_t nb = (int64_t)1 << (t->log2_slots - t->log2_bucket_slots);
+    if (!fill || bucket_begin < 0 || bucket_end < bucket_begin || bucket_end > nb) return pg_fail(PG_EINVAL, "pg_table_bucket_fill_range: bad arguments");
+    if (bucket_end == bucket_begin) return PG_OK;
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3((unsigned)(bucket_end - bucket_begin)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint64_t *)t->data + ((uint64_t)bucket_begin << t->log2_bucket_slots), t->log2_bucket_slots, (long long *)fill);
+    return check_launch("pg_table_bucket_fill_range");
+}
+
+extern "C" int pg_table_compact_planes_range(const pg_table *t, int64_t bucket_begin, int64_t bucket_end, const int64_t *tag_elem,
+                                             const int64_t *cnt_elem, void *out, uint64_t *overflow, uint64_t *overflow_count,
+                                             int64_t overflow_cap, uint32_t *status, void *stream)
+{
+    int rc = check_bucketed(t, "pg_table_compact_planes_range");
+    if (rc) return rc;
+    const int bits = t->log2_slots - t->log2_bucket_slots;
+    if (KEY_BITS - bits > 31) return pg_fail(PG_EINVAL, "pg_table_compact_planes_range: needs at least 2^11 buckets (tags of at most 31 bits)");
+    if (!tag_elem || !cnt_elem || !out || !overflow || !overflow_count || !status || bucket_begin < 0 || bucket_end < bucket_begin ||
+        bucket_end > ((int64_t)1 << bits))
+        return pg_fail(PG_EINVAL, "pg_table_compact_planes_range: bad arguments");
+    if (bucket_end == bucket_begin) return PG_OK;
+    hipLaunchKernelGGL(table_compact_planes_kernel, dim3((unsigned)(bucket_end - bucket_begin)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint64_t *)t->data + ((uint64_t)bucket_begin << t->log2_bucket_slots), t->log2_bucket_slots,
+                       (const long long *)tag_elem, (const long long *)cnt_elem, (uint32_t)((1u << (KEY_BITS - bits)) - 1u), (uint32_t *)out,
+                       (uint16_t *)out, overflow, (unsigned long long *)overflow_count, (unsigned long long)overflow_cap, status);
+    return check_launch("pg_table_compact_planes_range");
 }
 
 extern "C" int pg_table_compact(const pg_table *t, const int64_t *seg, uint64_t *out, void *stream)

@@ -245,9 +245,10 @@ class KmerTable:
         if self.kind != "dense" and int(self.status[0].item()) != 0:
             raise _lib.PangaeaError(_lib.PG_ETABLEFULL, f"hash table with 2^{self.log2_slots} slots is full")
 
-    def merge(self, pairs: torch.Tensor, check: bool = True) -> "KmerTable":
+    def merge(self, pairs: torch.Tensor, check: bool = True, pending_ok: bool = False) -> "KmerTable":
         """add (key << 22 | count) pairs (slot format, key = key42(code)), e.g. the compacted table of another GPU"""
-        self._require_counts()
+        if not pending_ok:
+            self._require_counts()
         if self.kind != "hash":
             raise ValueError("merge() is for hash tables; dense tables are summed with all_reduce")
         pairs = pairs.to(self.device, torch.int64).contiguous()
@@ -372,7 +373,33 @@ class KmerTable:
                                                              overflow.data_ptr(), overflow_count.data_ptr(), overflow.numel(),
                                                              self.status.data_ptr(), _stream_ptr(self.device)))
 
-    def rebuild_from_planes(self, buf: torch.Tensor, part_stride: int, cap: int, seg: torch.Tensor, buckets: tuple) -> None:
+    def bucket_fill_range(self, buckets: tuple) -> torch.Tensor:
+        """occupied slots of buckets ``[begin, end)`` (int64 [end - begin]); the rest of the table is not read"""
+        b0, b1 = buckets
+        fill = torch.empty(b1 - b0, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_table_bucket_fill_range(self.desc(), b0, b1, fill.data_ptr(), _stream_ptr(self.device)))
+        return fill
+
+    def compact_planes_range(self, buckets: tuple, out: torch.Tensor, tag_elem: torch.Tensor, cnt_elem: torch.Tensor,
+                             overflow: torch.Tensor, overflow_count: torch.Tensor) -> None:
+        """buckets ``[begin, end)`` of the table in the 6-byte exchange format (as ``deferred_planes_into``; the element
+        indices are per bucket of the range)"""
+        b0, b1 = buckets
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.data_ptr() % 16 == 0
+        assert tag_elem.dtype == cnt_elem.dtype == torch.int64 and tag_elem.numel() == cnt_elem.numel() == b1 - b0
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pg_table_compact_planes_range(self.desc(), b0, b1, tag_elem.data_ptr(), cnt_elem.data_ptr(), out.data_ptr(),
+                                                                 overflow.data_ptr(), overflow_count.data_ptr(), overflow.numel(),
+                                                                 self.status.data_ptr(), _stream_ptr(self.device)))
+
+    def mark_rebuilt(self) -> None:
+        """every bucket range has been rebuilt: the table holds counts again"""
+        self._empty = False
+        self._deferred = None
+
+    def rebuild_from_planes(self, buf: torch.Tensor, part_stride: int, cap: int, seg: torch.Tensor, buckets: tuple,
+                            in_order: bool = True) -> None:
         """rebuild buckets ``[begin, end)`` from gathered 6-byte planes (``seg`` int64 [n_parts, end - begin + 1], indices
         inside every part's range)"""
         b0, b1 = buckets
@@ -381,9 +408,8 @@ class KmerTable:
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().pg_kmer_rebuild_planes_range(buf.data_ptr(), int(part_stride), int(cap), seg.data_ptr(), int(seg.shape[0]),
                                                                 self.desc(), b0, b1, self.status.data_ptr(), _stream_ptr(self.device)))
-        if b1 == self.n_buckets:
-            self._empty = False
-            self._deferred = None
+        if in_order and b1 == self.n_buckets:       # ranges rebuilt in another order: the caller calls mark_rebuilt()
+            self.mark_rebuilt()
 
     def rebuild_from(self, pairs: torch.Tensor, seg: torch.Tensor, check: bool = True, buckets: tuple | None = None) -> "KmerTable":
         """replace the table by the merge of ``seg.shape[0]`` bucket-ordered compacted tables of this geometry laid out in

@@ -178,6 +178,14 @@ def _rccl_worker(rank, world, port):
             pdist._exchange_bucketed(table)
             table.check_status()
             assert not table.pending and all(np.array_equal(x, y) for x, y in zip(table.items(), want))
+        # the owner-partitioned form over RCCL (all-to-all + all-gather), as far as one rank can show it
+        pdist.OWNER_MIN_WORLD = 1
+        table = kmer.KmerTable.with_slots(21, "cuda:0", 21, 10)
+        table.count(s, deferred_group=1)
+        pdist._exchange_bucketed(table)
+        table.check_status()
+        assert not table.pending and all(np.array_equal(x, y) for x, y in zip(table.items(), want))
+        pdist.OWNER_MIN_WORLD = 4
         # counts beyond 0xffff travel as 0xffff + a remainder in the overflow list: 3.1 M copies of one 21-mer
         s2 = ReadStream.from_runs([("a", b"A" * 1_600_000 + b"N" + b"T" * 1_500_040 + b"N"), ("b", b"ACGT" * 600 + b"N")], device="cuda:0")
         want2 = kmer.KmerTable.with_slots(21, "cuda:0", 21, 10).count(s2).items()
@@ -200,10 +208,12 @@ def _exchange_worker(rank, world, port, outdir, deferred):
     _init(rank, world, port)
     try:
         torch.cuda.set_device(0)
+        if world == 3:
+            pdist.OWNER_MIN_WORLD = 3          # uneven owner ranges (2048 buckets over 3 owners)
         cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=24, n_genomes=3, genome_len=20_000, fragment=8_000, seed=51)
         s = synth.generate(cfg, device="cuda:0")
-        cut = (s.n_words // 2 + 7) if world == 2 else s.n_words
-        w0, w1 = (0, cut) if rank == 0 else (cut, s.n_words)
+        bounds = [0] + [s.n_words * (r + 1) // world + 7 * (r + 1) for r in range(world - 1)] + [s.n_words]
+        w0, w1 = bounds[rank], bounds[rank + 1]
         # 1024 / 2048 buckets: exchanged in four ranges; from 2^11 buckets on a deferred count travels in the 6-byte format
         table = kmer.KmerTable.with_slots(21, "cuda:0", 21 if deferred == "planes" else 20, 10)
         assert table.n_buckets >= 64 * pdist.EXCHANGE_RANGES and (table.tag_bits <= 31) == (deferred == "planes")
@@ -216,6 +226,18 @@ def _exchange_worker(rank, world, port, outdir, deferred):
         assert not table.pending
         c, n = table.items()
         np.savez(os.path.join(outdir, f"t{rank}.npz"), c=c, n=n)
+        if deferred == "planes":
+            # counts beyond 0xffff (3.1 M copies of one 21-mer on EVERY rank): 0xffff in the planes + remainders in the overflow
+            # lists, in both phases of the owner-partitioned form; the sum saturates exactly
+            s2 = ReadStream.from_runs([("a", b"A" * 1_600_000 + b"N" + b"T" * 1_500_040 + b"N"), ("b", b"ACGT" * 600 + b"N")], device="cuda:0")
+            want = kmer.KmerTable.with_slots(21, "cuda:0", 21, 10)
+            for _ in range(world):
+                want.count(s2)
+            table = kmer.KmerTable.with_slots(21, "cuda:0", 21, 10)
+            table.count(s2, deferred_group=0)
+            pdist.exchange_table(table)
+            got, exp = table.items(), want.items()
+            assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and got[1].max() == 1 << 21
     finally:
         dist.destroy_process_group()
 
@@ -225,10 +247,22 @@ def _exchange_worker(rank, world, port, outdir, deferred):
 def test_two_ranks_exchange_in_bucket_ranges(tmp_path, deferred):
     """each rank counts half of a stream (directly / in deferred form); after the exchange -- fills, compaction, four
     range-wise gathers and LDS rebuilds -- both hold the table of the whole stream"""
-    _spawn(_exchange_worker, 2, str(tmp_path), deferred)
+    _check_exchange(tmp_path, 2, deferred)
+
+
+def _check_exchange(tmp_path, world, deferred):
+    _spawn(_exchange_worker, world, str(tmp_path), deferred)
     cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=24, n_genomes=3, genome_len=20_000, fragment=8_000, seed=51)
     s = synth.generate(cfg, device="cuda:0")
     want = kmer.KmerTable.with_slots(21, "cuda:0", 20, 0).count(s).items()
-    for r in range(2):
+    for r in range(world):
         got = np.load(str(tmp_path / f"t{r}.npz"))
         assert np.array_equal(got["c"], want[0]) and np.array_equal(got["n"], want[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 3])
+def test_owner_partitioned_exchange(tmp_path, world):
+    """from four ranks on the partial tables are reduced at bucket-range owners (all-to-all, LDS rebuild of the owned range)
+    and the merged ranges are all-gathered; every rank ends with the table of the whole stream (3 ranks: uneven ranges)"""
+    _check_exchange(tmp_path, world, "planes")
