@@ -242,7 +242,9 @@ def main():
             "config": {"workload": f"synthetic {args.pairs} x 150 bp read pairs and {n_bc} barcodes per GPU, k=21 hash table "
                                    f"(2^{table.log2_slots} slots), TNF k=4 + abundance V=400 W=10, L1-normalise, VAE 536-512-512-32 encode",
                        "pairs_per_gpu": args.pairs, "barcodes_per_gpu": n_bc, "rows_per_gpu": len(rows),
-                       "parallelism": (f"run-sharded x{world}, deferred count, range-wise table all-gather overlapped with LDS rebuilds ({args.backend})" if world > 1
+                       "parallelism": (f"run-sharded x{world}, deferred count, " + ("owner-partitioned table exchange (all-to-all + all-gather of merged ranges, 6-byte entries)"
+                                                                                    if world >= 4 else "range-wise table all-gather (6-byte entries) overlapped with LDS rebuilds")
+                                       + f" ({args.backend})" if world > 1
                                        else f"REHEARSAL of the {args.rehearse_dist}-rank path on one GPU (one-rank RCCL group)" if multi else "single GPU"),
                        "input": "packed reads resident in HBM", "table_load": table_load,
                        "table_buckets": table.n_buckets, "bucket_slots": 1 << table.log2_bucket if table.log2_bucket else None},
