@@ -39,7 +39,10 @@ class KmerTable:
     many int32 counts in the same tensor; direct kernels only.
     """
 
-    WORKSPACE_BUDGET = 96 << 30          # bytes of scratch one bucketed launch may use; longer streams go in pieces
+    # bytes of scratch one bucketed launch may use (longer streams are counted in pieces): two 8-byte record buffers now, the
+    # row shuffle adds half as much again later -- 132 GiB + 66 GiB + table + stream stay inside 288 GB of HBM and cover the
+    # 25 M-pair share of BASELINE config 3 in one piece
+    WORKSPACE_BUDGET = 132 << 30
 
     def __init__(self, k: int, kind: str, data: torch.Tensor, log2_slots: int = 0, log2_bucket: int = 0):
         self.k, self.kind, self.data, self.log2_slots, self.log2_bucket = int(k), kind, data, int(log2_slots), int(log2_bucket)
