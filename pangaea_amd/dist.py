@@ -297,20 +297,40 @@ def _exchange_owner(table: KmerTable, group, me: int, world: int, seg) -> None:
     fills2 = torch.empty((world, longest), dtype=torch.int64, device=dev)
     _all_gather_flat(fills2.view(-1), fill2, group)
     ends2 = torch.cumsum(fills2, dim=1)
-    cap2 = max(8, (int(ends2[:, -1].max().item()) + 7) // 8 * 8)                 # host sync: buffer size
-    s2 = 6 * cap2
     seg2 = torch.zeros((world, longest + 1), dtype=torch.int64, device=dev)
     seg2[:, 1:] = ends2
-    send2 = torch.empty(s2, dtype=torch.uint8, device=dev)
+    # the merged ranges travel in EXCHANGE_RANGES chunks (sub-ranges of every owner's range), all issued at once on RCCL's
+    # stream: the rebuild of one chunk runs while the next is still in flight
+    n_chunks = EXCHANGE_RANGES if longest >= 64 * EXCHANGE_RANGES else 1
+    local = [[(cuts[o + 1] - cuts[o]) * c // n_chunks for c in range(n_chunks + 1)] for o in range(world)]      # per owner, in its own buckets
+    at2 = torch.stack([seg2[o, local[o]] for o in range(world)])                 # [owner, n_chunks + 1]
+    caps2 = [max(8, (int(v) + 7) // 8 * 8) for v in (at2[:, 1:] - at2[:, :-1]).max(dim=0).values.cpu().tolist()]   # host sync: buffer sizes
+    stride2 = [6 * c for c in caps2]
+    base2 = [0]
+    for c in range(n_chunks):
+        base2.append(base2[-1] + stride2[c])
+    which2 = torch.bucketize(torch.arange(n_mine, device=dev), torch.tensor(local[me][1:-1], device=dev, dtype=torch.int64), right=True)
+    j2 = seg2[me, :n_mine] - at2[me][which2]
+    base2_t = torch.tensor(base2[:-1], device=dev, dtype=torch.int64)
+    caps2_t = torch.tensor(caps2, device=dev, dtype=torch.int64)
+    send2 = torch.empty(base2[-1], dtype=torch.uint8, device=dev)
     n_over.zero_()
-    table.compact_planes_range(mine, send2, seg2[me, :n_mine].contiguous(), (seg2[me, :n_mine] + 2 * cap2).contiguous(), overflow, n_over)
-    recv2 = torch.empty(world * s2, dtype=torch.uint8, device=dev)
-    _all_gather_flat(recv2, send2, group)
-    for o in range(world):
-        if o != me and cuts[o + 1] > cuts[o]:
-            n_o = cuts[o + 1] - cuts[o]
-            table.rebuild_from_planes(recv2[o * s2:(o + 1) * s2], s2, cap2, seg2[o:o + 1, :n_o + 1].contiguous(), (cuts[o], cuts[o + 1]),
-                                      in_order=False)
+    table.compact_planes_range(mine, send2, (base2_t[which2] // 4 + j2).contiguous(),
+                               ((base2_t[which2] + 4 * caps2_t[which2]) // 2 + j2).contiguous(), overflow, n_over)
+    bufs, works = [], []
+    for c in range(n_chunks):
+        buf = torch.empty(world * stride2[c], dtype=torch.uint8, device=dev)
+        works.append(_all_gather_flat(buf, send2[base2[c]:base2[c + 1]], group, async_op=True))
+        bufs.append(buf)
+    for c in range(n_chunks):
+        if works[c] is not None:
+            works[c].wait()
+        for o in range(world):
+            lo, hi = local[o][c], local[o][c + 1]
+            if o != me and hi > lo:
+                seg_o = (seg2[o:o + 1, lo:hi + 1] - at2[o, c]).contiguous()
+                table.rebuild_from_planes(bufs[c][o * stride2[c]:(o + 1) * stride2[c]], stride2[c], caps2[c], seg_o,
+                                          (cuts[o] + lo, cuts[o] + hi), in_order=False)
     table.mark_rebuilt()
     for r, part in enumerate(_gather_overflow(overflow, n_over, group)):        # the owners' remainders: ranges this rank does not own
         if r != me and part.numel():
