@@ -169,9 +169,15 @@ def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_l
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         return int(flag.item()) != 0
 
+    def everyone(flag: bool) -> bool:
+        t = _staged(torch.tensor([1 if flag else 0], dtype=torch.int32, device=stream.device), group)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(t.item())
+
     while True:
         g = deferred_group_for(table, int(1.1 * local)) if kind == "hash" else None
-        if g is not None and table.can_defer(stream.n_words):
+        # the exchange takes different collectives for deferred and materialised counts: all ranks must take the same form
+        if everyone(g is not None and table.can_defer(stream.n_words)):
             table.count(stream, rows=rows, deferred_group=g, check=False)
         else:
             table.count(stream, rows=rows, check=False)
