@@ -519,3 +519,23 @@ def test_row_shuffle_one_pass_and_two_pass_forms(n_barcodes, force_two, monkeypa
     _, abd = kmer.features(s, plan, k_tnf=None, table=table, window=3, vsize=400)
     _, abd2 = kmer.features(s, rows, k_tnf=None, table=table, window=3, vsize=400)
     assert torch.equal(abd, abd2) and int(abd.sum()) > 0
+
+
+def test_mid_scale_table_and_rows_against_oracle():
+    """200 k pairs (52 M k-mer occurrences, 2^15-bucket geometry with the split 32-bit LDS tables, one-pass row shuffle): the
+    whole multiplicity table equals the oracle's, and so do the TNF / abundance rows of a spread of barcodes"""
+    cfg = synth.SynthConfig(n_pairs=200_000, n_barcodes=1000, n_genomes=8, genome_len=400_000, fragment=40_000, sub_rate=0.002, n_rate=0.01, seed=71)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    table = kmer.KmerTable.with_slots(21, DEV, 29, 14).count(s, rows=plan)         # the bench's geometry
+    assert table.tag_bits <= 31 and table.has_records_for(plan, 400)
+    tnf, abd = kmer.features(s, plan, k_tnf=4, table=table, window=10, vsize=400)
+    text = s.decode()
+    otab = oracle.Table(21, threads=8).count(text)
+    assert all(np.array_equal(x, y) for x, y in zip(table.items(), otab.items()))
+    pick = list(range(0, len(rows), max(1, len(rows) // 25)))
+    for i in pick:
+        seq = text[int(rows.start[i]):int(rows.end[i])]
+        assert np.array_equal(tnf[i].cpu().numpy(), oracle.tnf_row(seq, 4))
+        assert np.array_equal(abd[i].cpu().numpy(), oracle.abd_row(seq, 21, otab, 10, 400))
