@@ -34,8 +34,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec
 #   stream  : 302 characters x (2-bit code + 1-bit validity) = 113.25 B
 #   K2 hash : stream + n_k x 16 B (8-B slot read + 8-B slot write-back)      = 4273.25 B
 #   K3 hash : stream + n_k x 8 B (slot read) + (136+400) x 4 B / 200 pairs   = 2203.97 B
+# One GPU runs K3's table lookups INSIDE the K2 kernel pass (a bucket's records are looked up while its counts are still in
+# LDS): the n_k x 8 B of slot reads then belong to the stage that does them, "kmer_count+lookup"; what is left of K3 (row
+# shuffle, row histograms, TNF) only owes the stream and the output rows.
 STREAM_B = 302 * 3 / 8
 ALG_BYTES = {"kmer_count": STREAM_B + 260 * 16, "features": STREAM_B + 260 * 8 + (136 + 400) * 4 / 200}
+ALG_BYTES_FUSED = {"kmer_count+lookup": STREAM_B + 260 * 16 + 260 * 8, "features": STREAM_B + (136 + 400) * 4 / 200}
 
 
 def parse_args():
@@ -49,6 +53,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-dist", type=int, default=0, metavar="N",
                     help="one GPU: run the N-rank code path (deferred count, exchange over a one-rank RCCL group, table sized for N shards) -- not a result")
+    ap.add_argument("--no-fuse", action="store_true", help="N = 1: separate count and lookup kernels (as N > 1 must run them)")
     ap.add_argument("--no-defer", action="store_true", help="N > 1: write every rank's own table and compact it (instead of the deferred count)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     return ap.parse_args()
@@ -167,14 +172,19 @@ def main():
     vae.network.eval()
     names = np.array(rows.names, dtype=object)
 
-    ev = {k: [] for k in (("kmer_count", "exchange", "features") if multi else ("kmer_count", "features"))}
+    fused = not multi and not args.no_fuse
+    k2 = "kmer_count+lookup" if fused else "kmer_count"
+    alg = ALG_BYTES_FUSED if fused else ALG_BYTES
+    ev = {k: [] for k in ((k2, "exchange", "features") if multi else (k2, "features"))}
 
     def step(timed: bool):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         table.reset()                   # bucketed tables are overwritten slice by slice: no 4 GB clear
 
-        table.count(stream, check=False, rows=plan, deferred_group=defer if defer is not None and table.can_defer(stream.n_words) else None)
+        # one GPU: the lookup pass of the abundance rows rides inside the counting kernel (same table, same matrices)
+        table.count(stream, check=False, rows=plan, deferred_group=defer if defer is not None and table.can_defer(stream.n_words) else None,
+                    emit=(WINDOW, VSIZE) if fused else None)
         e[1].record()
         if world > 1:
             pdist.exchange_table(table, check=False)
@@ -186,7 +196,7 @@ def main():
         d = Data(names, abd, tnf, device=dev)
         mu = vae.encode(d)
         if timed:
-            ev["kmer_count"].append((e[0], e[1]))
+            ev[k2].append((e[0], e[1]))
             ev["features"].append((e[2], e[3]))
             if multi:
                 ev["exchange"].append((e[1], e[2]))
@@ -216,7 +226,7 @@ def main():
     kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
     table_load = table.occupancy() if table.kind == "hash" else None
     dominant = max((k for k in kern_ms if k != "exchange"), key=kern_ms.get)
-    achieved = ALG_BYTES[dominant] * args.pairs / (kern_ms[dominant] * 1e-3) / 1e9
+    achieved = alg[dominant] * args.pairs / (kern_ms[dominant] * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")        # per-launch HBM bytes from rocprofv3 --pmc passes
     if os.path.exists(tpath):
@@ -251,7 +261,7 @@ def main():
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_pair": ALG_BYTES[dominant]},
+                         "alg_bytes_per_pair": alg[dominant]},
         }
         if world == 1 and not args.no_cpu_baseline:
             state = {k: v.detach().cpu().numpy() for k, v in vae.network.state_dict().items()}

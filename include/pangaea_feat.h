@@ -191,6 +191,16 @@ int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t
                            const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
                            uint32_t *status, void *stream);
 
+/* One GPU, a fresh table, abundance parameters known: pg_kmer_count_bucketed with the lookup pass of
+ * pg_abundance_from_records fused into the counting kernel -- while a bucket's counts are still in LDS its records are
+ * looked up and their (row, bin) words left in `shuffle_workspace` (pg_abundance_workspace_bytes); the abundance rows
+ * are then finished by pg_abundance_from_emitted (same arguments as pg_abundance_from_records).  Needs rows and at least
+ * 2^11 buckets. */
+int pg_kmer_count_bucketed_emit(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                                const pg_table *t, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
+                                int window, int vsize, void *shuffle_workspace, int64_t shuffle_workspace_bytes,
+                                uint32_t *status, void *stream);
+
 /* Add n (code,count) pairs -- `pairs[i] = (code << 22) | count`, the slot format -- into a hash table:
  * the merge step after tables of other GPUs have been gathered. */
 int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t, uint32_t *status, void *stream);
@@ -275,6 +285,9 @@ int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,
 #define PG_SHUFFLE_MAX_VSIZE 512
 int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t n_rows, int vsize, const pg_table *t);
 int pg_abundance_from_records(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
+                              const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                              void *workspace, int64_t workspace_bytes, void *stream);
+int pg_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
                               const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
                               void *workspace, int64_t workspace_bytes, void *stream);
 

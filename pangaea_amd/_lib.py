@@ -94,6 +94,8 @@ def load() -> C.CDLL:
         "pg_kmer_count_bucketed": (i32, [vp, vp, i64, i64, tp, i32, rp, vp, i64, vp, vp]),
         "pg_abundance_workspace_bytes": (i64, [i64, i64, i32, tp]),
         "pg_abundance_from_records": (i32, [tp, rp, i32, i32, vp, vp, i64, i64, vp, i64, vp]),
+        "pg_abundance_from_emitted": (i32, [tp, rp, i32, i32, vp, vp, i64, i64, vp, i64, vp]),
+        "pg_kmer_count_bucketed_emit": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, i32, i32, vp, i64, vp, vp]),
         "pg_kmer_merge": (i32, [vp, i64, tp, vp, vp]),
         "pg_kmer_merge_bucketed": (i32, [vp, vp, i32, tp, vp, vp]),
         "pg_kmer_rebuild_bucketed": (i32, [vp, vp, i32, tp, vp, vp]),
@@ -126,7 +128,7 @@ EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fast
            "pg_reads_valid", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
            "pg_pack_ascii", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_distinct_sketch", "pg_kmer_count_workspace_bytes",
            "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed", "pg_kmer_rebuild_bucketed", "pg_kmer_rebuild_bucketed_range", "pg_table_bucket_fill", "pg_kmer_count_deferred", "pg_deferred_gather", "pg_deferred_gather_planes", "pg_kmer_rebuild_planes_range", "pg_table_bucket_fill_range", "pg_table_compact_planes_range", "pg_table_compact", "pg_kmer_merge_wide", "pg_abundance_workspace_bytes",
-           "pg_abundance_from_records",
+           "pg_abundance_from_records", "pg_abundance_from_emitted", "pg_kmer_count_bucketed_emit",
            "pg_features", "pg_write_csv_gz", "pg_extract_reads"]
 
 

@@ -1471,6 +1471,113 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup32_kernel(const uint64
     if (threadIdx.x == 0) emit_end[blockIdx.x] = (unsigned long long)r0 + emitted;
 }
 
+// B and S1 in one kernel (one GPU, a fresh table): while the bucket's counts are still in LDS -- right after the last insert --
+// the bucket's records are streamed a second time (they were read a moment ago: L2 / MALL hits) and looked up, so the slice
+// is never re-loaded or re-split, and the packed slice image is written out while the lookups run.
+__global__ __launch_bounds__(BIG_BLOCK) void bucket_count_emit32_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
+                                                                        HashView t, uint32_t window, uint32_t vsize, int vbits,
+                                                                        uint32_t *__restrict__ words, unsigned long long *__restrict__ emit_end,
+                                                                        uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ uint32_t emitted;
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    uint32_t *tags = reinterpret_cast<uint32_t *>(tab), *cnts = tags + n_slots;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = t.limit();
+    const int hsh = KEY_BITS - t.log2_slots;
+    const int tag_bits = KEY_BITS - (t.log2_slots - t.log2_bucket);
+    const uint32_t tag_mask = (1u << tag_bits) - 1u;
+    uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    if (threadIdx.x == 0) emitted = 0;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) { tags[i] = 0u; cnts[i] = 0u; }
+    __syncthreads();
+    bool full = false;
+    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
+    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
+    const int64_t stride = (int64_t)BIG_BLOCK * (CNT_BATCH / 2);
+    for (int64_t base = q0; base < q1; base += stride) {               // ---- count
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH];
+        bool live[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            ulonglong2 v = make_ulonglong2(0ull, 0ull);
+            if (q < q1) v = rec2[q];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
+            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
+            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
+            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
+            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
+        }
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
+#define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
+        PG_RESOLVE(0) PG_RESOLVE(1) PG_RESOLVE(2) PG_RESOLVE(3) PG_RESOLVE(4) PG_RESOLVE(5) PG_RESOLVE(6) PG_RESOLVE(7)
+#undef PG_RESOLVE
+    }
+    if (full) atomicOr(status, 1u);
+    __syncthreads();
+    const uint64_t high = (uint64_t)blockIdx.x << tag_bits;            // ---- the slice image (stores overlap the lookups)
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint32_t tg = tags[i], c = cnts[i];
+        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    for (int64_t base = q0; base < q1; base += stride) {               // ---- lookups of the same records
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH], row[CNT_BATCH];
+        bool live[CNT_BATCH];
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            ulonglong2 v = make_ulonglong2(~0ull, ~0ull);
+            if (q < q1) v = rec2[q];
+            live[2 * j] = q < q1 && 2 * q >= r0;
+            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+            row[2 * j] = (uint32_t)(v.x >> REC_KEY_BITS);
+            row[2 * j + 1] = (uint32_t)(v.y >> REC_KEY_BITS);
+            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
+            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
+            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
+            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
+            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
+        }
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            live[j] = live[j] && row[j] != ROW_NONE;
+            first[j] = live[j] ? tags[ss[j]] : 0u;
+        }
+#define PG_EMIT(J)                                                                                                          \
+        {                                                                                                                   \
+            uint32_t bin = vsize;                                                                                           \
+            if (live[J]) {                                                                                                  \
+                uint32_t sl = ss[J], cur = first[J];                                                                        \
+                for (uint32_t i = 0; i < limit && cur != 0; ++i) {                                                          \
+                    if (cur == tg[J]) { bin = cnts[sl] / window; break; }                                                   \
+                    sl = (sl + 1) & smask;                                                                                  \
+                    cur = tags[sl];                                                                                         \
+                }                                                                                                           \
+            }                                                                                                               \
+            const bool put = bin < vsize;                                                                                   \
+            const unsigned long long m = __ballot(put);                                                                     \
+            if (m) {                                                                                                        \
+                const int leader = __ffsll((long long)m) - 1;                                                               \
+                uint32_t at = 0;                                                                                            \
+                if ((int)lane == leader) at = atomicAdd(&emitted, (uint32_t)__popcll(m));                                   \
+                at = __shfl(at, leader);                                                                                    \
+                if (put) words[r0 + at + __popcll(m & ((1ull << lane) - 1ull))] = (row[J] << vbits) | bin;                  \
+            }                                                                                                               \
+        }
+        PG_EMIT(0) PG_EMIT(1) PG_EMIT(2) PG_EMIT(3) PG_EMIT(4) PG_EMIT(5) PG_EMIT(6) PG_EMIT(7)
+#undef PG_EMIT
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) emit_end[blockIdx.x] = (unsigned long long)r0 + emitted;
+}
+
 // capacity of every row group (64 rows): the rows' character counts bound their k-mer counts
 __global__ __launch_bounds__(BLOCK) void group_caps_kernel(const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end,
                                                            int64_t n_rows, int64_t n_groups_padded, unsigned long long *__restrict__ caps)
@@ -1833,9 +1940,10 @@ extern "C" int64_t pg_kmer_count_workspace_bytes(int64_t n_words, const pg_table
 }
 
 namespace {
+struct EmitArgs { int window, vsize; void *shuffle_ws; int64_t shuffle_ws_bytes; };     // fused count + lookup (one GPU)
 int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
                         const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
-                        uint32_t *status, void *stream, int deferred_group, int64_t *fill);
+                        uint32_t *status, void *stream, int deferred_group, int64_t *fill, const EmitArgs *emit = nullptr);
 }
 
 extern "C" int pg_kmer_count_bucketed(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
@@ -1915,10 +2023,23 @@ extern "C" int pg_kmer_rebuild_planes_range(const void *buf, int64_t part_stride
     return check_launch("pg_kmer_rebuild_planes_range");
 }
 
+extern "C" int pg_kmer_count_bucketed_emit(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
+                                           const pg_table *t, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
+                                           int window, int vsize, void *shuffle_workspace, int64_t shuffle_workspace_bytes,
+                                           uint32_t *status, void *stream)
+{
+    if (!rows || rows->n_rows < 1) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed_emit: needs rows");
+    if (!shuffle_workspace) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed_emit: null shuffle workspace");
+    if (window < 1 || (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
+        return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed_emit: window %d x vector size %d outside the exact range of the hash table", window, vsize);
+    const EmitArgs e{window, vsize, shuffle_workspace, shuffle_workspace_bytes};
+    return count_bucketed_impl(codes, valid, word_begin, word_end, t, 0, rows, workspace, workspace_bytes, status, stream, -1, nullptr, &e);
+}
+
 namespace {
 int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
                         const pg_table *t, int accumulate, const pg_rows *rows, void *workspace, int64_t workspace_bytes,
-                        uint32_t *status, void *stream, int deferred_group, int64_t *fill)
+                        uint32_t *status, void *stream, int deferred_group, int64_t *fill, const EmitArgs *emit)
 {
     if (!codes || !valid || !workspace || !status) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: null argument");
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed: bad word range");
@@ -2001,6 +2122,21 @@ int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t wo
                            dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)bufb,
                            (const unsigned long long *)off, view_of(t), deferred_group, bufa, (long long *)fill, status);
         return check_launch("pg_kmer_count_deferred");
+    }
+    if (emit) {
+        // B + S1 fused: counts, slice image and the (row, bin) words of the abundance rows in one pass over the buckets
+        if (KEY_BITS - p.bits > 31) return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed_emit: needs at least 2^11 buckets");
+        ShufflePlan sp;
+        if ((rc = plan_shuffle(p.cap, rows->n_rows, emit->vsize, (int64_t)nb, &sp))) return rc;
+        if ((int64_t)sp.total > emit->shuffle_ws_bytes || (reinterpret_cast<uintptr_t>(emit->shuffle_ws) & 255) != 0)
+            return pg_fail(PG_EINVAL, "pg_kmer_count_bucketed_emit: shuffle workspace of %lld bytes (256-byte aligned), %lld needed",
+                           (long long)emit->shuffle_ws_bytes, (long long)sp.total);
+        char *sws = (char *)emit->shuffle_ws;
+        if ((rc = raise_lds_limit((const void *)bucket_count_emit32_kernel, slice_lds, "pg_kmer_count_bucketed_emit"))) return rc;
+        hipLaunchKernelGGL(bucket_count_emit32_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)(p.bits2 ? bufb : bufa),
+                           (const unsigned long long *)off, view_of(t), (uint32_t)emit->window, (uint32_t)emit->vsize, sp.vbits,
+                           (uint32_t *)(sws + sp.words_e_off), (unsigned long long *)(sws + sp.emit_off), status);
+        return check_launch("pg_kmer_count_bucketed_emit");
     }
     // B: count every bucket inside LDS and write its slice of the table
     if (KEY_BITS - p.bits <= 31 && !getenv("PG_B64")) {
@@ -2155,9 +2291,29 @@ extern "C" int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t
     return (int64_t)sp.total;
 }
 
+static int abundance_impl(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
+                          const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                          void *workspace, int64_t workspace_bytes, void *stream, bool emitted);
+
 extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
                                          const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
                                          void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return abundance_impl(t, rows, window, vsize, abd_out, count_workspace, count_workspace_bytes, n_words_counted, workspace, workspace_bytes,
+                          stream, false);
+}
+
+extern "C" int pg_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
+                                         const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                                         void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return abundance_impl(t, rows, window, vsize, abd_out, count_workspace, count_workspace_bytes, n_words_counted, workspace, workspace_bytes,
+                          stream, true);
+}
+
+static int abundance_impl(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
+                          const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
+                          void *workspace, int64_t workspace_bytes, void *stream, bool emitted)
 {
     int rc = check_table(t);
     if (rc) return rc;
@@ -2194,7 +2350,9 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
     if ((rc = raise_lds_limit((const void *)bucket_lookup_kernel, slice_lds, "pg_abundance_from_records"))) return rc;
     if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
-    if (hipMemsetAsync(ws, 0, sp.dhist_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
+    // (emitted: the lookup pass already ran inside pg_kmer_count_bucketed_emit and left emit_end + the words behind)
+    if (hipMemsetAsync(ws + (emitted ? sp.caps_off : 0), 0, sp.dhist_off - (emitted ? sp.caps_off : 0), s) != hipSuccess)
+        return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
 
     // row-group capacities -> offsets of the group regions
     hipLaunchKernelGGL(group_caps_kernel, dim3((unsigned)((sp.n_groups_padded + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_start, rows->row_end,
@@ -2202,7 +2360,8 @@ extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows,
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)caps, sp.n_groups_padded, goff);
     // S1: counts out of the LDS copies of the slices -> (row, bin) words, packed per bucket
     const int gshift = sp.vbits + GROUP_ROWS_LOG2;
-    if (KEY_BITS - p.bits <= 31 && !getenv("PG_B64")) {
+    if (emitted) {
+    } else if (KEY_BITS - p.bits <= 31 && !getenv("PG_B64")) {
         if ((rc = raise_lds_limit((const void *)bucket_lookup32_kernel, slice_lds, "pg_abundance_from_records"))) return rc;
         hipLaunchKernelGGL(bucket_lookup32_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, recs, off, view_of(t), (uint32_t)window, (uint32_t)vsize,
                            sp.vbits, words_e, emit_end);

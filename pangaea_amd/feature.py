@@ -97,7 +97,7 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     rows = stream.rows(min_len)
     plan = Plan(rows, device)
     if want_abd and table is None:
-        table = pdist.count_kmers_sharded(stream, k, rows=plan) if world > 1 else count_kmers(stream, k, rows=plan)
+        table = pdist.count_kmers_sharded(stream, k, rows=plan) if world > 1 else count_kmers(stream, k, rows=plan, emit=(window, vsize))
     tnf, abd = features(stream, plan, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
                         window=window, vsize=vsize)
     names = list(rows.names)

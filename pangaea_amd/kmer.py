@@ -54,6 +54,7 @@ class KmerTable:
         self._shuffle_ws = None
         self._records = None             # (plan, n_words) while the workspace holds the row-tagged records of ONE count
         self._deferred = None            # (fill, n_words) after a deferred count: entries wait in the workspace, slots unwritten
+        self._emitted = None             # (window, vsize) while the shuffle workspace holds the words of a fused count + lookup
 
     # ------------------------------------------------------------------ construction
 
@@ -153,6 +154,7 @@ class KmerTable:
         self._empty = True
         self._records = None
         self._deferred = None
+        self._emitted = None
         return self
 
     def _workspace_for(self, n_words: int) -> torch.Tensor:
@@ -167,8 +169,15 @@ class KmerTable:
         step = int(self.WORKSPACE_BUDGET // (2 * 8 * 32))
         return self._bucketed() and self._empty and self.log2_slots - self.log2_bucket > 8 and n_words <= step
 
+    def _shuffle_workspace_for(self, n_words: int, n_rows: int, vsize: int) -> torch.Tensor:
+        need = _lib.check(_lib.load().pg_abundance_workspace_bytes(n_words, n_rows, vsize, self.desc()))
+        if self._shuffle_ws is None or self._shuffle_ws.numel() < need:
+            self._shuffle_ws = None
+            self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._shuffle_ws
+
     def count(self, stream: ReadStream, word_begin: int = 0, word_end: int | None = None, check: bool = True,
-              rows: "Plan | None" = None, deferred_group: int | None = None) -> "KmerTable":
+              rows: "Plan | None" = None, deferred_group: int | None = None, emit: tuple | None = None) -> "KmerTable":
         """add the k-mers ending in words [word_begin, word_end) of the stream (asynchronous unless ``check``).
         With ``rows`` (a Plan of this stream's rows) a bucketed table also keeps the row-tagged partition records, which
         lets ``features`` build the abundance rows by shuffle instead of by table lookups.
@@ -176,7 +185,12 @@ class KmerTable:
         ``deferred_group`` = g (multi-GPU, ``can_defer``): this table has the geometry of the union over all ranks and
         is NOT written; 2^g adjacent buckets are counted together in LDS and only their occupied entries and the
         per-bucket fills are kept, for ``dist.exchange_table`` to gather and to rebuild the table from.  Until then the
-        table holds no counts (``pending``)."""
+        table holds no counts (``pending``).
+
+        ``emit`` = (window, vector_size) (one GPU, a fresh table, ``rows`` given, at least 2^11 buckets): the lookup pass of
+        the abundance rows is fused into the counting kernel -- a bucket's records are looked up while its counts are
+        still in LDS -- and ``features`` with the same window and vector size starts from the emitted (row, bin) words.
+        Silently ignored where it does not apply."""
         _require_gpu(stream.codes, "the read stream")
         if stream.device != self.device:
             raise ValueError("stream and table are on different devices")
@@ -200,6 +214,7 @@ class KmerTable:
                 self.check_status()
             return self
         self._deferred = None
+        self._emitted = None
         with torch.cuda.device(self.device):
             if self.kind == "hash" and self.log2_bucket:
                 # pieces bounded by the scratch budget: two record buffers of 8 B per character
@@ -207,6 +222,21 @@ class KmerTable:
                 single = self._empty and word_end - word_begin <= step
                 keep = rows if (single and rows is not None and rows.shuffle_ok) else None
                 self._records = None
+                if (emit is not None and keep is not None and self._bucketed() and self.tag_bits <= 31 and word_end > word_begin
+                        and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1 and emit[0] * emit[1] <= _lib.HASH_COUNT_SAT):
+                    window, vsize = int(emit[0]), int(emit[1])
+                    n_words = word_end - word_begin
+                    ws = self._workspace_for(n_words)
+                    sws = self._shuffle_workspace_for(n_words, keep.n_rows, vsize)
+                    _lib.check(L.pg_kmer_count_bucketed_emit(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end, self.desc(),
+                                                             C.byref(keep.rows_desc), ws.data_ptr(), ws.numel(), window, vsize,
+                                                             sws.data_ptr(), sws.numel(), self.status.data_ptr(), _stream_ptr(self.device)))
+                    self._empty = False
+                    self._records = (keep, n_words)
+                    self._emitted = (window, vsize)
+                    if check:
+                        self.check_status()
+                    return self
                 for w0 in range(word_begin, word_end, step):
                     w1 = min(word_end, w0 + step)
                     ws = self._workspace_for(w1 - w0)
@@ -234,14 +264,13 @@ class KmerTable:
             raise RuntimeError("no partition records for these rows: count(stream, rows=plan) first")
         n_words = self._records[1]
         L = _lib.load()
-        need = _lib.check(L.pg_abundance_workspace_bytes(n_words, plan.n_rows, vsize, self.desc()))
-        if self._shuffle_ws is None or self._shuffle_ws.numel() < need:
-            self._shuffle_ws = None
-            self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        emitted = self._emitted == (int(window), int(vsize))          # the lookup pass already ran inside the count
+        sws = self._shuffle_ws if emitted else self._shuffle_workspace_for(n_words, plan.n_rows, vsize)
+        fn = L.pg_abundance_from_emitted if emitted else L.pg_abundance_from_records
         with torch.cuda.device(self.device):
-            _lib.check(L.pg_abundance_from_records(self.desc(), C.byref(plan.rows_desc), window, vsize, out.data_ptr(),
-                                                   self._workspace.data_ptr(), self._workspace.numel(), n_words,
-                                                   self._shuffle_ws.data_ptr(), self._shuffle_ws.numel(), _stream_ptr(self.device)))
+            _lib.check(fn(self.desc(), C.byref(plan.rows_desc), window, vsize, out.data_ptr(),
+                          self._workspace.data_ptr(), self._workspace.numel(), n_words, sws.data_ptr(), sws.numel(), _stream_ptr(self.device)))
+        self._emitted = None            # the row shuffle reuses the emitted words' buffer: they are gone now
         return out
 
     def check_status(self) -> None:
@@ -525,8 +554,10 @@ def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end:
 
 
 def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hint: int | None = None,
-                max_log2_slots: int = 36, log2_bucket: int | None = None, rows: "Plan | None" = None) -> KmerTable:
-    """build the table of one stream; a full hash table is re-built with four times the slots"""
+                max_log2_slots: int = 36, log2_bucket: int | None = None, rows: "Plan | None" = None,
+                emit: tuple | None = None) -> KmerTable:
+    """build the table of one stream; a full hash table is re-built with four times the slots.  ``emit`` = (window,
+    vector_size) fuses the lookup pass of the abundance rows into the count where that applies (``KmerTable.count``)."""
     resolved = kind or KmerTable.default_kind(k)
     if distinct_hint is None and resolved != "dense":
         # size from a HyperLogLog pass (as cheap as the bucket histogram) instead of guessing the coverage; +10 % covers
@@ -538,7 +569,7 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
     table = KmerTable.alloc(k, stream.device, kind, distinct_hint, load=load, log2_bucket=log2_bucket)
     while True:
         try:
-            return table.count(stream, rows=rows)
+            return table.count(stream, rows=rows, emit=emit)
         except _lib.PangaeaError as e:
             if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
                 raise

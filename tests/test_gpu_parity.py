@@ -539,3 +539,33 @@ def test_mid_scale_table_and_rows_against_oracle():
         seq = text[int(rows.start[i]):int(rows.end[i])]
         assert np.array_equal(tnf[i].cpu().numpy(), oracle.tnf_row(seq, 4))
         assert np.array_equal(abd[i].cpu().numpy(), oracle.abd_row(seq, 21, otab, 10, 400))
+
+
+@pytest.mark.parametrize("k,window,vsize,log2_slots,log2_bucket", [(21, 10, 400, 22, 10), (15, 3, 64, 24, 13), (21, 1, 512, 29, 14), (9, 2, 33, 21, 10)])
+def test_fused_count_and_lookup_equals_separate_kernels(k, window, vsize, log2_slots, log2_bucket):
+    """count(emit=(window, vsize)): the abundance lookups ride inside the counting kernel; table and matrix are those of the
+    separate kernels and of the oracle, a second features() call falls back to the table, other parameters too"""
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=37, n_genomes=3, genome_len=30_000, fragment=8_000, sub_rate=0.01, n_rate=0.2, seed=300 + k)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    plain = kmer.KmerTable.with_slots(k, DEV, log2_slots, log2_bucket).count(s, rows=plan)
+    _, want = kmer.features(s, plan, k_tnf=None, table=plain, window=window, vsize=vsize)
+    fused = kmer.KmerTable.with_slots(k, DEV, log2_slots, log2_bucket)
+    fused.data.fill_(0x7FFF_FFFF_FFFF); fused._empty = True
+    fused.count(s, rows=plan, emit=(window, vsize))
+    assert fused._emitted == (window, vsize)
+    assert all(np.array_equal(x, y) for x, y in zip(fused.items(), plain.items()))
+    _, got = kmer.features(s, plan, k_tnf=None, table=fused, window=window, vsize=vsize)
+    assert fused._emitted is None and torch.equal(got, want)
+    _, oabd = _oracle_rows(s, rows, None, k, window, vsize)[1:] if False else (None, _oracle_rows(s, rows, None, k, window, vsize)[2])
+    assert np.array_equal(got.cpu().numpy(), oabd)
+    _, again = kmer.features(s, plan, k_tnf=None, table=fused, window=window, vsize=vsize)          # from the records + table now
+    assert torch.equal(again, want)
+    fused.reset().count(s, rows=plan, emit=(window, vsize))
+    _, other = kmer.features(s, plan, k_tnf=None, table=fused, window=window + 1, vsize=vsize)       # other parameters: unfused path
+    _, other_want = kmer.features(s, rows, k_tnf=None, table=plain, window=window + 1, vsize=vsize)
+    assert torch.equal(other, other_want)
+    # where fusion does not apply (few buckets) the argument is ignored
+    small = kmer.KmerTable.with_slots(k, DEV, 18, 14).count(s, rows=plan, emit=(window, vsize))
+    assert small._emitted is None

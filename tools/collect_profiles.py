@@ -28,7 +28,7 @@ KERNELS = [
     ("bucket_hist_kernel", "kmer_count", 2.0), ("scan_kernel", "kmer_count", 1.0), ("digit_scan_kernel", "kmer_count", 1.0),
     ("tile_rows_kernel", "kmer_count", 1.0), ("scatter_stream_kernel", "kmer_count", 1.0),
     ("scatter_records_kernel<unsigned long", "kmer_count", 2.0), ("bucket_count_kernel", "kmer_count", 2.0),
-    ("bucket_count32_kernel", "kmer_count", 2.0), ("bucket_count_compact32_kernel", "kmer_count", 2.0),
+    ("bucket_count32_kernel", "kmer_count", 2.0), ("bucket_count_emit32_kernel", "kmer_count+lookup", 2.0), ("bucket_count_compact32_kernel", "kmer_count", 2.0),
     ("bucket_count_compact_kernel", "kmer_count", 2.0),
     ("kmer_count_kernel", "kmer_count", 1.0),
     ("bucket_lookup_kernel", "features", 2.0), ("bucket_lookup32_kernel", "features", 2.0), ("scatter_records_kernel<unsigned int", "features", 2.0),
@@ -80,6 +80,8 @@ def main():
         e["fetch_correction"] = corr
         e["hbm_bytes"] = (e["FETCH_SIZE_KB"] * corr + e["WRITE_SIZE_KB"]) * 1024
         stages[stage] = stages.get(stage, 0.0) + e["hbm_bytes"]
+    if "kmer_count+lookup" in stages:                  # fused run: the stage is the whole K2 pipeline with the lookups inside
+        stages["kmer_count+lookup"] += stages.pop("kmer_count", 0.0)
     json.dump({"pairs": pairs, "tag": tag,
                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around bench.py --steps 1 --warmup 0",
                "note": "counters are KiB; per kernel: hbm_bytes = (FETCH_SIZE x fetch_correction + WRITE_SIZE) x 1024; "
