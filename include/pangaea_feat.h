@@ -201,7 +201,7 @@ int pg_kmer_count_bucketed_emit(const uint64_t *codes, const uint32_t *valid, in
                                 int window, int vsize, void *shuffle_workspace, int64_t shuffle_workspace_bytes,
                                 uint32_t *status, void *stream);
 
-/* Add n (code,count) pairs -- `pairs[i] = (code << 22) | count`, the slot format -- into a hash table:
+/* Add n (key,count) pairs -- `pairs[i] = (pg_key42(code) << 22) | count`, the slot format -- into a hash table:
  * the merge step after tables of other GPUs have been gathered. */
 int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t, uint32_t *status, void *stream);
 
