@@ -495,6 +495,11 @@ def test_randomized_configurations(seed):
     tnf, abd = kmer.features(s, plan, k_tnf=k_tnf, table=table, window=window, vsize=vsize)
     tnf_l, abd_l = kmer.features(s, rows, k_tnf=k_tnf, table=table, window=window, vsize=vsize, seg_chars=64)
     assert torch.equal(tnf, tnf_l) and torch.equal(abd, abd_l)
+    # the fused count + lookup form (applies from 2^11 buckets on, silently ignored otherwise): same table, same rows
+    fused = kmer.KmerTable.with_slots(k, DEV, log2_slots, log2_bucket).count(s, rows=plan, emit=(window, vsize))
+    assert (fused._emitted is not None) == (len(rows) > 0 and log2_slots - log2_bucket >= 11)
+    _, abd_f = kmer.features(s, plan, k_tnf=None, table=fused, window=window, vsize=vsize)
+    assert torch.equal(abd_f, abd) and all(np.array_equal(x, y) for x, y in zip(fused.items(), table.items()))   # (slot order is free)
     if len(rows):
         otab, otnf, oabd = _oracle_rows(s, rows, k_tnf, k, window, vsize)
         assert all(np.array_equal(x, y) for x, y in zip(table.items(), otab.items()))
