@@ -1138,6 +1138,121 @@ struct BinFiles {
 
 }  // namespace
 
+namespace {
+
+// Threaded form of the interleaved branch below, byte for byte the same files: T threads stream their byte ranges of the
+// (uncompressed) input twice -- first to size every thread's share of every cluster file, then to write the records with
+// pwrite at their exact offsets -- so every file keeps the input order although no thread ever waits for another.
+int extract_interleaved_parallel(int fd, size_t size, const char *path, const std::unordered_map<std::string, uint32_t> &cluster_of,
+                                 const std::vector<std::string> &stems, int T, int64_t *pairs_written)
+{
+    const size_t n_bins = stems.size();
+    const Latch L = find_latch(fd, size);
+    const size_t block = reader_block((size_t)1 << 20);
+    std::vector<size_t> rb(T + 1);
+    for (int t = 0; t <= T; ++t) rb[t] = (size_t)((unsigned __int128)size * (unsigned)t / (unsigned)T);
+    std::vector<uint64_t> nl(T, 0);
+    std::vector<char> at_line_start(T, 1), io_bad(T, 0);
+    run_threads(T, [&](int t) {
+        if (t > 0 && rb[t] > 0) { char c = 0; if (pread(fd, &c, 1, (off_t)(rb[t] - 1)) != 1) io_bad[t] = 1; at_line_start[t] = c == '\n'; }
+        UnitReader rd(fd, rb[t], rb[t + 1], block);
+        nl[t] = rd.count_newlines();
+        if (rd.io_error()) io_bad[t] = 1;
+    });
+    for (char x : io_bad) if (x) return pg_fail(PG_EIO, "read error in %s", path);
+    std::vector<uint64_t> nl_before(T + 1, 0);
+    for (int t = 0; t < T; ++t) nl_before[t + 1] = nl_before[t] + nl[t];
+    // one unit -> (cluster, rewritten header, barcode); false = not kept
+    struct Out { std::vector<uint64_t> fq, bc; uint64_t bad_unit = UINT64_MAX; bool io_error = false; int64_t pairs = 0; };
+    std::vector<Out> out(T);
+    std::vector<int> fq_fd(n_bins, -1), bc_fd(n_bins, -1);
+    auto walk = [&](int t, auto &&visit) {
+        Out &o = out[t];
+        if (rb[t] >= rb[t + 1]) return;
+        UnitReader rd(fd, rb[t], size, block);
+        uint64_t line = nl_before[t];
+        if (!at_line_start[t]) { if (!rd.skip_line()) { o.io_error = rd.io_error(); return; } ++line; }
+        for (uint64_t skip = (8 - line % 8) % 8; skip; --skip, ++line)
+            if (!rd.skip_line()) { o.io_error = rd.io_error(); return; }
+        uint64_t unit = line / 8;
+        UnitLines u;
+        std::string barcode;
+        while (rd.offset() < rb[t + 1] && rd.next(u)) {
+            int mode = mode_of(L, unit);
+            Span nm, bc;
+            if (!header_fields(u.p[0], u.n[0], mode, nm, bc)) { o.bad_unit = unit; return; }
+            if (u.count == 8) {                                    // the sequential loop emits on the 8th line only
+                barcode.assign(u.p[0] + bc.b, bc.n);
+                auto it = cluster_of.find(barcode);
+                if (it != cluster_of.end()) visit(it->second, u, nm, barcode);
+            }
+            ++unit;
+        }
+        o.io_error = rd.io_error();
+    };
+    // pass 1: bytes per (thread, cluster)
+    run_threads(T, [&](int t) {
+        out[t].fq.assign(n_bins, 0); out[t].bc.assign(n_bins, 0);
+        walk(t, [&](uint32_t id, const UnitLines &u, const Span &nm, const std::string &barcode) {
+            uint64_t bytes = nm.n + 6 + barcode.size() + 3;         // name \t BX:Z: barcode -1 \n
+            for (int k = 1; k < 8; ++k) bytes += u.n[k] + 1;
+            out[t].fq[id] += bytes;
+            out[t].bc[id] += barcode.size() + 1;
+            ++out[t].pairs;
+        });
+    });
+    uint64_t first_bad = UINT64_MAX;
+    int64_t written = 0;
+    for (int t = 0; t < T; ++t) {
+        if (out[t].io_error) return pg_fail(PG_EIO, "read error in %s", path);
+        first_bad = std::min(first_bad, out[t].bad_unit);
+        written += out[t].pairs;
+    }
+    if (first_bad != UINT64_MAX)
+        return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag", path, (unsigned long long)(first_bad * 8 + 1));
+    // offsets of every thread's share, files sized up front
+    std::vector<std::vector<uint64_t>> fq_at(T, std::vector<uint64_t>(n_bins)), bc_at(T, std::vector<uint64_t>(n_bins));
+    int rc = PG_OK;
+    for (size_t b = 0; b < n_bins && !rc; ++b) {
+        uint64_t f = 0, c = 0;
+        for (int t = 0; t < T; ++t) { fq_at[t][b] = f; f += out[t].fq[b]; bc_at[t][b] = c; c += out[t].bc[b]; }
+        fq_fd[b] = open((stems[b] + ".fq").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        bc_fd[b] = open((stems[b] + ".barcode").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fq_fd[b] < 0 || bc_fd[b] < 0 || ftruncate(fq_fd[b], (off_t)f) != 0 || ftruncate(bc_fd[b], (off_t)c) != 0)
+            rc = pg_fail(PG_EIO, "cannot create %s.{fq,barcode}", stems[b].c_str());
+    }
+    // pass 2: the records, through per-cluster buffers, at their offsets
+    std::vector<char> wr_bad(T, 0);
+    if (!rc) run_threads(T, [&](int t) {
+        std::vector<std::string> fq_buf(n_bins), bc_buf(n_bins);
+        auto flush = [&](size_t b, bool all) {
+            if (!fq_buf[b].empty() && (all || fq_buf[b].size() > ((size_t)1 << 18))) {
+                if (pwrite(fq_fd[b], fq_buf[b].data(), fq_buf[b].size(), (off_t)fq_at[t][b]) != (ssize_t)fq_buf[b].size()) wr_bad[t] = 1;
+                fq_at[t][b] += fq_buf[b].size(); fq_buf[b].clear();
+            }
+            if (!bc_buf[b].empty() && (all || bc_buf[b].size() > ((size_t)1 << 16))) {
+                if (pwrite(bc_fd[b], bc_buf[b].data(), bc_buf[b].size(), (off_t)bc_at[t][b]) != (ssize_t)bc_buf[b].size()) wr_bad[t] = 1;
+                bc_at[t][b] += bc_buf[b].size(); bc_buf[b].clear();
+            }
+        };
+        walk(t, [&](uint32_t id, const UnitLines &u, const Span &nm, const std::string &barcode) {
+            std::string &f = fq_buf[id];
+            f.append(u.p[0] + nm.b, nm.n).append("\tBX:Z:").append(barcode).append("-1\n");
+            for (int k = 1; k < 8; ++k) { f.append(u.p[k], u.n[k]); f.push_back('\n'); }
+            bc_buf[id].append(barcode).push_back('\n');
+            flush(id, false);
+        });
+        for (size_t b = 0; b < n_bins; ++b) flush(b, true);
+    });
+    for (size_t b = 0; b < n_bins; ++b) { if (fq_fd[b] >= 0) close(fq_fd[b]); if (bc_fd[b] >= 0) close(bc_fd[b]); }
+    if (rc) return rc;
+    for (char x : wr_bad) if (x) return pg_fail(PG_EIO, "write error in %s_bin*", path);
+    if (pairs_written) *pairs_written = written;
+    return PG_OK;
+}
+
+}  // namespace
+
 extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clusters_tsv, const char *out_prefix, int64_t *pairs_written)
 {
     if (!r1 || !clusters_tsv || !out_prefix) return pg_fail(PG_EINVAL, "pg_extract_reads: null argument");
@@ -1152,6 +1267,7 @@ extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clus
     }
     std::unordered_map<std::string, uint32_t> cluster_of;
     std::vector<BinFiles> bins;
+    std::vector<std::string> stems;
     auto close_all = [&]() {
         for (auto &b : bins) { b.flush(); if (b.fq) fclose(b.fq); if (b.bc) fclose(b.bc); }
     };
@@ -1173,6 +1289,7 @@ extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clus
                 return pg_fail(PG_EIO, "cannot create %s.{fq,barcode}", stem.c_str());
             }
             bins.push_back(std::move(files));
+            stems.push_back(stem);
             const uint32_t id = (uint32_t)bins.size() - 1;
             // the reference walks `pos` with wrap-around when the line has no TAB (then the whole line is a barcode list)
             std::string bc;
@@ -1182,6 +1299,20 @@ extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clus
                 bc.clear();
             }
         }
+    }
+    const int T = ingest_threads();
+    if (!r2 && T > 1) {               // an uncompressed interleaved file of some size: the threaded form (same bytes)
+        int fd; size_t size = 0; bool plain;
+        int rc0 = open_plain(r1, fd, size, plain);
+        if (rc0) { close_all(); return rc0; }
+        if (plain && size >= ((size_t)1 << 16) * (size_t)T) {
+            close_all();                                             // the files exist (empty); the threads reopen them
+            try { rc0 = extract_interleaved_parallel(fd, size, r1, cluster_of, stems, T, pairs_written); }
+            catch (const std::bad_alloc &) { rc0 = pg_fail(PG_ENOMEM, "out of memory while writing the bins of %s", r1); }
+            close(fd);
+            return rc0;
+        }
+        close(fd);
     }
     FileBuf f1, f2;
     int rc = slurp(r1, f1);

@@ -67,3 +67,42 @@ def test_live_against_reference_binary(name, tmp_path):
     assert sorted(os.listdir(a)) == sorted(os.listdir(b))
     for fn in os.listdir(a):
         assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
+
+
+@pytest.mark.parametrize("style", ["10x", "stlfr"])
+def test_threaded_bin_writer_writes_the_same_bytes(style, tmp_path):
+    """a file big enough for the threaded form (ranges streamed twice: sizes, then pwrite at exact offsets) gives, for any
+    thread count and reader block size, exactly the files of the sequential loop -- and of the reference's extract_reads"""
+    import numpy as np
+    from pangaea_amd import synth
+    cfg = synth.SynthConfig(n_pairs=7000, n_barcodes=60, n_genomes=2, genome_len=30_000, fragment=5_000, unbarcoded=0.1, seed=3)
+    stream = synth.generate(cfg)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(stream, cfg, fq, style=style)
+    lines = open(fq).read().splitlines(keepends=True)
+    open(fq, "w").write("".join(lines[:-3]))                       # the last record is cut short: never written
+    barcodes = sorted({n for n in oracle.Reads(fq).names if n})
+    rng = random.Random(7)
+    tsv = str(tmp_path / "clusters.tsv")
+    write_clusters_tsv(tsv, [rng.choice([-1, 0, 1, 2, 3, 9]) for _ in barcodes], barcodes)
+    L = _lib.load()
+    outs = {}
+    try:
+        for tag, threads, block in (("serial", 1, None), ("t4", 4, None), ("t7_small_blocks", 7, "700")):
+            L.pg_set_ingest_threads(threads)
+            if block:
+                os.environ["PG_INGEST_BLOCK"] = block
+            d = tmp_path / tag
+            d.mkdir()
+            n = extract_reads(fq, None, tsv, str(d / "cluster"))
+            outs[tag] = (n, {fn: (d / fn).read_bytes() for fn in sorted(os.listdir(d))})
+    finally:
+        L.pg_set_ingest_threads(0)
+        os.environ.pop("PG_INGEST_BLOCK", None)
+    assert outs["serial"][0] > 0 and len(outs["serial"][1]) == 10
+    assert outs["t4"] == outs["serial"] and outs["t7_small_blocks"] == outs["serial"]
+    if oracle.ref_tool("extract_reads") is not None:
+        d = tmp_path / "ref"
+        d.mkdir()
+        subprocess.run([oracle.ref_tool("extract_reads"), "-i", fq, "-c", tsv, "-o", str(d / "cluster")], check=True, stdout=subprocess.DEVNULL)
+        assert {fn: (d / fn).read_bytes() for fn in sorted(os.listdir(d))} == outs["serial"][1]

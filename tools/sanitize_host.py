@@ -100,6 +100,20 @@ open(tsv, "w").write("3\tAAACCCGG,ACGTACGT\n-1\tAACGTTTC\n0\tCCGGTTAA\n")
 wrote = i64(0)
 assert lib.pg_extract_reads(os.path.join(G, "tenx_mixed.fq").encode(), None, tsv.encode(), os.path.join(tmp, "cl").encode(), C.byref(wrote)) == 0
 assert lib.pg_extract_reads(os.path.join(G, "pair_R1.fq").encode(), os.path.join(G, "pair_R2.fq").encode(), tsv.encode(), os.path.join(tmp, "cp").encode(), C.byref(wrote)) == 0
+# the threaded bin writer on the larger file (sizes pass + pwrite pass), also with tiny reader blocks
+tsv2 = os.path.join(tmp, "c2.tsv")
+bcs = sorted({n.decode() for n in ref[(big, None)][2] if n})
+open(tsv2, "w").write("".join(f"{i % 5}\t{','.join(bcs[i::7])}\n" for i in range(5)))
+sizes = None
+for threads, block in ((1, None), (4, None), (6, "300")):
+    lib.pg_set_ingest_threads(threads)
+    if block:
+        os.environ["PG_INGEST_BLOCK"] = block
+    assert lib.pg_extract_reads(big.encode(), None, tsv2.encode(), os.path.join(tmp, f"w{threads}").encode(), C.byref(wrote)) == 0, lib.pg_last_error()
+    got = sorted((os.path.basename(f)[2:], open(f, "rb").read()) for f in glob.glob(os.path.join(tmp, f"w{threads}_bin*")))
+    assert wrote.value > 0 and (sizes is None or got == sizes)
+    sizes = got
+os.environ.pop("PG_INGEST_BLOCK", None)
 for f in glob.glob(os.path.join(tmp, "*")):
     os.remove(f)
 os.rmdir(tmp)
