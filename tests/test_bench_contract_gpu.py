@@ -1,0 +1,36 @@
+"""bench.py's one JSON line carries every key the driver's contract names (small workload, one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-fuse"], ["--rehearse-dist", "4"]])
+def test_bench_line_honours_the_contract(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "200000", "--steps", "2", "--warmup", "1", "--cpu-sample", "2000"] + extra
+    if extra:
+        cmd.append("--no-cpu-baseline")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["unit"] == "pairs/s" and j["vs_baseline"] is None and j["data"] == "synthetic" and j["dtype"] == "u64"
+    assert abs(j["value"] - 200000 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "traffic" in r and r["kernel"] in j["kernel_ms"]
+    if not extra:
+        c = j["cpu_baseline"]
+        assert c["unit"] == "pairs/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
