@@ -698,6 +698,36 @@ __device__ __forceinline__ bool lds_insert(unsigned long long *tab, uint32_t sma
 // bucket's records stream through (8 loads per lane in flight, first LDS probes of a batch issued back to back);
 // the LDS image is then written back as the slice.
 constexpr int CNT_BATCH = 8;               // the resolve macros below are written for exactly 8
+
+// ---- one batch of a bucket's records.  The records [r0, r1) of a bucket are read as aligned 16-byte pairs (pair q = records
+// 2q and 2q + 1 of the buffer), CNT_BATCH / 2 pairs per lane and batch, all loads in flight together.
+struct PairRange {
+    const ulonglong2 *rec2;
+    int64_t q0, q1, r0, r1;
+    __device__ __forceinline__ PairRange(const uint64_t *rec, int64_t r0_, int64_t r1_)
+        : rec2(reinterpret_cast<const ulonglong2 *>(rec)), q0(r0_ >> 1), q1((r1_ + 1) >> 1), r0(r0_), r1(r1_) {}
+    static constexpr int64_t stride = (int64_t)BIG_BLOCK * (CNT_BATCH / 2);
+    // pairs of the batch at `base`; lanes beyond the range get `pad` in both halves
+    __device__ __forceinline__ void load(int64_t base, ulonglong2 (&v)[CNT_BATCH / 2], unsigned long long pad) const
+    {
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            v[j] = q < q1 ? rec2[q] : make_ulonglong2(pad, pad);
+        }
+    }
+    // which of the batch's records belong to the bucket (the first / last pair may straddle its ends)
+    __device__ __forceinline__ void live(int64_t base, bool (&l)[CNT_BATCH]) const
+    {
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH / 2; ++j) {
+            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
+            l[2 * j] = q < q1 && 2 * q >= r0;
+            l[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
+        }
+    }
+};
+
 __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t *__restrict__ rec, const unsigned long long *__restrict__ off,
                                                                  HashView t, int accumulate, uint32_t *status)
 {
@@ -712,34 +742,19 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = accumulate ? slice[i] : 0ull;
     __syncthreads();
     bool full = false;
-    // records are read as aligned 16-byte pairs: pair index q covers records 2q, 2q+1 of the buffer
-    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
-    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
-    // software pipeline: the loads of the next batch are in flight while this batch is resolved in LDS
-    const int64_t stride = (int64_t)BIG_BLOCK * (CNT_BATCH / 2);
+    const PairRange pr(rec, r0, r1);
     ulonglong2 nxt[CNT_BATCH / 2];
-#pragma unroll
-    for (int j = 0; j < CNT_BATCH / 2; ++j) {
-        const int64_t q = q0 + (int64_t)j * BIG_BLOCK + threadIdx.x;
-        nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
-    }
-    for (int64_t base = q0; base < q1; base += stride) {
+    pr.load(pr.q0, nxt, 0ull);
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
         uint64_t rr[CNT_BATCH];
         bool live[CNT_BATCH];
+        pr.live(base, live);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            const ulonglong2 v = nxt[j];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            rr[2 * j] = live[2 * j] ? v.x & REC_KEY_MASK : 0ull;
-            rr[2 * j + 1] = live[2 * j + 1] ? v.y & REC_KEY_MASK : 0ull;
+            rr[2 * j] = live[2 * j] ? nxt[j].x & REC_KEY_MASK : 0ull;
+            rr[2 * j + 1] = live[2 * j + 1] ? nxt[j].y & REC_KEY_MASK : 0ull;
         }
-#pragma unroll
-        for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + stride + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
-        }
+        pr.load(base + PairRange::stride, nxt, 0ull);               // software pipeline: the next batch's loads fly during the inserts
         uint32_t ss[CNT_BATCH];
         unsigned long long first[CNT_BATCH];
 #pragma unroll
@@ -756,6 +771,41 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_kernel(const uint64_t 
     if (full) atomicOr(status, 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+}
+
+// split-table view of a batch: tag (the key's bits below the bucket / group id, | 0x80000000), home slot, row id
+__device__ __forceinline__ void split32(const ulonglong2 (&v)[CNT_BATCH / 2], uint32_t tag_mask, int hsh, uint32_t smask,
+                                        uint32_t (&tg)[CNT_BATCH], uint32_t (&ss)[CNT_BATCH], uint32_t (&row)[CNT_BATCH])
+{
+#pragma unroll
+    for (int j = 0; j < CNT_BATCH / 2; ++j) {
+        const uint64_t k0 = v[j].x & REC_KEY_MASK, k1 = v[j].y & REC_KEY_MASK;
+        tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
+        tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
+        ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
+        ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
+        row[2 * j] = (uint32_t)(v[j].x >> REC_KEY_BITS);
+        row[2 * j + 1] = (uint32_t)(v[j].y >> REC_KEY_BITS);
+    }
+}
+
+// the two 4-byte planes of a slice <-> its packed 8-byte slots (counts are clamped to the saturation value on the way out)
+__device__ __forceinline__ void planes_from_slice(uint32_t *tags, uint32_t *cnts, uint32_t n_slots, uint32_t tag_mask, const uint64_t *slice)
+{
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const uint64_t v = slice ? slice[i] : 0ull;
+        tags[i] = v ? ((uint32_t)(v >> HASH_CBITS) & tag_mask) | 0x80000000u : 0u;
+        cnts[i] = (uint32_t)(v & HASH_CMASK);
+    }
+}
+__device__ __forceinline__ uint64_t packed_slot(uint64_t high, uint32_t tag, uint32_t tag_mask, uint32_t count)
+{
+    return ((high | (tag & tag_mask)) << HASH_CBITS) | (count < HASH_SAT ? count : HASH_SAT);
+}
+__device__ __forceinline__ void slice_from_planes(const uint32_t *tags, const uint32_t *cnts, uint32_t n_slots, uint32_t tag_mask, uint64_t high,
+                                                  uint64_t *slice)
+{
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tags[i] ? packed_slot(high, tags[i], tag_mask, cnts[i]) : 0ull;
 }
 
 // B with a split LDS table (buckets >= 2^11, i.e. the key's bits below the bucket id fit 31 bits): tags[] = those bits
@@ -791,42 +841,18 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count32_kernel(const uint64_
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
     if (r0 == r1 && accumulate) return;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
-        const uint64_t v = accumulate ? slice[i] : 0ull;
-        tags[i] = v ? ((uint32_t)(v >> HASH_CBITS) & tag_mask) | 0x80000000u : 0u;
-        cnts[i] = (uint32_t)(v & HASH_CMASK);
-    }
+    planes_from_slice(tags, cnts, n_slots, tag_mask, accumulate ? slice : nullptr);
     __syncthreads();
     bool full = false;
-    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
-    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
-    const int64_t stride = (int64_t)BIG_BLOCK * (CNT_BATCH / 2);
+    const PairRange pr(rec, r0, r1);
     ulonglong2 nxt[CNT_BATCH / 2];
-#pragma unroll
-    for (int j = 0; j < CNT_BATCH / 2; ++j) {
-        const int64_t q = q0 + (int64_t)j * BIG_BLOCK + threadIdx.x;
-        nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
-    }
-    for (int64_t base = q0; base < q1; base += stride) {
-        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH];
+    pr.load(pr.q0, nxt, 0ull);
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], row[CNT_BATCH], first[CNT_BATCH];
         bool live[CNT_BATCH];
-#pragma unroll
-        for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            const ulonglong2 v = nxt[j];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
-            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
-            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
-            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
-            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
-        }
-#pragma unroll
-        for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + stride + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            nxt[j] = q < q1 ? rec2[q] : make_ulonglong2(0ull, 0ull);
-        }
+        pr.live(base, live);
+        split32(nxt, tag_mask, hsh, smask, tg, ss, row);
+        pr.load(base + PairRange::stride, nxt, 0ull);               // software pipeline: the next batch's loads fly during the inserts
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
 #define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
@@ -835,11 +861,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count32_kernel(const uint64_
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
-    const uint64_t high = (uint64_t)blockIdx.x << tag_bits;         // the bucket id is the key's top bits
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
-        const uint32_t tg = tags[i], c = cnts[i];
-        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
-    }
+    slice_from_planes(tags, cnts, n_slots, tag_mask, (uint64_t)blockIdx.x << tag_bits, slice);     // the bucket id is the key's top bits
 }
 
 // B for the multi-GPU path: the rank's table is never materialised.  The table descriptor has the geometry of the UNION
@@ -867,20 +889,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact_kernel(const u
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = 0ull;
     __syncthreads();
     bool full = false;
-    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
-    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
-    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
+    const PairRange pr(rec, r0, r1);
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
+        ulonglong2 v[CNT_BATCH / 2];
         uint64_t rr[CNT_BATCH];
         bool live[CNT_BATCH];
+        pr.load(base, v, 0ull);
+        pr.live(base, live);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            ulonglong2 v = make_ulonglong2(0ull, 0ull);
-            if (q < q1) v = rec2[q];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            rr[2 * j] = live[2 * j] ? v.x & REC_KEY_MASK : 0ull;
-            rr[2 * j + 1] = live[2 * j + 1] ? v.y & REC_KEY_MASK : 0ull;
+            rr[2 * j] = live[2 * j] ? v[j].x & REC_KEY_MASK : 0ull;
+            rr[2 * j + 1] = live[2 * j + 1] ? v[j].y & REC_KEY_MASK : 0ull;
         }
         uint32_t ss[CNT_BATCH];
         unsigned long long first[CNT_BATCH];
@@ -925,27 +944,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact32_kernel(const
     const int64_t r0 = (int64_t)off[b0], r1 = (int64_t)off[b0 + (1 << g)];
     if (threadIdx.x <= qmask) qcnt[threadIdx.x] = 0;
     if (r0 == r1) { if (threadIdx.x <= qmask) fill[b0 + threadIdx.x] = 0; return; }
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) { tags[i] = 0u; cnts[i] = 0u; }
+    planes_from_slice(tags, cnts, n_slots, tag_mask, nullptr);
     __syncthreads();
     bool full = false;
-    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
-    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
-    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
-        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH];
+    const PairRange pr(rec, r0, r1);
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
+        ulonglong2 v[CNT_BATCH / 2];
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], row[CNT_BATCH], first[CNT_BATCH];
         bool live[CNT_BATCH];
-#pragma unroll
-        for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            ulonglong2 v = make_ulonglong2(0ull, 0ull);
-            if (q < q1) v = rec2[q];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
-            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
-            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
-            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
-            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
-        }
+        pr.load(base, v, 0ull);
+        pr.live(base, live);
+        split32(v, tag_mask, hsh, smask, tg, ss, row);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
 #define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
@@ -958,9 +967,8 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact32_kernel(const
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
         const uint32_t tg = tags[i];
         if (tg) {
-            const uint32_t c = cnts[i];
             const uint32_t q = ((tg & tag_mask) >> (tag_bits - g)) & qmask;          // the final bucket inside the group
-            scratch[off[b0 + q] + atomicAdd(&qcnt[q], 1u)] = ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT);
+            scratch[off[b0 + q] + atomicAdd(&qcnt[q], 1u)] = packed_slot(high, tg, tag_mask, cnts[i]);
         }
     }
     __syncthreads();
@@ -1029,7 +1037,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_planes_kernel(const ui
     const uint32_t tag_mask = (1u << tag_bits) - 1u;
     const int64_t bucket = bucket_base + blockIdx.x;
     uint64_t *slice = t.slots + ((uint64_t)bucket << t.log2_bucket);
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) { tags[i] = 0u; cnts[i] = 0u; }
+    planes_from_slice(tags, cnts, n_slots, tag_mask, nullptr);
     __syncthreads();
     bool full = false;
     for (int p = 0; p < n_parts; ++p) {
@@ -1069,11 +1077,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge_planes_kernel(const ui
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
-    const uint64_t high = (uint64_t)bucket << tag_bits;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
-        const uint32_t tg = tags[i], c = cnts[i];
-        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
-    }
+    slice_from_planes(tags, cnts, n_slots, tag_mask, (uint64_t)bucket << tag_bits, slice);
 }
 
 // Bucket-wise merge of other tables into this one: the compacted tables of the other ranks arrive bucket by bucket
@@ -1170,11 +1174,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge32_kernel(const uint64_
     int64_t total = 0;
     for (int p = 0; p < n_parts; ++p) total += seg[p * (n_seg + 1) + blockIdx.x + 1] - seg[p * (n_seg + 1) + blockIdx.x];
     if (total == 0 && !rebuild) return;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
-        const uint64_t v = rebuild ? 0ull : slice[i];
-        tags[i] = v ? ((uint32_t)(v >> HASH_CBITS) & tag_mask) | 0x80000000u : 0u;
-        cnts[i] = (uint32_t)(v & HASH_CMASK);
-    }
+    planes_from_slice(tags, cnts, n_slots, tag_mask, rebuild ? nullptr : slice);
     __syncthreads();
     bool full = false;
     for (int p = 0; p < n_parts; ++p) {
@@ -1212,11 +1212,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_merge32_kernel(const uint64_
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
-    const uint64_t high = (uint64_t)bucket << tag_bits;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
-        const uint32_t tg = tags[i], c = cnts[i];
-        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
-    }
+    slice_from_planes(tags, cnts, n_slots, tag_mask, (uint64_t)bucket << tag_bits, slice);
 }
 
 // occupied slots of every bucket: the segment lengths of a bucket-ordered compaction (one workgroup per bucket)
@@ -1344,20 +1340,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup_kernel(const uint64_t
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = slice[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;                 // aligned 16-byte pairs, as in bucket_count_kernel
-    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
-    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
+    const PairRange pr(rec, r0, r1);
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
+        ulonglong2 v[CNT_BATCH / 2];
         uint64_t rr[CNT_BATCH];
         bool live[CNT_BATCH];
+        pr.load(base, v, ~0ull);                                    // a padding lane carries ROW_NONE
+        pr.live(base, live);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            ulonglong2 v = make_ulonglong2(~0ull, ~0ull);            // a padding lane carries ROW_NONE
-            if (q < q1) v = rec2[q];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            rr[2 * j] = live[2 * j] ? v.x : ~0ull;
-            rr[2 * j + 1] = live[2 * j + 1] ? v.y : ~0ull;
+            rr[2 * j] = live[2 * j] ? v[j].x : ~0ull;
+            rr[2 * j + 1] = live[2 * j + 1] ? v[j].y : ~0ull;
         }
         uint32_t ss[CNT_BATCH];
         unsigned long long first[CNT_BATCH];
@@ -1418,26 +1411,14 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup32_kernel(const uint64
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
-    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
-    for (int64_t base = q0; base < q1; base += (int64_t)BIG_BLOCK * (CNT_BATCH / 2)) {
+    const PairRange pr(rec, r0, r1);
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
+        ulonglong2 v[CNT_BATCH / 2];
         uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH], row[CNT_BATCH];
         bool live[CNT_BATCH];
-#pragma unroll
-        for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            ulonglong2 v = make_ulonglong2(~0ull, ~0ull);            // a padding lane carries ROW_NONE
-            if (q < q1) v = rec2[q];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            row[2 * j] = (uint32_t)(v.x >> REC_KEY_BITS);
-            row[2 * j + 1] = (uint32_t)(v.y >> REC_KEY_BITS);
-            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
-            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
-            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
-            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
-            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
-        }
+        pr.load(base, v, ~0ull);                                    // a padding lane carries ROW_NONE
+        pr.live(base, live);
+        split32(v, tag_mask, hsh, smask, tg, ss, row);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
             live[j] = live[j] && row[j] != ROW_NONE;
@@ -1491,28 +1472,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_emit32_kernel(const ui
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
     if (threadIdx.x == 0) emitted = 0;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) { tags[i] = 0u; cnts[i] = 0u; }
+    planes_from_slice(tags, cnts, n_slots, tag_mask, nullptr);
     __syncthreads();
     bool full = false;
-    const int64_t q0 = r0 >> 1, q1 = (r1 + 1) >> 1;
-    const ulonglong2 *rec2 = reinterpret_cast<const ulonglong2 *>(rec);
-    const int64_t stride = (int64_t)BIG_BLOCK * (CNT_BATCH / 2);
-    for (int64_t base = q0; base < q1; base += stride) {               // ---- count
-        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH];
+    const PairRange pr(rec, r0, r1);
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {       // ---- count
+        ulonglong2 v[CNT_BATCH / 2];
+        uint32_t tg[CNT_BATCH], ss[CNT_BATCH], row[CNT_BATCH], first[CNT_BATCH];
         bool live[CNT_BATCH];
-#pragma unroll
-        for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            ulonglong2 v = make_ulonglong2(0ull, 0ull);
-            if (q < q1) v = rec2[q];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
-            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
-            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
-            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
-            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
-        }
+        pr.load(base, v, 0ull);
+        pr.live(base, live);
+        split32(v, tag_mask, hsh, smask, tg, ss, row);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
 #define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
@@ -1521,30 +1491,15 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_emit32_kernel(const ui
     }
     if (full) atomicOr(status, 1u);
     __syncthreads();
-    const uint64_t high = (uint64_t)blockIdx.x << tag_bits;            // ---- the slice image (stores overlap the lookups)
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
-        const uint32_t tg = tags[i], c = cnts[i];
-        slice[i] = tg ? ((high | (tg & tag_mask)) << HASH_CBITS) | (c < HASH_SAT ? c : HASH_SAT) : 0ull;
-    }
+    slice_from_planes(tags, cnts, n_slots, tag_mask, (uint64_t)blockIdx.x << tag_bits, slice);      // ---- the slice image (stores overlap the lookups)
     const uint32_t lane = threadIdx.x & 63;
-    for (int64_t base = q0; base < q1; base += stride) {               // ---- lookups of the same records
+    for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {       // ---- lookups of the same records
+        ulonglong2 v[CNT_BATCH / 2];
         uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH], row[CNT_BATCH];
         bool live[CNT_BATCH];
-#pragma unroll
-        for (int j = 0; j < CNT_BATCH / 2; ++j) {
-            const int64_t q = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            ulonglong2 v = make_ulonglong2(~0ull, ~0ull);
-            if (q < q1) v = rec2[q];
-            live[2 * j] = q < q1 && 2 * q >= r0;
-            live[2 * j + 1] = q < q1 && 2 * q + 1 < r1;
-            row[2 * j] = (uint32_t)(v.x >> REC_KEY_BITS);
-            row[2 * j + 1] = (uint32_t)(v.y >> REC_KEY_BITS);
-            const uint64_t k0 = v.x & REC_KEY_MASK, k1 = v.y & REC_KEY_MASK;
-            tg[2 * j] = ((uint32_t)k0 & tag_mask) | 0x80000000u;
-            tg[2 * j + 1] = ((uint32_t)k1 & tag_mask) | 0x80000000u;
-            ss[2 * j] = (uint32_t)(k0 >> hsh) & smask;
-            ss[2 * j + 1] = (uint32_t)(k1 >> hsh) & smask;
-        }
+        pr.load(base, v, ~0ull);                                    // a padding lane carries ROW_NONE
+        pr.live(base, live);
+        split32(v, tag_mask, hsh, smask, tg, ss, row);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
             live[j] = live[j] && row[j] != ROW_NONE;
