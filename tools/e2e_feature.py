@@ -18,7 +18,7 @@ tmp = tempfile.mkdtemp(prefix="pg_e2e_")
 fq = os.path.join(tmp, "reads.fq")
 cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=n_pairs // 200, seed=5)
 t0 = time.perf_counter()
-synth.write_fastq(synth.generate(cfg, device="cuda:0"), cfg, fq)
+synth.write_fastq(synth.generate(cfg, device="cuda:0", chunk_pairs=1 << 17), cfg, fq)
 print(f"(wrote {os.path.getsize(fq) / 1e6:.0f} MB FASTQ in {time.perf_counter() - t0:.1f} s)")
 torch.cuda.synchronize()
 kmer.count_kmers(synth.generate(synth.SynthConfig(n_pairs=2000, n_barcodes=10), device="cuda:0"), 21)   # warm the runtime
@@ -31,6 +31,7 @@ def lap(msg, t):
     return now
 
 
+torch.cuda.empty_cache()          # (the generator's temporaries: otherwise the first big allocation pays for flushing them)
 t = t_all = time.perf_counter()
 host = ReadStream.from_fastq(fq); t = lap("ingest (threaded parse + pack)", t)
 s = host.to("cuda:0"); t = lap("H2D (pageable)", t)
