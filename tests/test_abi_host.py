@@ -291,3 +291,16 @@ def test_packed_stream_cache_round_trip(tmp_path):
     open(path, "wb").write(b"@r1\nACGT\n")
     with pytest.raises(ValueError, match="not a packed read stream"):
         ReadStream.load(path)
+
+
+def test_sharded_ingest_of_degenerate_files(tmp_path):
+    """an empty file, a single pair and a file that ends inside its first record: any number of shards gives the whole-file runs"""
+    cases = {"empty.fq": "", "one.fq": "@r BX:Z:AAAA-1\nACGT\n+\nIIII\n@r BX:Z:AAAA-1\nTTGG\n+\nIIII\n", "partial.fq": "@r BX:Z:AAAA-1\nACGT\n+\n"}
+    for name, content in cases.items():
+        path = str(tmp_path / name)
+        open(path, "w").write(content)
+        whole = ReadStream.from_fastq(path)
+        for parts in (1, 2, 5):
+            shards = [ReadStream.from_fastq_shard(path, r, parts) for r in range(parts)]
+            assert [n for s in shards for n in s.run_names] == whole.run_names
+            assert sum(s.n_chars for s in shards) == whole.n_chars and sum(s.n_pairs for s in shards) == whole.n_pairs
