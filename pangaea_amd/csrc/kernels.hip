@@ -2323,10 +2323,12 @@ static int abundance_impl(const pg_table *t, const pg_rows *rows, int window, in
     } else
     hipLaunchKernelGGL(bucket_lookup_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, recs, off, view_of(t), (uint32_t)window, (uint32_t)vsize, sp.vbits,
                        words_e, emit_end);
-    // S2a: scatter the words by the first gb1 bits of their row group (global cursors: measured faster here than
-    // per-bucket offsets, unlike the stream pass, because a bucket's few tiles would be serialised in one workgroup)
+    // S2a: scatter the words by the first gb1 bits of their row group (destinations from global cursors, one add per digit
+    // and tile)
     {
-        const int tiles_x = 4;
+        // ONE workgroup per bucket walks the bucket's tiles (about five wide ones): measured 10.5 ms against 12.2 / 13.8 / 14.9 ms with
+        // 2 / 4 / 8 workgroups per bucket -- every workgroup first waits for the two dependent loads of its region bounds
+        const int tiles_x = 1;
         if (sp.gb1 > MAX_FAN_BITS)         // all row groups in ONE pass: bigger tiles keep the runs per group at 64 B
             hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32_WIDE, WIDE_FAN_BITS>), dim3((unsigned)(tiles_x * nb)), dim3(BLOCK), 0, s,
                                (const uint32_t *)words_e, off, (const unsigned long long *)emit_end, 0, (const unsigned long long *)nullptr, tiles_x,
