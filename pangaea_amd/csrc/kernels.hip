@@ -654,14 +654,28 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
         }
         __syncthreads();
         scatter_scan(L, n_dig);
-        for (int d = threadIdx.x; d < n_dig; d += BLOCK) {          // cnt[] is gone (it shared gbase's storage): start[] has it
-            const uint32_t c = L.start[d + 1] - L.start[d];
-            if (c) L.gbase[d] = obase[(base_index + d) << oshift] + atomicAdd(&cursor[base_index + d], (unsigned long long)c) - L.start[d];
+        // the returning cursor adds (one per digit and tile) are issued first and consumed after the placement: their round
+        // trip to L2 overlaps the LDS stores instead of standing in front of them
+        constexpr int DPL = ((1 << FAN_BITS) + BLOCK - 1) / BLOCK;  // digits per lane
+        unsigned long long gpos[DPL];
+#pragma unroll
+        for (int q = 0; q < DPL; ++q) {                             // cnt[] is gone (it shared gbase's storage): start[] has it
+            const int d = (int)threadIdx.x + q * BLOCK;
+            gpos[q] = 0;
+            if (d < n_dig) {
+                const uint32_t c = L.start[d + 1] - L.start[d];
+                if (c) gpos[q] = obase[(base_index + d) << oshift] + atomicAdd(&cursor[base_index + d], (unsigned long long)c) - L.start[d];
+            }
         }
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
+        }
+#pragma unroll
+        for (int q = 0; q < DPL; ++q) {
+            const int d = (int)threadIdx.x + q * BLOCK;
+            if (d < n_dig) L.gbase[d] = gpos[q];
         }
         __syncthreads();
         const uint32_t total = L.start[n_dig];
