@@ -12,6 +12,8 @@ The reference is single-process; the decomposition is the build's own (SURVEY 8e
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -366,8 +368,9 @@ def _exchange_bucketed(table: KmerTable, group=None) -> None:
     cuts = [nb * c // n_ranges for c in range(n_ranges + 1)]
     at = seg[:, cuts]                                                            # [world, n_ranges + 1]
     sizes = at[:, 1:] - at[:, :-1]
-    if table.pending and table.tag_bits <= 31 and PLANES:
-        if world >= OWNER_MIN_WORLD and nb >= 64 * world:
+    form = os.environ.get("PG_EXCHANGE", "")          # "" = choose; "allgather8" / "allgather6" / "owner" force one form (debugging)
+    if table.pending and table.tag_bits <= 31 and PLANES and form != "allgather8":
+        if form == "owner" or (form == "" and world >= OWNER_MIN_WORLD and nb >= 64 * world):
             _exchange_owner(table, group, me, world, seg)
         else:
             _exchange_planes(table, group, me, world, seg, cuts, at, sizes)
