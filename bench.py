@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-dist", type=int, default=0, metavar="N",
                     help="one GPU: run the N-rank code path (deferred count, exchange over a one-rank RCCL group, table sized for N shards) -- not a result")
+    ap.add_argument("--load", type=float, default=0.6, help="highest load of the hash table (its size is the next power of two)")
     ap.add_argument("--no-fuse", action="store_true", help="N = 1: separate count and lookup kernels (as N > 1 must run them)")
     ap.add_argument("--no-defer", action="store_true", help="N > 1: write every rank's own table and compact it (instead of the deferred count)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
@@ -161,7 +162,7 @@ def main():
                                device=dev, chunk_pairs=1 << 17, with_names=False)
         regs = torch.maximum(regs, kmer.distinct_sketch(other, K_ABD).to(regs.device))
         del other
-    table = kmer.KmerTable.alloc(K_ABD, dev, "hash", distinct_hint=max(1 << 14, int(1.05 * kmer.sketch_estimate(regs))), load=0.6)
+    table = kmer.KmerTable.alloc(K_ABD, dev, "hash", distinct_hint=max(1 << 14, int(1.05 * kmer.sketch_estimate(regs))), load=args.load)
     # N > 1: a rank's own keys are 2^g times sparser than the union and are counted in deferred form (entries + fills for
     # the exchange; the rank's own sparse table is never written)
     defer = pdist.deferred_group_for(table, int(1.1 * local_distinct)) if multi and not args.no_defer else None
