@@ -86,6 +86,11 @@ int64_t pg_reads_n_unpaired(const pg_reads *r);
 int64_t pg_reads_n_runs(const pg_reads *r);
 const uint64_t *pg_reads_codes(const pg_reads *r);
 const uint32_t *pg_reads_valid(const pg_reads *r);
+/* NULL, or the plane of LOWER-case a c g t (same layout as valid) when the input has any: jellyfish counts them as bases
+ * (feature.py:94), the reference's own counters reset on them (count_tnf.cpp:91-96) -- so `valid` excludes them, their
+ * codes are in `codes` all the same, and a caller that wants jellyfish's table counts with valid | lower (and gives the
+ * strict plane in pg_rows.strict_valid). */
+const uint32_t *pg_reads_lower(const pg_reads *r);
 const int64_t *pg_reads_run_off(const pg_reads *r); /* [n_runs + 1] */
 const char *pg_reads_run_name(const pg_reads *r, int64_t i);
 /* "" (undecided), "10x" or "stLFR": the header mode the file latched (count_tnf.cpp:27-32) */
@@ -98,6 +103,8 @@ int64_t pg_reads_rows(const pg_reads *r, int min_len, int64_t *row_run);
  * already hold reads in memory).  codes/valid must hold pg_words_for(n) words. */
 int64_t pg_words_for(int64_t n_chars);
 int pg_pack_ascii(const char *text, int64_t n_chars, uint64_t *codes, uint32_t *valid);
+/* the same with the lower-case plane (may be NULL); returns 1 if the text has lower-case bases, 0 if not */
+int pg_pack_ascii_lower(const char *text, int64_t n_chars, uint64_t *codes, uint32_t *valid, uint32_t *lower);
 
 /* Split rows into work segments of at most seg_chars characters (a multiple of 32).  Call with
  * seg_row == NULL to obtain the number of segments.  Host arrays. */
@@ -174,6 +181,11 @@ typedef struct {
     const int64_t *row_start; /* device [n_rows] */
     const int64_t *row_end;   /* device [n_rows] */
     int64_t n_rows;           /* < 2^22 - 1 per launch */
+    /* NULL, or the STRICT validity plane (upper-case ACGT only) when the `valid` plane given to the counting call also
+     * accepts lower-case bases -- jellyfish counts them (feature.py:94), the reference's own row counters reset on them
+     * (count_kmer.cpp:73-78): k-mers that are only valid under the lenient rule enter the table but no row.  Device
+     * uint32_t[n_words], same layout as `valid`. */
+    const uint32_t *strict_valid;
 } pg_rows;
 
 /* The same result as pg_kmer_count for a bucketed hash table, without random HBM traffic: the k-mer

@@ -54,20 +54,23 @@ namespace {
 struct StreamWriter {
     std::vector<uint64_t> codes;
     std::vector<uint32_t> valid;
+    std::vector<uint32_t> lower;   // bit set for a LOWER-case a c g t: a base for jellyfish, a reset for the reference's own counters
+    bool any_lower = false;
     int64_t n = 0;          // characters written
     uint64_t cw = 0;        // word under construction
-    uint32_t vw = 0;
+    uint32_t vw = 0, lw = 0;
 
     inline void put(unsigned char c)
     {
-        // A C G T -> valid with code (c>>1)&3 ; everything else (N, lower case, IUPAC, '\r', separators) invalid
+        // A C G T -> valid with code (c>>1)&3 ; everything else (N, lower case, IUPAC, '\r', separators) invalid.
+        // a c g t keep their code ((c>>1)&3 is the same in both cases) and are marked in the `lower` plane.
         const bool ok = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+        const bool lo = (c == 'a') | (c == 'c') | (c == 'g') | (c == 't');
         const int sh = (int)(n & 31);
-        if (ok) {
-            cw |= (uint64_t)((c >> 1) & 3) << (2 * sh);
-            vw |= 1u << sh;
-        }
-        if (sh == 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; }
+        if (ok | lo) cw |= (uint64_t)((c >> 1) & 3) << (2 * sh);
+        if (ok) vw |= 1u << sh;
+        if (lo) { lw |= 1u << sh; any_lower = true; }
+        if (sh == 31) { codes.push_back(cw); valid.push_back(vw); lower.push_back(lw); cw = 0; vw = 0; lw = 0; }
         ++n;
     }
     void put_span(const char *s, size_t len)
@@ -76,12 +79,13 @@ struct StreamWriter {
     }
     void finish()
     {
-        if (n & 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; }
+        if (n & 31) { codes.push_back(cw); valid.push_back(vw); lower.push_back(lw); cw = 0; vw = 0; lw = 0; }
         size_t words = codes.size();
         size_t padded = (words + PG_WORD_ALIGN - 1) / PG_WORD_ALIGN * PG_WORD_ALIGN;
         if (padded == 0) padded = PG_WORD_ALIGN;
         codes.resize(padded, 0);
         valid.resize(padded, 0);
+        if (any_lower) lower.resize(padded, 0); else std::vector<uint32_t>().swap(lower);
     }
 };
 
@@ -253,6 +257,8 @@ struct pg_reads {
     void *huge_c = nullptr, *huge_v = nullptr;   // ... the threaded one in uninitialised huge-page arrays
     uint64_t *codes_w = nullptr;
     uint32_t *valid_w = nullptr;
+    uint32_t *lower_w = nullptr;                 // NULL unless the input has lower-case bases
+    std::vector<uint32_t> lower_plane;           // (the threaded path keeps the rare plane here)
     int64_t n_words = 0, n_chars = 0;
     std::vector<int64_t> run_off;      // [n_runs + 1]
     std::vector<std::string> run_name;
@@ -267,6 +273,7 @@ struct pg_reads {
     {
         st.finish();
         codes_w = st.codes.data(); valid_w = st.valid.data();
+        lower_w = st.any_lower ? st.lower.data() : nullptr;
         n_words = (int64_t)st.codes.size(); n_chars = st.n;
     }
     bool alloc_stream(int64_t total_chars)
@@ -492,9 +499,24 @@ bool simd_ok()
     return ok;
 }
 
+// lower-case a c g t of a block of `count` <= 32 characters that is not all upper-case bases (the rare path): their mask,
+// and their codes OR-ed into cb (a base keeps its code in both cases: (c >> 1) & 3)
+inline uint32_t lower_bases(const char *s, int count, uint64_t &cb)
+{
+    uint32_t lb = 0;
+    for (int i = 0; i < count; ++i) {
+        const unsigned char c = (unsigned char)s[i];
+        if ((c == 'a') | (c == 'c') | (c == 'g') | (c == 't')) { lb |= 1u << i; cb |= (uint64_t)((c >> 1) & 3) << (2 * i); }
+    }
+    return lb;
+}
+
+struct LowerMask { int64_t pos; uint32_t mask; };     // lower-case bases at characters pos .. pos + 31 of the thread's stream
+
 struct LocalStream {          // one thread's characters, packed from bit 0
     std::vector<uint64_t> codes;
     std::vector<uint32_t> valid;
+    std::vector<LowerMask> lower;         // sparse: sequencer reads are upper case
     int64_t n = 0;
     uint64_t cw = 0; uint32_t vw = 0;
     const bool simd = simd_ok();
@@ -515,12 +537,26 @@ struct LocalStream {          // one thread's characters, packed from bit 0
     {
         size_t i = 0;
         uint64_t cb; uint32_t vb;
-        if (simd) for (; i + 32 <= len; i += 32) { pack32_avx2(s + i, cb, vb); put_bits(cb, vb, 32); }
-        for (; i + 8 <= len; i += 8) { uint64_t x; memcpy(&x, s + i, 8); pack8(x, cb, vb); put_bits(cb, vb, 8); }
+        if (simd) for (; i + 32 <= len; i += 32) {
+            pack32_avx2(s + i, cb, vb);
+            if (vb != 0xffffffffu) note_lower(s + i, 32, cb);
+            put_bits(cb, vb, 32);
+        }
+        for (; i + 8 <= len; i += 8) {
+            uint64_t x; memcpy(&x, s + i, 8); pack8(x, cb, vb);
+            if (vb != 0xffu) note_lower(s + i, 8, cb);
+            put_bits(cb, vb, 8);
+        }
         uint64_t x = 0;
         memcpy(&x, s + i, len - i);                  // < 8 characters, zero padded (zero bytes are invalid), then the separator
         pack8(x, cb, vb);
+        if (len - i) note_lower(s + i, (int)(len - i), cb);
         put_bits(cb, vb, (int)(len - i) + 1);
+    }
+    inline void note_lower(const char *s, int count, uint64_t &cb)
+    {
+        const uint32_t lb = lower_bases(s, count, cb);
+        if (lb) lower.push_back(LowerMask{n, lb});
     }
     void finish() { if (n & 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; } }
 };
@@ -628,6 +664,19 @@ int ingest_interleaved_range(int fd, size_t A, size_t B, const char *path, pg_re
             else { gc[g] = c; gv[g] = v; }
         }
     });
+    bool any_lower = false;
+    for (int t = 0; t < T; ++t) any_lower |= !out[t].st.lower.empty();
+    if (any_lower) {                                  // rare: a dense plane, bits set from the threads' sparse lists
+        R->lower_plane.assign((size_t)R->n_words, 0u);
+        for (int t = 0; t < T; ++t)
+            for (const LowerMask &m : out[t].st.lower) {
+                const int64_t pos = cstart[t] + m.pos;
+                const int sh = (int)(pos & 31);
+                R->lower_plane[(size_t)(pos >> 5)] |= m.mask << sh;
+                if (sh && (m.mask >> (32 - sh))) R->lower_plane[(size_t)(pos >> 5) + 1] |= m.mask >> (32 - sh);
+            }
+        R->lower_w = R->lower_plane.data();
+    }
     tm.lap("place");
     // ---- D. runs: the first complete pair of a thread is compared with the last one of the threads before it
     R->mode = L.mode;
@@ -923,6 +972,7 @@ extern "C" int64_t pg_reads_n_unpaired(const pg_reads *r) { return r->n_unpaired
 extern "C" int64_t pg_reads_n_runs(const pg_reads *r) { return (int64_t)r->run_name.size(); }
 extern "C" const uint64_t *pg_reads_codes(const pg_reads *r) { return r->codes_w; }
 extern "C" const uint32_t *pg_reads_valid(const pg_reads *r) { return r->valid_w; }
+extern "C" const uint32_t *pg_reads_lower(const pg_reads *r) { return r->lower_w; }
 extern "C" const int64_t *pg_reads_run_off(const pg_reads *r) { return r->run_off.data(); }
 extern "C" const char *pg_reads_run_name(const pg_reads *r, int64_t i)
 {
@@ -954,20 +1004,29 @@ extern "C" int64_t pg_words_for(int64_t n_chars)
     return padded ? padded : PG_WORD_ALIGN;
 }
 
-extern "C" int pg_pack_ascii(const char *text, int64_t n_chars, uint64_t *codes, uint32_t *valid)
+extern "C" int pg_pack_ascii_lower(const char *text, int64_t n_chars, uint64_t *codes, uint32_t *valid, uint32_t *lower)
 {
     if (n_chars < 0 || (n_chars > 0 && !text) || !codes || !valid) return pg_fail(PG_EINVAL, "pg_pack_ascii: bad arguments");
     const int64_t words = pg_words_for(n_chars);
     memset(codes, 0, (size_t)words * sizeof(uint64_t));
     memset(valid, 0, (size_t)words * sizeof(uint32_t));
+    if (lower) memset(lower, 0, (size_t)words * sizeof(uint32_t));
+    int any = 0;
     for (int64_t i = 0; i < n_chars; ++i) {
         const unsigned char c = (unsigned char)text[i];
-        if (c == 'A' || c == 'C' || c == 'G' || c == 'T') {
-            codes[i >> 5] |= (uint64_t)((c >> 1) & 3) << (2 * (i & 31));
-            valid[i >> 5] |= 1u << (i & 31);
-        }
+        const bool up = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+        const bool lo = c == 'a' || c == 'c' || c == 'g' || c == 't';
+        if (up || lo) codes[i >> 5] |= (uint64_t)((c >> 1) & 3) << (2 * (i & 31));
+        if (up) valid[i >> 5] |= 1u << (i & 31);
+        if (lo && lower) { lower[i >> 5] |= 1u << (i & 31); any = 1; }
     }
-    return PG_OK;
+    return any;             // 1: the text has lower-case bases (only reported when `lower` is given)
+}
+
+extern "C" int pg_pack_ascii(const char *text, int64_t n_chars, uint64_t *codes, uint32_t *valid)
+{
+    const int rc = pg_pack_ascii_lower(text, n_chars, codes, valid, nullptr);
+    return rc < 0 ? rc : PG_OK;
 }
 
 extern "C" int64_t pg_plan_segments(const int64_t *row_start, const int64_t *row_end, int64_t n_rows, int64_t seg_chars,

@@ -510,7 +510,8 @@ static_assert(CHUNK_WORDS % A1_TILE_WORDS == 0, "a chunk is a whole number of st
 __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                                int64_t word_begin, int64_t word_end, int k, int bits1,
                                                                const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end,
-                                                               int64_t n_rows, const int32_t *__restrict__ tile_row,
+                                                               int64_t n_rows, const uint32_t *__restrict__ strict,
+                                                               const int32_t *__restrict__ tile_row,
                                                                uint64_t *__restrict__ rec_out,
                                                                const unsigned long long *__restrict__ chunk_off, int64_t n_chunks,
                                                                int64_t chunk_stride)
@@ -536,6 +537,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
         if (w < word_end) {
             const Word x = load_word(codes, valid, w, k);
             ok = (uint32_t)(((uint64_t)x.ok >> (A1_CHARS * half)) & ((1ull << A1_CHARS) - 1ull));
+            // `valid` may count lower-case bases as bases (jellyfish's rule for the table); the rows follow the reference's own
+            // counters, which do not: with a second, strict validity plane a k-mer that is only valid under the lenient rule is
+            // counted but belongs to no row
+            uint32_t ok_row = ok;
+            if (strict && ok) {
+                const uint32_t sv = strict[w], sp = w > 0 ? strict[w - 1] : 0u;
+                ok_row &= (uint32_t)(((runs_of(((uint64_t)sv << 32) | sp, k) >> 32) >> (A1_CHARS * half)) & ((1ull << A1_CHARS) - 1ull));
+            }
             if (ok) {
                 // row bookkeeping: r = first row that can still contain a position >= the current one
                 int64_t r = n_rows, rs = INT64_MAX, re = INT64_MAX;
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
                             rs = r < n_rows ? row_start[r] : INT64_MAX;
                             re = r < n_rows ? row_end[r] : INT64_MAX;
                         }
-                        const uint64_t row = pos >= rs ? (uint64_t)r : (uint64_t)ROW_NONE;
+                        const uint64_t row = (pos >= rs && ((ok_row >> j) & 1)) ? (uint64_t)r : (uint64_t)ROW_NONE;
                         const uint64_t key = key42(rl.canon());
                         const uint32_t d = (uint32_t)(key >> dsh);
                         rec[j] = key | (row << REC_KEY_BITS);
@@ -2072,7 +2081,8 @@ int count_bucketed_impl(const uint64_t *codes, const uint32_t *valid, int64_t wo
     // A1: stream -> 2^bits1 regions (region d1 = final buckets [d1 << bits2, (d1+1) << bits2)); one workgroup per chunk
     hipLaunchKernelGGL(scatter_stream_kernel, dim3((unsigned)p.n_chunks), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k, p.bits1,
                        with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
-                       with_rows ? rows->n_rows : (int64_t)0, (const int32_t *)tile_row, bufa, (const unsigned long long *)chunk_tab, p.n_chunks,
+                       with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
+                       (const int32_t *)tile_row, bufa, (const unsigned long long *)chunk_tab, p.n_chunks,
                        chunk_stride);
     // A2: every region -> its 2^bits2 final buckets
     if (p.bits2) {

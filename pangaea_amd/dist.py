@@ -67,7 +67,18 @@ def shard_stream(stream: ReadStream, rank: int, world: int) -> ReadStream:
         codes = torch.cat([codes, codes.new_zeros(pad)])
         valid = torch.cat([valid, valid.new_zeros(pad)])
     run_off = stream.run_off[first:last + 1] - 32 * w0
-    return ReadStream(codes, valid, c1 - 32 * w0, run_off.astype(np.int64), stream.run_names[first:last], mode=stream.mode)
+    lower = None
+    if stream.valid_lower is not None:          # the lower-case plane is cut and masked exactly like `valid`
+        lower = stream.valid_lower[w0:w1].clone()
+        if lower.numel():
+            lv = lower.to(torch.int64) & 0xFFFFFFFF
+            lv[0] &= keep_first
+            lv[-1] &= keep_last
+            lower = torch.where(lv >= (1 << 31), lv - (1 << 32), lv).to(torch.int32)
+        if pad:
+            lower = torch.cat([lower, lower.new_zeros(pad)])
+    return ReadStream(codes, valid, c1 - 32 * w0, run_off.astype(np.int64), stream.run_names[first:last], mode=stream.mode,
+                      valid_lower=lower)
 
 
 def ingest_shard(reads1: str, reads2: str | None = None, group=None) -> ReadStream:
@@ -146,7 +157,8 @@ def deferred_group_for(table: KmerTable, local_distinct: int) -> int | None:
     return max(0, table.log2_slots - local_log2)
 
 
-def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_log2_slots: int = 36) -> KmerTable:
+def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_log2_slots: int = 36,
+                        lowercase_is_base: bool = False) -> KmerTable:
     """the global table of all ranks' streams, on every rank: the distributed form of ``kmer.count_kmers``.
 
     The ranks' HyperLogLog sketches are combined with an all-reduce(MAX) -- the sketch of the union -- so every rank
@@ -156,8 +168,8 @@ def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_l
     from . import _lib, kmer
     kind = KmerTable.default_kind(k)
     if kind == "dense":
-        return exchange_table(KmerTable.alloc(k, stream.device, kind).count(stream), group)
-    regs = kmer.distinct_sketch(stream, k)
+        return exchange_table(KmerTable.alloc(k, stream.device, kind).count(stream, lowercase_is_base=lowercase_is_base), group)
+    regs = kmer.distinct_sketch(stream, k, lowercase_is_base=lowercase_is_base)
     local = kmer.sketch_estimate(regs)
     union = _staged(regs.clone(), group)
     dist.all_reduce(union, op=dist.ReduceOp.MAX, group=group)
@@ -180,9 +192,9 @@ def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_l
         g = deferred_group_for(table, int(1.1 * local)) if kind == "hash" else None
         # the exchange takes different collectives for deferred and materialised counts: all ranks must take the same form
         if everyone(g is not None and table.can_defer(stream.n_words)):
-            table.count(stream, rows=rows, deferred_group=g, check=False)
+            table.count(stream, rows=rows, deferred_group=g, check=False, lowercase_is_base=lowercase_is_base)
         else:
-            table.count(stream, rows=rows, check=False)
+            table.count(stream, rows=rows, check=False, lowercase_is_base=lowercase_is_base)
         full = any_full()
         if not full:
             exchange_table(table, group, check=False)

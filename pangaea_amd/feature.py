@@ -86,7 +86,7 @@ def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | Non
 
 def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window: int, vsize: int, min_len: int,
                      device=None, want_tnf: bool = True, want_abd: bool = True, table: KmerTable | None = None,
-                     stream_cache: str | None = None):
+                     stream_cache: str | None = None, lowercase_is_base: bool = False):
     """(names, tnf int32 ndarray or None, abd int32 ndarray or None) of a barcode-sorted FASTQ, on the GPU.
     Under an initialised ``torch.distributed`` group every rank takes a contiguous range of runs, the table is
     exchanged once, and the rows are gathered so every rank returns the full matrices."""
@@ -97,7 +97,8 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     rows = stream.rows(min_len)
     plan = Plan(rows, device)
     if want_abd and table is None:
-        table = pdist.count_kmers_sharded(stream, k, rows=plan) if world > 1 else count_kmers(stream, k, rows=plan, emit=(window, vsize))
+        table = (pdist.count_kmers_sharded(stream, k, rows=plan, lowercase_is_base=lowercase_is_base) if world > 1
+                 else count_kmers(stream, k, rows=plan, emit=(window, vsize), lowercase_is_base=lowercase_is_base))
     tnf, abd = features(stream, plan, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
                         window=window, vsize=vsize)
     names = list(rows.names)
@@ -151,7 +152,9 @@ class Feature:
             cache = os.path.join(self.feature_dir, "reads") if os.environ.get("PANGAEA_STREAM_CACHE", "0") not in ("", "0") else None
             self._cache = compute_features(r1, r2, int(self.kmer), int(self.tnf_k), int(self.ws), int(self.vs), int(self.minl),
                                            device=getattr(self.args, "device", None), want_tnf=want_tnf, want_abd=want_abd,
-                                           stream_cache=cache)
+                                           stream_cache=cache,
+                                           # jellyfish's rule for the multiplicity table (soft-masked input only)
+                                           lowercase_is_base=os.environ.get("PANGAEA_LOWERCASE_IS_BASE", "0") not in ("", "0"))
         return self._cache
 
     # ------------------------------------------------------------------ the reference's public methods

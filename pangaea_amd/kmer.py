@@ -177,7 +177,8 @@ class KmerTable:
         return self._shuffle_ws
 
     def count(self, stream: ReadStream, word_begin: int = 0, word_end: int | None = None, check: bool = True,
-              rows: "Plan | None" = None, deferred_group: int | None = None, emit: tuple | None = None) -> "KmerTable":
+              rows: "Plan | None" = None, deferred_group: int | None = None, emit: tuple | None = None,
+              lowercase_is_base: bool = False) -> "KmerTable":
         """add the k-mers ending in words [word_begin, word_end) of the stream (asynchronous unless ``check``).
         With ``rows`` (a Plan of this stream's rows) a bucketed table also keeps the row-tagged partition records, which
         lets ``features`` build the abundance rows by shuffle instead of by table lookups.
@@ -190,12 +191,29 @@ class KmerTable:
         ``emit`` = (window, vector_size) (one GPU, a fresh table, ``rows`` given, at least 2^11 buckets): the lookup pass of
         the abundance rows is fused into the counting kernel -- a bucket's records are looked up while its counts are
         still in LDS -- and ``features`` with the same window and vector size starts from the emitted (row, bin) words.
-        Silently ignored where it does not apply."""
+        Silently ignored where it does not apply.
+
+        ``lowercase_is_base``: count lower-case a c g t as bases, as ``jellyfish count`` does (src/feature.py:94) -- the
+        reference's own row counters reset on them (count_kmer.cpp:73-78), so k-mers that are only valid under this rule
+        enter the table but belong to no row.  Only matters for soft-masked input (``stream.valid_lower`` is not None)."""
         _require_gpu(stream.codes, "the read stream")
         if stream.device != self.device:
             raise ValueError("stream and table are on different devices")
         word_end = stream.n_words if word_end is None else word_end
         L = _lib.load()
+        lenient = lowercase_is_base and stream.valid_lower is not None
+        valid_ptr = (stream.lenient_valid() if lenient else stream.valid).data_ptr()
+
+        def rows_arg(plan):
+            # the rows' own validity rule stays the strict one: with a lenient counting plane the strict plane rides along
+            if plan is None:
+                return None
+            if not lenient:
+                return C.byref(plan.rows_desc)
+            desc = _lib.pg_rows(plan.row_start.data_ptr(), plan.row_end.data_ptr(), plan.n_rows, stream.valid.data_ptr())
+            self._rows_desc_keepalive = desc
+            return C.byref(desc)
+
         if deferred_group is not None:
             if not self.can_defer(word_end - word_begin):
                 raise ValueError("deferred counting needs a fresh bucketed table with more than 256 buckets and a single pass")
@@ -204,8 +222,8 @@ class KmerTable:
             ws = self._workspace_for(word_end - word_begin)
             fill = torch.empty(self.n_buckets, dtype=torch.int64, device=self.device)
             with torch.cuda.device(self.device):
-                _lib.check(L.pg_kmer_count_deferred(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end, self.desc(), g,
-                                                    C.byref(keep.rows_desc) if keep is not None else None, ws.data_ptr(), ws.numel(),
+                _lib.check(L.pg_kmer_count_deferred(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), g,
+                                                    rows_arg(keep), ws.data_ptr(), ws.numel(),
                                                     fill.data_ptr(), self.status.data_ptr(), _stream_ptr(self.device)))
             self._empty = False
             self._deferred = (fill, word_end - word_begin)
@@ -228,8 +246,8 @@ class KmerTable:
                     n_words = word_end - word_begin
                     ws = self._workspace_for(n_words)
                     sws = self._shuffle_workspace_for(n_words, keep.n_rows, vsize)
-                    _lib.check(L.pg_kmer_count_bucketed_emit(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end, self.desc(),
-                                                             C.byref(keep.rows_desc), ws.data_ptr(), ws.numel(), window, vsize,
+                    _lib.check(L.pg_kmer_count_bucketed_emit(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(),
+                                                             rows_arg(keep), ws.data_ptr(), ws.numel(), window, vsize,
                                                              sws.data_ptr(), sws.numel(), self.status.data_ptr(), _stream_ptr(self.device)))
                     self._empty = False
                     self._records = (keep, n_words)
@@ -240,14 +258,14 @@ class KmerTable:
                 for w0 in range(word_begin, word_end, step):
                     w1 = min(word_end, w0 + step)
                     ws = self._workspace_for(w1 - w0)
-                    _lib.check(L.pg_kmer_count_bucketed(stream.codes.data_ptr(), stream.valid.data_ptr(), w0, w1, self.desc(),
-                                                        0 if self._empty else 1, C.byref(keep.rows_desc) if keep is not None else None,
+                    _lib.check(L.pg_kmer_count_bucketed(stream.codes.data_ptr(), valid_ptr, w0, w1, self.desc(),
+                                                        0 if self._empty else 1, rows_arg(keep),
                                                         ws.data_ptr(), ws.numel(), self.status.data_ptr(), _stream_ptr(self.device)))
                     self._empty = False
                 if keep is not None:
                     self._records = (keep, word_end - word_begin)
             else:
-                _lib.check(L.pg_kmer_count(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end,
+                _lib.check(L.pg_kmer_count(stream.codes.data_ptr(), valid_ptr, word_begin, word_end,
                                            self.desc(), self.status.data_ptr(), _stream_ptr(self.device)))
                 self._empty = False
         if check:
@@ -524,7 +542,8 @@ def key42_inverse(keys: np.ndarray) -> np.ndarray:
     return x
 
 
-def distinct_sketch(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None) -> torch.Tensor:
+def distinct_sketch(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None,
+                    lowercase_is_base: bool = False) -> torch.Tensor:
     """HyperLogLog registers (int32 [4096], on the device) of the stream's canonical k-mers.  The elementwise maximum of
     two sketches is the sketch of the union -- how the ranks of a multi-GPU job size their common table."""
     _require_gpu(stream.codes, "the read stream")
@@ -532,7 +551,8 @@ def distinct_sketch(stream: ReadStream, k: int, word_begin: int = 0, word_end: i
     regs = torch.zeros(_lib.HLL_REGISTERS, dtype=torch.int32, device=dev)
     word_end = stream.n_words if word_end is None else word_end
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().pg_kmer_distinct_sketch(stream.codes.data_ptr(), stream.valid.data_ptr(), word_begin, word_end, k,
+        valid = stream.lenient_valid() if lowercase_is_base else stream.valid
+        _lib.check(_lib.load().pg_kmer_distinct_sketch(stream.codes.data_ptr(), valid.data_ptr(), word_begin, word_end, k,
                                                        regs.data_ptr(), _stream_ptr(dev)))
     return regs
 
@@ -548,28 +568,29 @@ def sketch_estimate(regs: torch.Tensor) -> int:
     return int(est)
 
 
-def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None) -> int:
+def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end: int | None = None,
+                      lowercase_is_base: bool = False) -> int:
     """HyperLogLog estimate of the number of distinct canonical k-mers"""
-    return sketch_estimate(distinct_sketch(stream, k, word_begin, word_end))
+    return sketch_estimate(distinct_sketch(stream, k, word_begin, word_end, lowercase_is_base))
 
 
 def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hint: int | None = None,
                 max_log2_slots: int = 36, log2_bucket: int | None = None, rows: "Plan | None" = None,
-                emit: tuple | None = None) -> KmerTable:
+                emit: tuple | None = None, lowercase_is_base: bool = False) -> KmerTable:
     """build the table of one stream; a full hash table is re-built with four times the slots.  ``emit`` = (window,
     vector_size) fuses the lookup pass of the abundance rows into the count where that applies (``KmerTable.count``)."""
     resolved = kind or KmerTable.default_kind(k)
     if distinct_hint is None and resolved != "dense":
         # size from a HyperLogLog pass (as cheap as the bucket histogram) instead of guessing the coverage; +10 % covers
         # the estimator's error, load 0.4 leaves room for per-bucket variance
-        distinct_hint = max(1 << 13, int(1.1 * estimate_distinct(stream, k)))
+        distinct_hint = max(1 << 13, int(1.1 * estimate_distinct(stream, k, lowercase_is_base=lowercase_is_base)))
         load = 0.4
     else:
         load = 0.5
     table = KmerTable.alloc(k, stream.device, kind, distinct_hint, load=load, log2_bucket=log2_bucket)
     while True:
         try:
-            return table.count(stream, rows=rows, emit=emit)
+            return table.count(stream, rows=rows, emit=emit, lowercase_is_base=lowercase_is_base)
         except _lib.PangaeaError as e:
             if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
                 raise

@@ -55,6 +55,10 @@ class ReadStream:
     n_unpaired: int = 0
     mode: str = ""
     _owner: object = field(default=None, repr=False)     # keeps library-owned host memory alive
+    # int32 [n_words] or None: bit j set iff character j is a LOWER-case a c g t.  jellyfish counts those as bases, the
+    # reference's own counters reset on them: `valid` excludes them (their 2-bit codes are in `codes` all the same) and
+    # ``KmerTable.count(..., lowercase_is_base=True)`` counts with ``valid | valid_lower``.  None: the input has none.
+    valid_lower: torch.Tensor | None = None
 
     @property
     def n_words(self) -> int:
@@ -63,6 +67,14 @@ class ReadStream:
     @property
     def device(self) -> torch.device:
         return self.codes.device
+
+    def lenient_valid(self) -> torch.Tensor:
+        """the validity plane under jellyfish's rule (lower-case bases are bases); ``valid`` itself when there are none"""
+        if self.valid_lower is None:
+            return self.valid
+        if getattr(self, "_lenient", None) is None:
+            self._lenient = self.valid | self.valid_lower
+        return self._lenient
 
     # ------------------------------------------------------------------ constructors
 
@@ -105,10 +117,13 @@ class ReadStream:
         # zero-copy views of the library's arrays (the handle is freed with the last reference to this stream)
         codes = np.ctypeslib.as_array(C.cast(L.pg_reads_codes(h), C.POINTER(C.c_int64)), shape=(nw,))
         valid = np.ctypeslib.as_array(C.cast(L.pg_reads_valid(h), C.POINTER(C.c_int32)), shape=(nw,))
+        lower_ptr = L.pg_reads_lower(h)
+        lower = torch.from_numpy(np.ctypeslib.as_array(C.cast(lower_ptr, C.POINTER(C.c_int32)), shape=(nw,))) if lower_ptr else None
         run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
         names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
         out = cls(torch.from_numpy(codes), torch.from_numpy(valid), int(L.pg_reads_n_chars(h)), run_off, names,
-                  int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode(), _owner=owner)
+                  int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode(), _owner=owner,
+                  valid_lower=lower)
         return out
 
     @classmethod
@@ -121,23 +136,26 @@ class ReadStream:
         nw = words_for(len(text))
         codes = np.zeros(nw, dtype=np.int64)
         valid = np.zeros(nw, dtype=np.int32)
-        _lib.check(L.pg_pack_ascii(text, len(text), codes.ctypes.data, valid.ctypes.data))
-        return cls(torch.from_numpy(codes), torch.from_numpy(valid), len(text), off, [n for n, _ in runs]).to(device)
+        lower = np.zeros(nw, dtype=np.int32)
+        any_lower = _lib.check(L.pg_pack_ascii_lower(text, len(text), codes.ctypes.data, valid.ctypes.data, lower.ctypes.data))
+        return cls(torch.from_numpy(codes), torch.from_numpy(valid), len(text), off, [n for n, _ in runs],
+                   valid_lower=torch.from_numpy(lower) if any_lower else None).to(device)
 
     # ------------------------------------------------------------------ packed-stream cache
 
-    _MAGIC = b"PGSTRM1\0"
+    _MAGIC = b"PGSTRM2\0"
 
     def save(self, path: str) -> None:
         """write the packed stream and its runs to ``path``: a second pass over the same reads (another k, a restart, the
         other ranks of a job) then costs a file read at memcpy speed instead of a FASTQ parse.  Layout, little endian:
-        magic, int64 x 7 (n_chars, n_words, n_runs, n_pairs, n_unpaired, names_bytes, mode_bytes), mode, run_off,
-        NUL-terminated names, zero padding to 4096, codes (8 B/word), valid (4 B/word)."""
+        magic, int64 x 8 (n_chars, n_words, n_runs, n_pairs, n_unpaired, names_bytes, mode_bytes, has_lower), mode, run_off,
+        NUL-terminated names, zero padding to 4096, codes (8 B/word), valid (4 B/word), lower (4 B/word, if has_lower)."""
         codes = self.codes.cpu().numpy()
         valid = self.valid.cpu().numpy()
         names = b"".join(n.encode() + b"\0" for n in self.run_names)
         mode = self.mode.encode()
-        head = np.array([self.n_chars, codes.size, len(self.run_names), self.n_pairs, self.n_unpaired, len(names), len(mode)], dtype="<i8")
+        has_lower = int(self.valid_lower is not None)
+        head = np.array([self.n_chars, codes.size, len(self.run_names), self.n_pairs, self.n_unpaired, len(names), len(mode), has_lower], dtype="<i8")
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
             f.write(self._MAGIC); f.write(head.tobytes()); f.write(mode)
@@ -145,6 +163,8 @@ class ReadStream:
             f.write(b"\0" * (-f.tell() % 4096))
             codes.astype("<i8", copy=False).tofile(f)
             valid.astype("<i4", copy=False).tofile(f)
+            if has_lower:
+                self.valid_lower.cpu().numpy().astype("<i4", copy=False).tofile(f)
         os.replace(tmp, path)
 
     @classmethod
@@ -153,27 +173,29 @@ class ReadStream:
         with open(path, "rb") as f:
             if f.read(8) != cls._MAGIC:
                 raise ValueError(f"{path} is not a packed read stream")
-            n_chars, n_words, n_runs, n_pairs, n_unpaired, names_bytes, mode_bytes = (int(v) for v in np.frombuffer(f.read(56), dtype="<i8"))
+            n_chars, n_words, n_runs, n_pairs, n_unpaired, names_bytes, mode_bytes, has_lower = (int(v) for v in np.frombuffer(f.read(64), dtype="<i8"))
             mode = f.read(mode_bytes).decode()
             run_off = np.frombuffer(f.read(8 * (n_runs + 1)), dtype="<i8").astype(np.int64)
             names = f.read(names_bytes).split(b"\0")[:-1] if names_bytes else []
             at = f.tell() + (-f.tell() % 4096)
-        if len(names) != n_runs or os.path.getsize(path) != at + 12 * n_words or n_words != words_for(n_chars):
+        if len(names) != n_runs or os.path.getsize(path) != at + (16 if has_lower else 12) * n_words or n_words != words_for(n_chars):
             raise ValueError(f"{path} is truncated or inconsistent")
         codes = np.memmap(path, dtype="<i8", mode="r", offset=at, shape=(n_words,))
         valid = np.memmap(path, dtype="<i4", mode="r", offset=at + 8 * n_words, shape=(n_words,))
+        lower = np.memmap(path, dtype="<i4", mode="r", offset=at + 12 * n_words, shape=(n_words,)) if has_lower else None
         device = torch.device(device)
         if device.type == "cpu":
-            codes, valid = np.array(codes), np.array(valid)
+            codes, valid, lower = np.array(codes), np.array(valid), (None if lower is None else np.array(lower))
         return cls(torch.from_numpy(codes).to(device), torch.from_numpy(valid).to(device), n_chars, run_off, [n.decode() for n in names],
-                   n_pairs, n_unpaired, mode)
+                   n_pairs, n_unpaired, mode, valid_lower=None if lower is None else torch.from_numpy(lower).to(device))
 
     def to(self, device) -> "ReadStream":
         device = torch.device(device)
         if device == self.codes.device:
             return self
         return ReadStream(self.codes.to(device), self.valid.to(device), self.n_chars, self.run_off, self.run_names,
-                          self.n_pairs, self.n_unpaired, self.mode)
+                          self.n_pairs, self.n_unpaired, self.mode,
+                          valid_lower=None if self.valid_lower is None else self.valid_lower.to(device))
 
     # ------------------------------------------------------------------ rows
 

@@ -47,7 +47,8 @@ def _np_pack(text: bytes):
     nw = words_for(n)
     a = np.frombuffer(text, dtype=np.uint8)
     ok = np.isin(a, np.frombuffer(b"ACGT", dtype=np.uint8))
-    code = np.where(ok, (a >> 1) & 3, 0).astype(np.uint64)
+    base = np.isin(a, np.frombuffer(b"ACGTacgt", dtype=np.uint8))     # lower-case bases keep their code, but are not valid
+    code = np.where(base, (a >> 1) & 3, 0).astype(np.uint64)
     pad = nw * 32 - n
     code = np.concatenate([code, np.zeros(pad, np.uint64)]).reshape(nw, 32)
     okp = np.concatenate([ok, np.zeros(pad, bool)]).reshape(nw, 32).astype(np.uint64)
@@ -304,3 +305,56 @@ def test_sharded_ingest_of_degenerate_files(tmp_path):
             shards = [ReadStream.from_fastq_shard(path, r, parts) for r in range(parts)]
             assert [n for s in shards for n in s.run_names] == whole.run_names
             assert sum(s.n_chars for s in shards) == whole.n_chars and sum(s.n_pairs for s in shards) == whole.n_pairs
+
+
+def test_lower_case_plane_of_the_ingest(tmp_path):
+    """lower-case a c g t: not valid (the reference's counters reset on them), but marked in `valid_lower` with their codes in
+    place, identically by the sequential loop, the threaded parser (any block size) and byte-range shards"""
+    from pangaea_amd import synth
+    L = _lib.load()
+    cfg = synth.SynthConfig(n_pairs=5000, n_barcodes=31, n_genomes=2, genome_len=30_000, fragment=5_000, n_rate=0.05, seed=8)
+    fq = str(tmp_path / "soft.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, fq)
+    rng = np.random.RandomState(3)
+    lines = open(fq).read().splitlines(keepends=True)
+    for i in range(1, len(lines), 4):                             # soft-mask stretches of every third read
+        if rng.rand() < 0.33:
+            seq = lines[i].rstrip("\n")
+            a = rng.randint(0, len(seq)); b = min(len(seq), a + rng.randint(1, 60))
+            lines[i] = seq[:a] + seq[a:b].lower() + seq[b:] + "\n"
+    open(fq, "w").write("".join(lines))
+    try:
+        L.pg_set_ingest_threads(1)
+        ref = ReadStream.from_fastq(fq)
+        assert ref.valid_lower is not None
+        text = b"".join((l.rstrip("\n") + "N").encode() for l in lines[1::4])
+        want_lower = np.array([c in b"acgt" for c in text])
+        sh = np.arange(32, dtype=np.uint32)
+        got_lower = ((ref.valid_lower.numpy().view(np.uint32)[:, None] >> sh[None, :]) & 1).astype(bool).ravel()[:len(text)]
+        got_valid = ((ref.valid.numpy().view(np.uint32)[:, None] >> sh[None, :]) & 1).astype(bool).ravel()[:len(text)]
+        assert np.array_equal(got_lower, want_lower) and not (got_lower & got_valid).any()
+        codes = ((ref.codes.numpy().view(np.uint64)[:, None] >> (2 * sh.astype(np.uint64))[None, :]) & np.uint64(3)).ravel()[:len(text)]
+        up = np.frombuffer(text.upper(), dtype=np.uint8)
+        base = np.isin(up, np.frombuffer(b"ACGT", dtype=np.uint8))
+        assert np.array_equal(codes[base], ((up[base] >> 1) & 3).astype(np.uint64))
+        assert ref.decode() == bytes(c if c in b"ACGT" else ord("N") for c in text)          # the strict view is unchanged
+        for threads, block in ((4, None), (7, "1000")):
+            L.pg_set_ingest_threads(threads)
+            if block:
+                os.environ["PG_INGEST_BLOCK"] = block
+            got = ReadStream.from_fastq(fq)
+            assert np.array_equal(got.codes.numpy(), ref.codes.numpy()) and np.array_equal(got.valid.numpy(), ref.valid.numpy())
+            assert np.array_equal(got.valid_lower.numpy(), ref.valid_lower.numpy())
+            parts = [ReadStream.from_fastq_shard(fq, r, 3) for r in range(3)]
+            assert sum(int(torch.count_nonzero(p.valid_lower)) > 0 for p in parts if p.valid_lower is not None) >= 1
+            tot = sum(sum(bin(int(w) & 0xFFFFFFFF).count("1") for w in p.valid_lower.numpy()) for p in parts if p.valid_lower is not None)
+            assert tot == int(want_lower.sum())
+        # the cache keeps the plane
+        ref.save(str(tmp_path / "s.pgstream"))
+        back = ReadStream.load(str(tmp_path / "s.pgstream"))
+        assert np.array_equal(back.valid_lower.numpy(), ref.valid_lower.numpy())
+    finally:
+        L.pg_set_ingest_threads(0)
+        os.environ.pop("PG_INGEST_BLOCK", None)
+    plain = ReadStream.from_fastq(os.path.join(GOLDEN, "tenx_clean.fq.gz"))
+    assert plain.valid_lower is None

@@ -574,3 +574,51 @@ def test_fused_count_and_lookup_equals_separate_kernels(k, window, vsize, log2_s
     # where fusion does not apply (few buckets) the argument is ignored
     small = kmer.KmerTable.with_slots(k, DEV, 18, 14).count(s, rows=plan, emit=(window, vsize))
     assert small._emitted is None
+
+
+@pytest.mark.parametrize("log2_slots,log2_bucket,mode", [(22, 10, "plain"), (22, 10, "emit"), (22, 10, "deferred"), (18, 14, "plain"), (18, 0, "plain")])
+def test_lowercase_is_base_counts_like_jellyfish_and_rows_stay_strict(log2_slots, log2_bucket, mode):
+    """count(lowercase_is_base=True): the table is jellyfish's (lower-case a c g t are bases: the oracle's counter on the
+    upper-cased text), while the TNF / abundance rows keep the reference's own rule (its counters reset on lower case), in
+    the direct, bucketed, fused and deferred forms, by shuffle and by lookups"""
+    rng = np.random.RandomState(11)
+    runs = []
+    for b in range(12):
+        seq = bytearray(rng.choice(list(b"ACGT"), size=rng.randint(2500, 6000)).astype(np.uint8).tobytes())
+        for _ in range(rng.randint(0, 6)):                         # soft-masked stretches, a few N
+            a = rng.randint(0, len(seq)); e = min(len(seq), a + rng.randint(1, 80))
+            seq[a:e] = bytes(seq[a:e]).lower()
+        for _ in range(3):
+            seq[rng.randint(0, len(seq))] = ord("N")
+        runs.append((f"bc{b}", bytes(seq) + b"N"))
+    s = ReadStream.from_runs(runs, device=DEV)
+    assert s.valid_lower is not None
+    text = b"".join(t for _, t in runs)
+    k, window, vsize = 21, 1, 64
+    lenient = oracle.Table(k, threads=2).count(text.upper())
+    strict = oracle.Table(k, threads=2).count(text)
+    assert len(lenient.items()[0]) > len(strict.items()[0])
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.KmerTable.with_slots(k, DEV, log2_slots, log2_bucket)
+    if mode == "deferred":
+        t.count(s, rows=plan, deferred_group=1, lowercase_is_base=True)
+        fill = t.deferred_fill()
+        seg = torch.zeros((1, t.n_buckets + 1), dtype=torch.int64, device=DEV)
+        seg[0, 1:] = torch.cumsum(fill, 0)
+        buf = torch.empty(int(fill.sum()) + 1, dtype=torch.int64, device=DEV)
+        t.deferred_compact_into(buf, seg[0].contiguous())
+        t.rebuild_from(buf, seg)
+    else:
+        t.count(s, rows=plan, lowercase_is_base=True, emit=(window, vsize) if mode == "emit" else None)
+    assert all(np.array_equal(x, y) for x, y in zip(t.items(), lenient.items()))
+    tnf, abd = kmer.features(s, plan, k_tnf=4, table=t, window=window, vsize=vsize)
+    tnf2, abd2 = kmer.features(s, rows, k_tnf=4, table=t, window=window, vsize=vsize)           # lookup kernel: strict by construction
+    assert torch.equal(tnf, tnf2) and torch.equal(abd, abd2)
+    for i, (a, b) in enumerate(zip(rows.start, rows.end)):
+        seq = text[int(a):int(b)]
+        assert np.array_equal(tnf[i].cpu().numpy(), oracle.tnf_row(seq, 4))
+        assert np.array_equal(abd[i].cpu().numpy(), oracle.abd_row(seq, k, lenient, window, vsize))
+    # default: the strict table
+    t2 = kmer.KmerTable.with_slots(k, DEV, log2_slots, log2_bucket).count(s, rows=plan)
+    assert all(np.array_equal(x, y) for x, y in zip(t2.items(), strict.items()))
