@@ -1,0 +1,85 @@
+"""Process-level helpers behind the reference's ``utils`` names (src/utils.py): the sampler that draws row indices with
+numpy's global generator (utils.py:9-21), checkpoint-on-improvement early stopping (utils.py:24-50), the external-tool
+runner (utils.py:67-79) and the seeding + logging set-up (utils.py:82-103).  ``pangaea_amd.utils`` re-exports them under
+the reference's module name."""
+from __future__ import annotations
+
+import contextlib
+import logging
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+from torch.utils.data.sampler import WeightedRandomSampler
+
+
+class CustomWeightedRandomSampler(WeightedRandomSampler):
+    """``np.random.choice`` over the row weights -- with or without replacement -- from numpy's global generator,
+    which ``init_all`` seeds; the draw is therefore the reference's draw for the same seed."""
+
+    def __iter__(self):
+        w = self.weights.numpy()
+        picks = np.random.choice(len(w), size=self.num_samples, p=w / w.sum(), replace=self.replacement)
+        return iter(picks.tolist())
+
+
+class EarlyStopping:
+    """Call with (validation loss, model) after every validation pass.  A loss at least ``delta`` below the best one seen
+    saves the model's ``state_dict`` to ``path`` and resets the patience; ``patience`` passes in a row without such an
+    improvement set ``early_stop``.  ``best_score`` (= minus the best loss), ``counter`` and ``val_loss_min`` (the loss of
+    the last checkpoint) are kept as attributes because callers of the reference's class read them."""
+
+    def __init__(self, patience: int = 7, delta: float = 0, path: str = "checkpoint.pt"):
+        self.patience, self.delta, self.path = patience, delta, path
+        self.best_score = None
+        self.val_loss_min = float("inf")
+        self.counter = 0
+        self.early_stop = False
+
+    def _improved(self, val_loss) -> bool:
+        return self.best_score is None or -val_loss >= self.best_score + self.delta
+
+    def __call__(self, val_loss, model) -> None:
+        if self._improved(val_loss):
+            self.best_score, self.counter = -val_loss, 0
+            self.save_checkpoint(val_loss, model)
+        else:
+            self.counter += 1
+            self.early_stop = self.early_stop or self.counter >= self.patience
+
+    def save_checkpoint(self, val_loss, model) -> None:
+        torch.save(model.state_dict(), self.path)
+        self.val_loss_min = val_loss
+
+
+def run_cmd(command, log_file=None) -> None:
+    """run an external tool with its stdout swallowed and its stderr appended to ``log_file`` (or dropped); a non-zero exit
+    status ends the whole program with status 1, as the reference's pipeline expects of a failed step"""
+    line = " ".join(map(str, command))
+    logging.info("running: %s", line)
+    with contextlib.ExitStack() as stack:
+        err = stack.enter_context(open(log_file, "a")) if log_file else subprocess.DEVNULL
+        done = subprocess.run(command, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=err, text=True)
+    if done.returncode != 0:
+        logging.error("failed with status %d: %s", done.returncode, line)
+        sys.exit(1)
+    logging.info("finished: %s", line)
+
+
+def init_all(seed, threads, logfile, level, outdir) -> None:
+    """seed numpy and torch (the samplers and the network initialisation take their randomness from there), bound torch's
+    host threads, create the output directory and send log records of ``level`` and above to ``outdir/logfile`` and stderr"""
+    for seeder in (np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all):
+        seeder(seed)
+    torch.set_num_threads(threads)
+    os.makedirs(outdir, exist_ok=True)
+    log = logging.getLogger()
+    log.setLevel(level)
+    layout = logging.Formatter("%(asctime)s (%(levelname)s): %(message)s", "%Y-%m-%d %H:%M:%S")
+    for sink in (logging.FileHandler(os.path.join(outdir, logfile)), logging.StreamHandler()):
+        sink.setLevel(level)
+        sink.setFormatter(layout)
+        log.addHandler(sink)
+    log.info("pangaea (MI355X feature path) starting, output in %s", outdir)
