@@ -112,8 +112,45 @@ def cpu_baseline(stream, cfg, n_sample: int, state: dict) -> dict:
             "sample": f"first {n} pairs of the workload as FASTQ; seconds: " + ", ".join(f"{k} {v:.2f}" for k, v in counted.items())}
 
 
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N rank processes of this same command (one per GPU, RCCL
+    rendezvous on 127.0.0.1) and wait for them.  The parent never touches the GPU (nothing here initialises HIP), so
+    the children are ordinary fresh processes; rank 0's JSON line passes through on stdout."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for o in pending:               # one rank failed: the others would wait in a collective for ever
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.rehearse_dist <= 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -26,31 +26,10 @@
 //   shuffle   (pg_abundance_from_records) the partition records carry their row id; every bucket's slice is loaded into
 //             LDS, each record's count becomes a (row, bin) word, the words are scattered back by row group (two passes)
 //             and histogrammed in LDS.  Again only streams.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "pangaea_feat.h"
-#include "pg_internal.h"
+#include "pg_device.hpp"
 
 namespace {
-
-constexpr int BLOCK = 256;
-constexpr int WAVES = BLOCK / 64;
-constexpr int BIG_BLOCK = 1024;           // one workgroup per CU kernels (LDS-resident tables / histograms)
-constexpr uint32_t HASH_CBITS = PG_HASH_COUNT_BITS;
-constexpr uint64_t HASH_CMASK = (1ull << HASH_CBITS) - 1;
-constexpr uint32_t HASH_SAT = PG_HASH_COUNT_SAT;
-constexpr uint32_t MAX_PROBE = 1u << 14;
-
 enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2, TK_WIDE = 3 };
-
-__device__ __forceinline__ uint64_t mix64(uint64_t x)
-{
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
-    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
-    x ^= x >> 33;
-    return x;
-}
 
 // Packed hash tables (k <= 21) do not store the canonical code but key42(code): a BIJECTION of the 42-bit codes onto
 // themselves with the avalanche of a hash (two xorshift-multiply rounds modulo 2^42; every step is invertible, the
@@ -85,17 +64,6 @@ struct HashView {
     __device__ __forceinline__ uint32_t limit() const { return log2_bucket < 14 ? (1u << log2_bucket) : MAX_PROBE; }
 };
 
-// bit p of the result is set iff bits p-k+1..p of m are all set (1 <= k <= 32): which positions of the
-// 64-character window [previous word | this word] end a run of >= k valid characters.
-__device__ __forceinline__ uint64_t runs_of(uint64_t m, int k)
-{
-    uint64_t r = m;
-    int len = 1;
-    while (2 * len <= k) { r &= r << len; len *= 2; }
-    if (len < k) r &= r << (k - len);
-    return r;
-}
-
 template <typename KT> __device__ __forceinline__ KT low_mask(int k)
 {
     return (2 * k >= (int)(8 * sizeof(KT))) ? (KT)~(KT)0 : (KT)(((KT)1 << (2 * k)) - 1);
@@ -122,22 +90,6 @@ template <typename KT> struct Roller {
         return f < rc ? f : rc;
     }
 };
-
-// word w of the stream, the word before it, and the mask of its positions that end a valid k-mer
-struct Word {
-    uint64_t cw, pw;
-    uint32_t ok;
-};
-__device__ __forceinline__ Word load_word(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, int64_t w, int k)
-{
-    Word x;
-    x.cw = codes[w];
-    const uint32_t vw = valid[w];
-    x.pw = w > 0 ? codes[w - 1] : 0;
-    const uint32_t pv = w > 0 ? valid[w - 1] : 0;
-    x.ok = (uint32_t)(runs_of(((uint64_t)vw << 32) | pv, k) >> 32);
-    return x;
-}
 
 // -------------------------------------------------------------------------------- table access
 
@@ -402,50 +354,6 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_hist_kernel(const uint64_t *
     __syncthreads();
     for (int i = threadIdx.x; i < n_bins; i += BIG_BLOCK)
         if (lds[i]) atomicAdd(&hist[bin_base + i], (unsigned long long)lds[i]);
-}
-
-// per-digit exclusive scan of table[d][0..n) in place, plus base[d << base_shift]; totals[d] (may be NULL) = row sum.
-// One workgroup per digit.
-__global__ __launch_bounds__(BIG_BLOCK) void digit_scan_kernel(unsigned long long *__restrict__ table, int64_t n,
-                                                               const unsigned long long *__restrict__ base, int base_shift,
-                                                               unsigned long long *__restrict__ totals)
-{
-    __shared__ unsigned long long part[BIG_BLOCK];
-    unsigned long long *row = table + (int64_t)blockIdx.x * n;
-    const int64_t per = (n + BIG_BLOCK - 1) / BIG_BLOCK;
-    const int64_t a = threadIdx.x * per, b = a + per < n ? a + per : n;
-    unsigned long long s = 0;
-    for (int64_t i = a; i < b; ++i) s += row[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < BIG_BLOCK; ++i) { unsigned long long v = part[i]; part[i] = run; run += v; }
-        if (totals) totals[blockIdx.x] = run;
-    }
-    __syncthreads();
-    unsigned long long run = part[threadIdx.x] + base[(int64_t)blockIdx.x << base_shift];
-    for (int64_t i = a; i < b; ++i) { const unsigned long long v = row[i]; row[i] = run; run += v; }
-}
-
-// exclusive prefix sum of hist[n] -> off[n+1] (one workgroup)
-__global__ __launch_bounds__(BIG_BLOCK) void scan_kernel(const unsigned long long *__restrict__ hist, int64_t n, unsigned long long *__restrict__ off)
-{
-    __shared__ unsigned long long part[BIG_BLOCK];
-    const int64_t per = (n + BIG_BLOCK - 1) / BIG_BLOCK;
-    const int64_t a = threadIdx.x * per, b = a + per < n ? a + per : n;
-    unsigned long long s = 0;
-    for (int64_t i = a; i < b; ++i) s += hist[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < BIG_BLOCK; ++i) { unsigned long long v = part[i]; part[i] = run; run += v; }
-        off[n] = run;
-    }
-    __syncthreads();
-    unsigned long long run = part[threadIdx.x];
-    for (int64_t i = a; i < b; ++i) { off[i] = run; run += hist[i]; }
 }
 
 // LDS bookkeeping shared by the scatter passes (<= 2^FAN_BITS digits)
@@ -1719,23 +1627,6 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
 }
 
 // -------------------------------------------------------------------------------- launch helpers
-
-int check_launch(const char *what)
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return pg_fail(PG_EHIP, "%s: %s", what, hipGetErrorString(e));
-    return PG_OK;
-}
-
-int grid_for(int64_t items, int block = BLOCK)
-{
-    int64_t blocks = (items + block - 1) / block;
-    const int64_t cap = 256 * 16;     // 256 CUs x 16 resident workgroups' worth, grid-stride beyond
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return (int)blocks;
-}
-
 int check_table(const pg_table *t)
 {
     if (!t || !t->data) return pg_fail(PG_EINVAL, "table descriptor is null");
@@ -1763,14 +1654,6 @@ HashView view_of(const pg_table *t)
     v.log2_slots = t->log2_slots;
     v.log2_bucket = t->log2_bucket_slots ? t->log2_bucket_slots : t->log2_slots;
     return v;
-}
-
-int raise_lds_limit(const void *kernel, size_t bytes, const char *who)
-{
-    if (bytes <= 64 * 1024) return PG_OK;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
-        return pg_fail(PG_EHIP, "%s: cannot raise the dynamic LDS limit", who);
-    return PG_OK;
 }
 
 // workspace carving of the bucketed counter
