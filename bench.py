@@ -55,6 +55,8 @@ def parse_args():
                     help="one GPU: run the N-rank code path (deferred count, exchange over a one-rank RCCL group, table sized for N shards) -- not a result")
     ap.add_argument("--load", type=float, default=0.6, help="highest load of the hash table (its size is the next power of two)")
     ap.add_argument("--no-fuse", action="store_true", help="N = 1: separate count and lookup kernels (as N > 1 must run them)")
+    ap.add_argument("--no-mini", action="store_true", help="N = 1: the key-partitioned pipeline (8-byte record per k-mer occurrence) instead of super-k-mers")
+    ap.add_argument("--plan-in-step", action="store_true", help="super-k-mer pipeline: recompute the partition plan inside every step")
     ap.add_argument("--no-defer", action="store_true", help="N > 1: write every rank's own table and compact it (instead of the deferred count)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     return ap.parse_args()
@@ -199,7 +201,11 @@ def main():
                                device=dev, chunk_pairs=1 << 17, with_names=False)
         regs = torch.maximum(regs, kmer.distinct_sketch(other, K_ABD).to(regs.device))
         del other
-    table = kmer.KmerTable.alloc(K_ABD, dev, "hash", distinct_hint=max(1 << 14, int(1.05 * kmer.sketch_estimate(regs))), load=args.load)
+    hint = max(1 << 14, int(1.05 * kmer.sketch_estimate(regs)))
+    fused = not multi and not args.no_fuse
+    import math
+    mini = fused and not args.no_mini and kmer.KmerTable.mini_applies(K_ABD, max(10, math.ceil(math.log2(max(1024, int(hint / args.load))))))
+    table = kmer.KmerTable.alloc(K_ABD, dev, "mini" if mini else "hash", distinct_hint=hint, load=args.load)
     # N > 1: a rank's own keys are 2^g times sparser than the union and are counted in deferred form (entries + fills for
     # the exchange; the rank's own sparse table is never written)
     defer = pdist.deferred_group_for(table, int(1.1 * local_distinct)) if multi and not args.no_defer else None
@@ -210,7 +216,6 @@ def main():
     vae.network.eval()
     names = np.array(rows.names, dtype=object)
 
-    fused = not multi and not args.no_fuse
     k2 = "kmer_count+lookup" if fused else "kmer_count"
     alg = ALG_BYTES_FUSED if fused else ALG_BYTES
     ev = {k: [] for k in ((k2, "exchange", "features") if multi else (k2, "features"))}
@@ -219,6 +224,8 @@ def main():
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         table.reset()                   # bucketed tables are overwritten slice by slice: no 4 GB clear
+        if mini and args.plan_in_step:
+            table._mini_plan = None
 
         # one GPU: the lookup pass of the abundance rows rides inside the counting kernel (same table, same matrices)
         table.count(stream, check=False, rows=plan, deferred_group=defer if defer is not None and table.can_defer(stream.n_words) else None,
@@ -294,6 +301,11 @@ def main():
                                                                                     if world >= 4 else "range-wise table all-gather (6-byte entries) overlapped with LDS rebuilds")
                                        + f" ({args.backend})" if world > 1
                                        else f"REHEARSAL of the {args.rehearse_dist}-rank path on one GPU (one-rank RCCL group)" if multi else "single GPU"),
+                       "pipeline": ("super-k-mers by minimizer bucket (12-byte records, LDS counting + lookups per bucket)" if mini
+                                    else "k-mer occurrences by key (8-byte records, LDS counting" + (" + lookups" if fused else "") + " per bucket)"),
+                       "partition_plan": (("recomputed in every step" if args.plan_in_step else
+                                           "computed once with the table sizing, outside the step (it depends on the reads, the rows and the geometry only)")
+                                          if mini else "bucket histogram inside the step"),
                        "input": "packed reads resident in HBM", "table_load": table_load,
                        "table_buckets": table.n_buckets, "bucket_slots": 1 << table.log2_bucket if table.log2_bucket else None},
             "kernel_ms": kern_ms,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2   /* 2: packed hash slots are keyed by pg_key42(code); exchange and sharded-ingest entry points */
+#define PG_ABI_VERSION 3   /* 3: PG_TABLE_MINI and the super-k-mer entry points; 2: packed hash slots keyed by pg_key42(code) */
 #define PG_CHARS_PER_WORD 32
 #define PG_WORD_ALIGN 256 /* stream arrays are padded to a multiple of this many words */
 
@@ -142,7 +142,18 @@ int pg_tnf_colmap(int k, uint16_t *colmap /* [4^k] host */, uint32_t *col_code /
  * Tables must be zero-filled by the caller before the first count; counting accumulates, so a stream
  * may be counted in pieces (and tables of several GPUs can be summed).
  * ---------------------------------------------------------------------------------------------- */
-enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3 };
+enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3, PG_TABLE_MINI = 4 };
+/*   PG_TABLE_MINI   PG_MINI_MIN_K <= k <= 21: uint64_t slots[2^log2_slots], slot = (canonical code << 22) | count, in
+ *                   buckets of 2^log2_bucket_slots slots (<= PG_BUCKET_MAX_LOG2_SLOTS, at most 2^15 buckets); a k-mer's
+ *                   bucket is a hash of its MINIMIZER (the smallest hashed canonical 13-mer inside it), its home slot
+ *                   inside the bucket a hash of its code; linear probing wraps inside the bucket.  Consecutive k-mers
+ *                   of a read share their minimizer, so the partition passes move super-k-mers (12 bytes for a run of
+ *                   k-mers) instead of 8 bytes per occurrence: built by pg_mini_plan + pg_mini_count, read by
+ *                   pg_features (lookups) and pg_kmer_merge (entries of a dump). */
+#define PG_MINI_M 13
+#define PG_MINI_MIN_K 16
+#define PG_MINI_MAX_LOG2_BUCKETS 15
+#define PG_MINI_MAX_ROWS ((1 << 21) - 2)
 #define PG_DENSE_MAX_K 16
 #define PG_HASH_MAX_K 21
 #define PG_WIDE_MAX_K 31
@@ -156,7 +167,7 @@ enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3 };
 #define PG_BUCKET_MAX_LOG2_BUCKETS 17  /* two scatter passes of <= 9 bits; the histogram takes 2^15 bins per launch */
 
 typedef struct {
-    int32_t kind;       /* PG_TABLE_DENSE or PG_TABLE_HASH */
+    int32_t kind;       /* PG_TABLE_DENSE, _HASH, _WIDE or _MINI */
     int32_t k;
     int32_t log2_slots;        /* hash only */
     int32_t log2_bucket_slots; /* hash only; 0 = unbucketed */
@@ -302,6 +313,34 @@ int pg_abundance_from_records(const pg_table *t, const pg_rows *rows, int window
 int pg_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
                               const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
                               void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * The super-k-mer form of the table build + abundance lookups (one GPU, PG_TABLE_MINI; same results as
+ * pg_kmer_count_bucketed_emit + pg_abundance_from_emitted, i.e. jellyfish count -C (feature.py:94) and
+ * count_kmer.cpp:55-108).
+ *   pg_mini_plan   one pass over the word range: how many super-k-mer records every CHUNK of the stream sends to each
+ *                  first-pass region and how many records every bucket receives -> exact write offsets for both scatter
+ *                  passes (no global cursor atomics in the first one).  Depends on the stream, `rows` and the table
+ *                  geometry only: a caller that counts the same range again (another pass, a benchmark step) keeps the
+ *                  plan.  Leaves the number of records in the first 8 bytes of `plan_ws` (device).
+ *   pg_mini_count  stream -> records by region -> records by bucket -> every bucket counted inside LDS by one
+ *                  workgroup (slots of a FRESH table are overwritten, no clearing) and, when window > 0, looked up again
+ *                  while its counts are still in LDS: the (row, bin) words of count_kmer.cpp:86-96 are left in
+ *                  `shuffle_ws` for pg_mini_abundance_from_emitted.  `rows` may be NULL and window = vsize = 0 (table only).
+ * plan_ws: pg_mini_plan_bytes; rec_ws: pg_mini_records_bytes(n_records) (two buffers of 12 B per record);
+ * shuffle_ws: pg_mini_shuffle_bytes.  All 256-byte aligned device memory.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t pg_mini_plan_bytes(int64_t n_words, const pg_table *t);
+int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                 const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *stream);
+int64_t pg_mini_records_bytes(int64_t n_records);
+int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize);
+int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                  const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                  int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream);
+int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int vsize, int32_t *abd_out,
+                                   const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
+                                   void *shuffle_ws, int64_t shuffle_ws_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Cache files.  Rows as the reference binaries print them: "<name>,v1,...,vD\n", numbers through

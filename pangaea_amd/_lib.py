@@ -15,14 +15,15 @@ _LIB = None
 
 PG_OK = 0
 PG_ETABLEFULL = -6
-TABLE_DENSE, TABLE_HASH, TABLE_WIDE = 1, 2, 3
+TABLE_DENSE, TABLE_HASH, TABLE_WIDE, TABLE_MINI = 1, 2, 3, 4
 DENSE_MAX_K, HASH_MAX_K, WIDE_MAX_K = 16, 21, 31
 HASH_COUNT_BITS = 22
 HASH_COUNT_SAT = 1 << 21
 TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
-ABI_VERSION = 2
+ABI_VERSION = 3
+MINI_MIN_K, MINI_MAX_LOG2_BUCKETS, MINI_MAX_ROWS = 16, 15, (1 << 21) - 2
 SHUFFLE_MAX_VSIZE = 512
 DEFERRED_MAX_GROUP_LOG2 = 3
 KEY42_M1 = 0x3d7ed558ccd          # pg_key42 (include/pangaea_feat.h)
@@ -111,6 +112,12 @@ def load() -> C.CDLL:
         "pg_table_compact_planes_range": (i32, [tp, i64, i64, vp, vp, vp, vp, vp, i64, vp, vp]),
         "pg_table_compact": (i32, [tp, vp, vp, vp]),
         "pg_kmer_merge_wide": (i32, [vp, vp, i64, tp, vp, vp]),
+        "pg_mini_plan_bytes": (i64, [i64, tp]),
+        "pg_mini_plan": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, vp]),
+        "pg_mini_records_bytes": (i64, [i64]),
+        "pg_mini_shuffle_bytes": (i64, [i64, i64, i32]),
+        "pg_mini_count": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, vp, i64, i32, i32, vp, i64, vp, vp]),
+        "pg_mini_abundance_from_emitted": (i32, [tp, rp, i32, vp, vp, i64, i64, vp, i64, vp]),
         "pg_features": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp, vp, tp, i32, i32, vp, vp]),
         "pg_write_csv_gz": (i32, [cp, cp, vp, i64, i64]),
         "pg_extract_reads": (i32, [cp, cp, cp, cp, C.POINTER(i64)]),
@@ -131,6 +138,7 @@ EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fast
            "pg_pack_ascii", "pg_pack_ascii_lower", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_distinct_sketch", "pg_kmer_count_workspace_bytes",
            "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed", "pg_kmer_rebuild_bucketed", "pg_kmer_rebuild_bucketed_range", "pg_table_bucket_fill", "pg_kmer_count_deferred", "pg_deferred_gather", "pg_deferred_gather_planes", "pg_kmer_rebuild_planes_range", "pg_table_bucket_fill_range", "pg_table_compact_planes_range", "pg_table_compact", "pg_kmer_merge_wide", "pg_abundance_workspace_bytes",
            "pg_abundance_from_records", "pg_abundance_from_emitted", "pg_kmer_count_bucketed_emit",
+           "pg_mini_plan_bytes", "pg_mini_plan", "pg_mini_records_bytes", "pg_mini_shuffle_bytes", "pg_mini_count", "pg_mini_abundance_from_emitted",
            "pg_features", "pg_write_csv_gz", "pg_extract_reads"]
 
 

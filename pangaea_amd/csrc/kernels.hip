@@ -29,7 +29,7 @@
 #include "pg_device.hpp"
 
 namespace {
-enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2, TK_WIDE = 3 };
+enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2, TK_WIDE = 3, TK_MINI = 4 };
 
 // Packed hash tables (k <= 21) do not store the canonical code but key42(code): a BIJECTION of the 42-bit codes onto
 // themselves with the avalanche of a hash (two xorshift-multiply rounds modulo 2^42; every step is invertible, the
@@ -56,6 +56,12 @@ struct HashView {
     int log2_bucket;
     __device__ __forceinline__ uint64_t home_wide(uint64_t code) const { return mix64(code) >> (64 - log2_slots); }
     __device__ __forceinline__ uint64_t home_key(uint64_t key) const { return key >> (KEY_BITS - log2_slots); }
+    // PG_TABLE_MINI: bucket from the k-mer's minimizer, slot inside the bucket from a hash of the code (the slots hold codes)
+    __device__ __forceinline__ uint64_t home_mini(uint64_t code, int k) const
+    {
+        const uint32_t b = mini_bucket(mini_minimizer_of(code, k), log2_slots - log2_bucket);
+        return ((uint64_t)b << log2_bucket) | (mini_slot_hash(code) & ((1u << log2_bucket) - 1u));
+    }
     __device__ __forceinline__ uint64_t next(uint64_t s) const
     {
         const uint64_t bm = (1ull << log2_bucket) - 1;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(BLOCK) void kmer_count_kernel(const uint64_t *__res
 }
 
 // merge (key,count) pairs of another table (slot format); counts saturate at SAT exactly (CAS loop; not a hot path)
-__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, HashView t, uint32_t *status)
+__global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__restrict__ pairs, int64_t n, HashView t, uint32_t *status, int mini_k)
 {
     const uint32_t limit = t.limit();
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) void kmer_merge_kernel(const uint64_t *__res
         const uint64_t code = p >> HASH_CBITS;
         uint32_t add = (uint32_t)(p & HASH_CMASK);
         if (add > HASH_SAT) add = HASH_SAT;
-        uint64_t s = t.home_key(code);
+        uint64_t s = mini_k ? t.home_mini(code, mini_k) : t.home_key(code);
         bool done = false;
         for (uint32_t tries = 0; tries < limit && !done; ++tries) {
             uint64_t cur = __hip_atomic_load(&t.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1575,8 +1581,8 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                         if (TK == TK_DENSE) {
                             cur[u] = dense[(uint32_t)canon[u]];
                         } else {
-                            key8[u] = TK == TK_WIDE ? (uint64_t)canon[u] : key42((uint64_t)canon[u]);
-                            hh[u] = TK == TK_WIDE ? t.home_wide(key8[u]) : t.home_key(key8[u]);
+                            key8[u] = TK == TK_HASH ? key42((uint64_t)canon[u]) : (uint64_t)canon[u];
+                            hh[u] = TK == TK_WIDE ? t.home_wide(key8[u]) : TK == TK_MINI ? t.home_mini(key8[u], k) : t.home_key(key8[u]);
                             // each table line is used once per launch: keep it out of the way of the stream (measured -2 %)
                             cur[u] = __builtin_nontemporal_load(&t.slots[hh[u]]);
                         }
@@ -1637,6 +1643,11 @@ int check_table(const pg_table *t)
         if (t->log2_slots < 10 || t->log2_slots > 40) return pg_fail(PG_EINVAL, "log2_slots %d out of range [10,40]", t->log2_slots);
         if (t->log2_bucket_slots != 0 && (t->log2_bucket_slots < 4 || t->log2_bucket_slots > t->log2_slots))
             return pg_fail(PG_EINVAL, "log2_bucket_slots %d out of range [4,%d]", t->log2_bucket_slots, t->log2_slots);
+    } else if (t->kind == PG_TABLE_MINI) {
+        if (t->k < PG_MINI_MIN_K || t->k > PG_HASH_MAX_K) return pg_fail(PG_EINVAL, "mini table needs %d <= k <= %d (got %d)", PG_MINI_MIN_K, PG_HASH_MAX_K, t->k);
+        if (t->log2_bucket_slots < 4 || t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS || t->log2_slots < t->log2_bucket_slots ||
+            t->log2_slots - t->log2_bucket_slots > PG_MINI_MAX_LOG2_BUCKETS)
+            return pg_fail(PG_EINVAL, "mini table geometry 2^%d slots in buckets of 2^%d", t->log2_slots, t->log2_bucket_slots);
     } else if (t->kind == PG_TABLE_WIDE) {
         if (t->k < 1 || t->k > PG_WIDE_MAX_K) return pg_fail(PG_EINVAL, "wide table needs 1 <= k <= %d (got %d)", PG_WIDE_MAX_K, t->k);
         if (t->log2_slots < 10 || t->log2_slots > 40) return pg_fail(PG_EINVAL, "log2_slots %d out of range [10,40]", t->log2_slots);
@@ -1758,6 +1769,7 @@ extern "C" int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_count: bad word range [%lld,%lld)", (long long)word_begin, (long long)word_end);
     int rc = check_table(t);
     if (rc) return rc;
+    if (t->kind == PG_TABLE_MINI) return pg_fail(PG_EINVAL, "pg_kmer_count: mini tables are built by pg_mini_plan + pg_mini_count");
     if (t->kind != PG_TABLE_DENSE && !status) return pg_fail(PG_EINVAL, "pg_kmer_count: hash tables need a status word");
     if (word_end == word_begin) return PG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -2016,10 +2028,12 @@ extern "C" int pg_kmer_merge(const uint64_t *pairs, int64_t n, const pg_table *t
 {
     int rc = check_table(t);
     if (rc) return rc;
-    if (t->kind != PG_TABLE_HASH) return pg_fail(PG_EINVAL, "pg_kmer_merge: hash tables only (dense tables are summed with an all-reduce)");
+    if (t->kind != PG_TABLE_HASH && t->kind != PG_TABLE_MINI)
+        return pg_fail(PG_EINVAL, "pg_kmer_merge: hash and mini tables only (dense tables are summed with an all-reduce)");
     if (n < 0 || (n > 0 && !pairs) || !status) return pg_fail(PG_EINVAL, "pg_kmer_merge: bad arguments");
     if (n == 0) return PG_OK;
-    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, view_of(t), status);
+    hipLaunchKernelGGL(kmer_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, pairs, n, view_of(t), status,
+                       t->kind == PG_TABLE_MINI ? t->k : 0);
     return check_launch("pg_kmer_merge");
 }
 
@@ -2156,6 +2170,33 @@ extern "C" int64_t pg_abundance_workspace_bytes(int64_t n_words_counted, int64_t
 static int abundance_impl(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
                           const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
                           void *workspace, int64_t workspace_bytes, void *stream, bool emitted);
+static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begin, int nb, const pg_rows *rows, int vsize,
+                        int32_t *abd_out, char *ws, hipStream_t s);
+
+// for the other translation units (pg_internal.h): where the lookup pass of another pipeline leaves its words, and the
+// row shuffle that finishes them
+int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out)
+{
+    ShufflePlan sp;
+    int rc = plan_shuffle(cap, n_rows, vsize, 0, &sp);
+    if (rc) return rc;
+    out->vbits = sp.vbits;
+    out->emit_off = sp.emit_off;
+    out->words_e_off = sp.words_e_off;
+    out->total = sp.total;
+    return PG_OK;
+}
+
+int pg_internal_shuffle_rows(const unsigned long long *in_begin, int nb, int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out,
+                             void *workspace, int64_t workspace_bytes, void *stream)
+{
+    ShufflePlan sp;
+    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp);
+    if (rc) return rc;
+    if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
+    if (rows->n_rows == 0) return PG_OK;
+    return shuffle_tail(sp, in_begin, nb, rows, vsize, abd_out, (char *)workspace, (hipStream_t)stream);
+}
 
 extern "C" int pg_abundance_from_records(const pg_table *t, const pg_rows *rows, int window, int vsize, int32_t *abd_out,
                                          const void *count_workspace, int64_t count_workspace_bytes, int64_t n_words_counted,
@@ -2200,28 +2241,14 @@ static int abundance_impl(const pg_table *t, const pg_rows *rows, int window, in
     const auto *recs = (const uint64_t *)(cws + p.final_off());
     char *ws = (char *)workspace;
     auto *emit_end = (unsigned long long *)(ws + sp.emit_off);
-    auto *caps = (unsigned long long *)(ws + sp.caps_off);
-    auto *goff = (unsigned long long *)(ws + sp.goff_off);
-    auto *gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
-    auto *gcur2 = (unsigned long long *)(ws + sp.gcur2_off);
     auto *words_e = (uint32_t *)(ws + sp.words_e_off);
-    auto *words_a = (uint32_t *)(ws + sp.words_a_off);
-    auto *words_b = (uint32_t *)(ws + sp.words_b_off);
     const int nb = 1 << p.bits;
     const size_t slice_lds = (size_t)8 << t->log2_bucket_slots;
-    const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
     if ((rc = raise_lds_limit((const void *)bucket_lookup_kernel, slice_lds, "pg_abundance_from_records"))) return rc;
-    if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
     // (emitted: the lookup pass already ran inside pg_kmer_count_bucketed_emit and left emit_end + the words behind)
-    if (hipMemsetAsync(ws + (emitted ? sp.caps_off : 0), 0, sp.dhist_off - (emitted ? sp.caps_off : 0), s) != hipSuccess)
+    if (!emitted && hipMemsetAsync(ws, 0, sp.caps_off, s) != hipSuccess)
         return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
-
-    // row-group capacities -> offsets of the group regions
-    hipLaunchKernelGGL(group_caps_kernel, dim3((unsigned)((sp.n_groups_padded + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_start, rows->row_end,
-                       rows->n_rows, sp.n_groups_padded, caps);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)caps, sp.n_groups_padded, goff);
     // S1: counts out of the LDS copies of the slices -> (row, bin) words, packed per bucket
-    const int gshift = sp.vbits + GROUP_ROWS_LOG2;
     if (emitted) {
     } else if (KEY_BITS - p.bits <= 31 && !getenv("PG_B64")) {
         if ((rc = raise_lds_limit((const void *)bucket_lookup32_kernel, slice_lds, "pg_abundance_from_records"))) return rc;
@@ -2230,6 +2257,32 @@ static int abundance_impl(const pg_table *t, const pg_rows *rows, int window, in
     } else
     hipLaunchKernelGGL(bucket_lookup_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, recs, off, view_of(t), (uint32_t)window, (uint32_t)vsize, sp.vbits,
                        words_e, emit_end);
+    return shuffle_tail(sp, off, nb, rows, vsize, abd_out, ws, s);
+}
+
+// S2 + S3: the (row, bin) words of every bucket b, words_e[in_begin[b] .. emit_end[b]), -> rows of the abundance matrix
+static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begin, int nb, const pg_rows *rows, int vsize,
+                        int32_t *abd_out, char *ws, hipStream_t s)
+{
+    int rc;
+    auto *emit_end = (unsigned long long *)(ws + sp.emit_off);
+    auto *caps = (unsigned long long *)(ws + sp.caps_off);
+    auto *goff = (unsigned long long *)(ws + sp.goff_off);
+    auto *gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
+    auto *gcur2 = (unsigned long long *)(ws + sp.gcur2_off);
+    auto *words_e = (uint32_t *)(ws + sp.words_e_off);
+    auto *words_a = (uint32_t *)(ws + sp.words_a_off);
+    auto *words_b = (uint32_t *)(ws + sp.words_b_off);
+    const unsigned long long *off = in_begin;
+    const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
+    if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
+    if (hipMemsetAsync(ws + sp.caps_off, 0, sp.dhist_off - sp.caps_off, s) != hipSuccess)
+        return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
+    // row-group capacities -> offsets of the group regions
+    hipLaunchKernelGGL(group_caps_kernel, dim3((unsigned)((sp.n_groups_padded + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_start, rows->row_end,
+                       rows->n_rows, sp.n_groups_padded, caps);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)caps, sp.n_groups_padded, goff);
+    const int gshift = sp.vbits + GROUP_ROWS_LOG2;
     // S2a: scatter the words by the first gb1 bits of their row group (destinations from global cursors, one add per digit
     // and tile)
     {
@@ -2287,10 +2340,10 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
         int rc = check_table(t);
         if (rc) return rc;
         if (window < 1 || vsize < 1 || vsize > 8192) return pg_fail(PG_EINVAL, "pg_features: window %d / vector size %d out of range", window, vsize);
-        if (t->kind == PG_TABLE_HASH && (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
+        if ((t->kind == PG_TABLE_HASH || t->kind == PG_TABLE_MINI) && (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
             return pg_fail(PG_EINVAL, "pg_features: window*vector_size %lld exceeds the exact range of the hash table (%u)",
                            (long long)window * vsize, PG_HASH_COUNT_SAT);
-        kind = t->kind == PG_TABLE_DENSE ? TK_DENSE : t->kind == PG_TABLE_WIDE ? TK_WIDE : TK_HASH;
+        kind = t->kind == PG_TABLE_DENSE ? TK_DENSE : t->kind == PG_TABLE_WIDE ? TK_WIDE : t->kind == PG_TABLE_MINI ? TK_MINI : TK_HASH;
         k = t->k;
         if (kind == TK_DENSE) dense = (const uint32_t *)t->data;
         else view = view_of(t);
@@ -2306,6 +2359,7 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
     if (kind == TK_NONE) PG_LAUNCH(uint32_t, TK_NONE);
     else if (kind == TK_DENSE) PG_LAUNCH(uint32_t, TK_DENSE);
     else if (kind == TK_WIDE) PG_LAUNCH(uint64_t, TK_WIDE);
+    else if (kind == TK_MINI) PG_LAUNCH(uint64_t, TK_MINI);
     else PG_LAUNCH(uint64_t, TK_HASH);
 #undef PG_LAUNCH
     return check_launch("pg_features");

@@ -1,0 +1,767 @@
+// mini.hip -- the super-k-mer form of K2 (global multiplicities) with K3's lookups inside, for PG_TABLE_MINI tables.
+//
+// Replaces (reference file:line, /root/reference/src): jellyfish count -C (feature.py:94) + the dump reload of
+// cpptools/count_kmer.cpp:139-170, and the per-occurrence table lookups of cpptools/count_kmer.cpp:86-96.
+//
+// Why: the key-partitioned pipeline of kernels.hip moves one 8-byte record per k-mer OCCURRENCE through two scatter
+// passes and two LDS-table passes (20.8 GB per trip at 10 M read pairs).  Here a k-mer's bucket is a hash of its MINIMIZER
+// (pg_device.hpp), consecutive k-mers of a read share it, and what travels is the SUPER-k-mer: one 12-byte record
+//     bases : uint64  the 32 characters ending at the record's last character, stream order (oldest in the low bits)
+//     meta  : uint32  row << 11 | (n - 1) << 7 | d2      row = index of the row the k-mers lie in (MINI_ROW_NONE: none),
+//                                                        n = k-mers in the record (they end at the last n characters),
+//                                                        d2 = the bucket's second-pass digit
+// for a run of n <= 16 k-mers (about 4.3 on 150 bp reads, k = 21), i.e. under 3 bytes per occurrence.  The bucket
+// workgroups re-derive the k-mers: forward codes are shifts of the character-reversed word, reverse-complement codes are
+// shifts of the complemented word -- one reversal per record, two shifts and a compare per k-mer.
+//
+// Launches of one count (10 M pairs: 94 M words, ~600 M records):
+//   mini_plan_kernel      (pg_mini_plan; depends on the stream, the rows and the geometry only) records per bucket and,
+//                         per 4096-word chunk, records per first-pass region  -> scans -> exact offsets
+//   mini_scatter_kernel   A1': one 512-thread workgroup per chunk, 512 words per round; a lane segments its word, ranks its
+//                         records with one LDS atomic each, the round is laid out region-sorted in LDS and copied out
+//   mini_scatter2_kernel  A2': every region -> its buckets (LDS multisplit, one global cursor add per digit and tile)
+//   mini_count_kernel     B' + S1': one workgroup per bucket, 8-byte LDS slots (canonical code << 22 | count); the packed
+//                         slice is written once; then the counts become bins in place and the records are read again
+//                         (L2 / MALL) and looked up: (row, bin) words for the row shuffle of kernels.hip
+#include "pg_device.hpp"
+
+namespace {
+
+constexpr int S1_BLOCK = 512;                          // threads of a first-pass workgroup (256 VGPRs per lane: no spills)
+constexpr int ROUND_WORDS = S1_BLOCK;                  // words per round of the first pass: one per lane
+constexpr int MINI_CHUNK_WORDS = 4096;                 // words per chunk (one workgroup of the first pass)
+constexpr int ROUNDS_PER_CHUNK = MINI_CHUNK_WORDS / ROUND_WORDS;
+constexpr int STAGE_CAP = 8 * S1_BLOCK;                // records of a (sub-)round staged in LDS: 8 positions x 512 lanes always fit
+constexpr int META_D2_BITS = 7, META_LEN_BITS = 4, META_ROW_SHIFT = META_D2_BITS + META_LEN_BITS;
+constexpr uint32_t MINI_ROW_NONE = (1u << (32 - META_ROW_SHIFT)) - 1u;
+constexpr int MINI_MAX_LEN = 1 << META_LEN_BITS;       // k-mers per record
+constexpr int MINI_BITS1 = 8;                          // first-pass digits (regions)
+static_assert(PG_MINI_MAX_ROWS == (int)MINI_ROW_NONE - 1, "row field of the record");
+static_assert(PG_MINI_MAX_LOG2_BUCKETS == MINI_BITS1 + META_D2_BITS, "bucket id = region digit + second-pass digit");
+
+struct MiniView {
+    uint64_t *slots;
+    int log2_slots, log2_bucket, k;
+    __device__ __forceinline__ int bits() const { return log2_slots - log2_bucket; }
+};
+
+// first row whose end lies beyond the first character of each round (rows sorted, disjoint)
+__global__ __launch_bounds__(BLOCK) void round_rows_kernel(const int64_t *__restrict__ row_end, int64_t n_rows, int64_t word_begin,
+                                                           int64_t n_rounds, int32_t *__restrict__ round_row)
+{
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_rounds) return;
+    const int64_t c0 = (word_begin + t * ROUND_WORDS) * 32;
+    int64_t lo = 0, hi = n_rows;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (row_end[mid] > c0) hi = mid; else lo = mid + 1;
+    }
+    round_row[t] = (int32_t)lo;
+}
+
+// ---- segmentation of ONE word into super-k-mer records.  A record is a maximal run of consecutive valid k-mers of the word
+// (records never cross words: the lane that owns the word sees the k - 1 characters before it, like every stream reader
+// here) that share their bucket and their row, capped at `cap` k-mers.  emit(e, n, bucket, row) is called once per record, e =
+// position of its last character in the word; e is a compile-time constant at every call site (the position loop is fully
+// unrolled), so callers may index register arrays with it.  The plan kernel and the scatter kernel both call this: they
+// see the same records by construction.
+struct RowBits {
+    // where the rows (sorted, disjoint character ranges) cut the lane's 32 characters: bit p of `starts` = a row starts at
+    // character p (p > 0), bit p of `ends` = character p is the first one behind a row; r0 = the row that holds character 0
+    // (inside0) or the next row to start.  No per-position loop is needed afterwards.
+    uint32_t starts, ends, r0;
+    bool inside0;
+    __device__ __forceinline__ void init(const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows, int64_t first, int64_t pos0)
+    {
+        starts = ends = 0; r0 = 0; inside0 = false;
+        if (!row_start) return;
+        int64_t r = first;
+        while (r < n_rows && row_end[r] <= pos0) ++r;           // first row that ends behind character 0
+        r0 = (uint32_t)r;
+        inside0 = r < n_rows && row_start[r] <= pos0;
+        for (; r < n_rows; ++r) {
+            const int64_t a = row_start[r] - pos0, b = row_end[r] - pos0;
+            if (a >= 32) break;
+            if (a > 0) starts |= 1u << a;
+            if (b < 32) ends |= 1u << b;
+        }
+    }
+    __device__ __forceinline__ uint32_t cuts() const { return starts | ends; }
+    // row of character p, MINI_ROW_NONE outside every row
+    __device__ __forceinline__ uint32_t at(int p) const
+    {
+        const uint32_t upto = p == 31 ? 0xffffffffu : (2u << p) - 1u;
+        const int s = __popc(starts & upto), e = __popc(ends & upto);
+        const int inside = (inside0 ? 1 : 0) + s - e;
+        return inside > 0 ? r0 + (uint32_t)s - (inside0 ? 0u : 1u) : MINI_ROW_NONE;
+    }
+};
+
+// emit(e, n, bucket): one record of n k-mers ending at characters e - n + 1 .. e of the word.  `cuts`: positions where the row
+// changes; ok_row: k-mer ends that count for rows (a record never mixes the two kinds)
+template <int W, class Emit>
+__device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_t ok_row, uint32_t cuts, int k, int bits, int cap, Emit &&emit)
+{
+    uint32_t fwm = 0, rcm = 0;
+    uint32_t win[W];                                            // win[0] = newest hashed canonical M-mer
+#pragma unroll
+    for (int i = 0; i < W; ++i) win[i] = 0xffffffffu;
+    // pre-roll the k - 1 characters before the word; the M-mers that end at the last W - 1 of them are complete
+    for (int c = 33 - k; c < 32; ++c) {
+        const uint32_t ch = (uint32_t)(x.pw >> (2 * c)) & 3u;
+        fwm = ((fwm << 2) | ch) & MINI_MMASK;
+        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
+#pragma unroll
+        for (int i = W - 1; i > 0; --i) win[i] = win[i - 1];
+        win[0] = mhash(fwm < rcm ? fwm : rcm);
+    }
+    // a k-mer may continue the open record if it is valid, of the same kind (row-counting or not) as its predecessor and
+    // no row boundary lies at its last character
+    const uint32_t same = ok & (ok << 1) & ~(ok_row ^ (ok_row << 1)) & ~cuts;
+    int n = 0;                                                  // k-mers of the open record (bucket cur_b)
+    uint32_t cur_b = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const uint32_t ch = (uint32_t)(x.cw >> (2 * p)) & 3u;
+        fwm = ((fwm << 2) | ch) & MINI_MMASK;
+        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
+#pragma unroll
+        for (int i = W - 1; i > 0; --i) win[i] = win[i - 1];
+        win[0] = mhash(fwm < rcm ? fwm : rcm);
+        uint32_t mv = win[0];
+#pragma unroll
+        for (int i = 1; i < W; ++i) mv = win[i] < mv ? win[i] : mv;
+        const uint32_t b = mini_bucket(mv, bits);
+        const bool v = (ok >> p) & 1u;
+        // the open record ends at p - 1 unless this k-mer continues it (a record cannot end before the word starts)
+        const bool cont = ((same >> p) & 1u) && n > 0 && b == cur_b && n < cap;
+        if (p > 0 && n > 0 && !cont) emit(p > 0 ? p - 1 : 0, n, cur_b);
+        n = cont ? n + 1 : (v ? 1 : 0);
+        cur_b = b;
+    }
+    if (n > 0) emit(31, n, cur_b);
+}
+
+// what a lane needs to segment word w: the word, its valid k-mer ends under the counting rule and under the rows' strict rule
+struct LaneWord {
+    Word x;
+    uint32_t ok, ok_row;
+};
+__device__ __forceinline__ LaneWord load_lane_word(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                   const uint32_t *__restrict__ strict, int64_t w, int k)
+{
+    LaneWord lw;
+    lw.x = load_word(codes, valid, w, k);
+    lw.ok = lw.x.ok;
+    lw.ok_row = lw.ok;
+    if (strict && lw.ok) {
+        const uint32_t sv = strict[w], sp = w > 0 ? strict[w - 1] : 0u;
+        lw.ok_row &= (uint32_t)(runs_of(((uint64_t)sv << 32) | sp, k) >> 32);
+    }
+    return lw;
+}
+
+// ---- plan: records per bucket (hist) and, per chunk, records per first-pass region (chunk_hist[d * n_chunks + slot(chunk)])
+template <int W>
+__global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                              int64_t word_begin, int64_t word_end, int k, int bits, int bits2,
+                                                              const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
+                                                              const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
+                                                              unsigned long long *__restrict__ hist, unsigned long long *__restrict__ chunk_hist,
+                                                              int64_t n_chunks, int64_t chunk_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int nb = 1 << bits;
+    uint32_t *coarse = lds + nb;                                    // [256]
+    for (int i = threadIdx.x; i < nb; i += BIG_BLOCK) lds[i] = 0;
+    const int cap = 33 - k < MINI_MAX_LEN ? 33 - k : MINI_MAX_LEN;
+    const int n_dig = 1 << (bits - bits2);
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        if (threadIdx.x < 256) coarse[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < MINI_CHUNK_WORDS; i += BIG_BLOCK) {
+            const int64_t wi = chunk * MINI_CHUNK_WORDS + i;        // word index inside the range
+            const int64_t w = word_begin + wi;
+            if (w >= word_end) continue;
+            const LaneWord lw = load_lane_word(codes, valid, strict, w, k);
+            if (lw.ok == 0) continue;
+            RowBits rb;
+            rb.init(row_start, row_end, n_rows, row_start ? round_row[wi / ROUND_WORDS] : 0, w << 5);
+            mini_segment<W>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, bits, cap, [&](int, int, uint32_t b) {
+                atomicAdd(&lds[b], 1u);
+                atomicAdd(&coarse[b >> bits2], 1u);
+            });
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < n_dig)
+            chunk_hist[(int64_t)threadIdx.x * n_chunks + (int64_t)(((__int128)chunk * chunk_stride) % n_chunks)] = coarse[threadIdx.x];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < nb; i += BIG_BLOCK)
+        if (lds[i]) atomicAdd(&hist[i], (unsigned long long)lds[i]);
+}
+
+// total records = off[nb] -> header[0]
+__global__ void mini_total_kernel(const unsigned long long *__restrict__ off, int nb, unsigned long long *__restrict__ header)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) header[0] = off[nb];
+}
+
+// exclusive scan of cnt[0..N) -> start[0..N] by the first N / 64 wavefronts (N = 128 or 256); every lane of the workgroup calls
+template <int N>
+__device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start, uint32_t *wave_tot)
+{
+    uint32_t v = 0, incl = 0;
+    if (threadIdx.x < N) {
+        v = cnt[threadIdx.x];
+        incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        uint32_t before = 0;
+        for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += wave_tot[wv];
+        start[threadIdx.x] = before + incl - v;
+        if (threadIdx.x == N - 1) start[N] = before + incl;
+    }
+    __syncthreads();
+}
+
+// ---- A1': stream -> regions
+struct Scatter1Lds {
+    uint64_t bases[STAGE_CAP];
+    uint32_t meta[STAGE_CAP];
+    uint8_t dig[STAGE_CAP];
+    uint32_t cnt[256];
+    uint32_t start[257];
+    unsigned long long gbase[256];
+    unsigned long long cur[256];                                    // running write offsets of this chunk, per region
+    uint32_t wave_tot[4];
+};
+
+template <int W>
+__global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                                 int64_t word_begin, int64_t word_end, int k, int bits, int bits2,
+                                                                 const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
+                                                                 const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
+                                                                 uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
+                                                                 const unsigned long long *__restrict__ chunk_off, int64_t n_chunks, int64_t chunk_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Scatter1Lds &L = *reinterpret_cast<Scatter1Lds *>(lds_raw);
+    const int n_dig = 1 << (bits - bits2);
+    const uint32_t d2mask = (1u << bits2) - 1u;
+    const int cap = 33 - k < MINI_MAX_LEN ? 33 - k : MINI_MAX_LEN;
+    const int64_t chunk = blockIdx.x;
+    const int64_t slot = (int64_t)(((__int128)chunk * chunk_stride) % n_chunks);
+    if (threadIdx.x < 256) L.cur[threadIdx.x] = (int)threadIdx.x < n_dig ? chunk_off[(int64_t)threadIdx.x * n_chunks + slot] : 0ull;
+    for (int rd = 0; rd < ROUNDS_PER_CHUNK; ++rd) {
+        const int64_t round = chunk * ROUNDS_PER_CHUNK + rd;
+        const int64_t w = word_begin + round * ROUND_WORDS + threadIdx.x;
+        if (word_begin + round * ROUND_WORDS >= word_end) break;    // (uniform)
+        if (threadIdx.x < 256) L.cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t dr[32];                                            // bucket << 16 | rank inside the region
+        uint32_t has = 0;
+        LaneWord lw;
+        lw.ok = 0;
+        if (w < word_end) lw = load_lane_word(codes, valid, strict, w, k);
+        RowBits rb;
+        rb.starts = rb.ends = rb.r0 = 0; rb.inside0 = false;
+        if (lw.ok) {
+            rb.init(row_start, row_end, n_rows, row_start ? round_row[round] : 0, w << 5);
+            mini_segment<W>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, bits, cap, [&](int e, int, uint32_t b) {
+                dr[e] = (b << 16) | atomicAdd(&L.cnt[b >> bits2], 1u);
+                has |= 1u << e;
+            });
+        }
+        __syncthreads();
+        scan_digits<256>(L.cnt, L.start, L.wave_tot);
+        const uint32_t total = L.start[256];
+        // a round has at most 32 x 512 records; 8 positions x 512 lanes always fit the stage.  Nearly every round fits whole.
+        const int n_win = total <= (uint32_t)STAGE_CAP ? 1 : 4;
+        for (int win = 0; win < n_win; ++win) {
+            const uint32_t wmask = n_win == 1 ? 0xffffffffu : (0xffu << (8 * win));
+            // (opaque to the optimiser: otherwise everything the placement derives from the word -- 32 shifted copies of it -- is
+            // hoisted out of this loop and spilled)
+            asm volatile("" : "+v"(lw.x.cw), "+v"(lw.x.pw), "+v"(has));
+            if (n_win > 1) {                                        // rank again, this window's records only
+                __syncthreads();
+                if (threadIdx.x < 256) L.cnt[threadIdx.x] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 32; ++e)
+                    if ((has & wmask) >> e & 1u) dr[e] = (dr[e] & 0xffff0000u) | atomicAdd(&L.cnt[dr[e] >> (16 + bits2)], 1u);
+                __syncthreads();
+                scan_digits<256>(L.cnt, L.start, L.wave_tot);
+            }
+            // gbase[d] = (where the region's run goes) - (where it starts in the stage): the copy-out adds the stage position
+            if (threadIdx.x < 256) {
+                const uint32_t c = L.start[threadIdx.x + 1] - L.start[threadIdx.x];
+                L.gbase[threadIdx.x] = L.cur[threadIdx.x] - L.start[threadIdx.x];
+                L.cur[threadIdx.x] += c;
+            }
+            {
+                // a record's length and row follow from where it ends: it starts behind the previous record's end or behind the
+                // last position that ends no valid k-mer, whichever is later; its k-mers share one row (that of its last character)
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    if ((has & wmask) >> e & 1u) {
+                        const uint32_t b = dr[e] >> 16, d = b >> bits2;
+                        const uint32_t at = L.start[d] + (dr[e] & 0xffffu);
+                        const uint32_t below = e ? ((has | ~lw.ok) & ((1u << e) - 1u)) : 0u;     // ends / non-k-mers before e
+                        const int n = below ? e - (31 - __clz((int)below)) : e + 1;
+                        const uint32_t row = (lw.ok_row >> e) & 1u ? rb.at(e) : MINI_ROW_NONE;
+                        // the 32 characters ending at position e of the word
+                        L.bases[at] = e == 31 ? lw.x.cw : (lw.x.cw << (2 * (31 - e))) | (lw.x.pw >> (2 * (e + 1)));
+                        L.meta[at] = (row << META_ROW_SHIFT) | ((uint32_t)(n - 1) << META_D2_BITS) | (b & d2mask);
+                        L.dig[at] = (uint8_t)d;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t tot = L.start[256];
+            for (uint32_t i = threadIdx.x; i < tot; i += S1_BLOCK) {
+                const unsigned long long g = L.gbase[L.dig[i]] + i;
+                out_bases[g] = L.bases[i];
+                out_meta[g] = L.meta[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- A2': region -> buckets.  Region = blockIdx.x / tiles_x, its records are [off[region << bits2], off[(region + 1) << bits2]);
+// digit = the low bits2 bits of meta; bucket (region << bits2) + d starts at off[...] and fills through cursor[...].
+constexpr int S2_RPL = 16;
+constexpr int S2_TILE = BLOCK * S2_RPL;
+struct Scatter2Lds {
+    uint64_t bases[S2_TILE];
+    uint32_t meta[S2_TILE];
+    uint32_t cnt[128];
+    uint32_t start[129];
+    unsigned long long gbase[128];
+    uint32_t wave_tot[WAVES];
+};
+__global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__restrict__ in_bases, const uint32_t *__restrict__ in_meta,
+                                                              const unsigned long long *__restrict__ off, int bits2, int tiles_x,
+                                                              uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
+                                                              unsigned long long *__restrict__ cursor)
+{
+    __shared__ Scatter2Lds L;
+    const int n_dig = 1 << bits2;
+    const uint32_t dmask = (uint32_t)n_dig - 1u;
+    const int64_t region = blockIdx.x / tiles_x;
+    const int64_t b0 = region << bits2;
+    const int64_t r0 = (int64_t)off[b0], r1 = (int64_t)off[b0 + n_dig];
+    const int64_t n_tiles = (r1 - r0 + S2_TILE - 1) / S2_TILE;
+    for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
+        if (threadIdx.x < 128) L.cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t t0 = r0 + tile * S2_TILE;
+        uint64_t rb[S2_RPL];
+        uint32_t rm[S2_RPL], dr[S2_RPL];
+#pragma unroll
+        for (int j = 0; j < S2_RPL; ++j) {                          // all loads of the lane in flight together
+            const int64_t i = t0 + j * BLOCK + threadIdx.x;
+            rb[j] = i < r1 ? in_bases[i] : 0ull;
+            rm[j] = i < r1 ? in_meta[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < S2_RPL; ++j) {
+            const int64_t i = t0 + j * BLOCK + threadIdx.x;
+            if (i < r1) {
+                const uint32_t d = rm[j] & dmask;
+                dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
+            }
+        }
+        __syncthreads();
+        scan_digits<128>(L.cnt, L.start, L.wave_tot);
+        // the returning cursor adds (one per digit and tile) are issued first and consumed after the placement
+        unsigned long long gpos = 0;
+        if ((int)threadIdx.x < n_dig) {
+            const uint32_t c = L.start[threadIdx.x + 1] - L.start[threadIdx.x];
+            if (c) gpos = off[b0 + threadIdx.x] + atomicAdd(&cursor[b0 + threadIdx.x], (unsigned long long)c) - L.start[threadIdx.x];
+        }
+#pragma unroll
+        for (int j = 0; j < S2_RPL; ++j) {
+            const int64_t i = t0 + j * BLOCK + threadIdx.x;
+            if (i < r1) {
+                const uint32_t at = L.start[dr[j] >> 16] + (dr[j] & 0xffffu);
+                L.bases[at] = rb[j];
+                L.meta[at] = rm[j];
+            }
+        }
+        if ((int)threadIdx.x < n_dig) L.gbase[threadIdx.x] = gpos;
+        __syncthreads();
+        const uint32_t total = L.start[128];
+        for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {     // flat sweep: the digit is in the record
+            const uint32_t m = L.meta[i];
+            const unsigned long long g = L.gbase[m & dmask] + i;
+            out_bases[g] = L.bases[i];
+            out_meta[g] = m;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- B' + S1': one workgroup per bucket
+__device__ __forceinline__ bool mini_insert(unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code, uint32_t s)
+{
+    unsigned long long cur = tab[s];
+    for (uint32_t i = 0; i < limit; ++i) {
+        if (cur == 0) {
+            cur = atomicCAS(&tab[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
+            if (cur == 0) return true;
+        }
+        if ((cur >> HASH_CBITS) == code) {
+            // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
+            if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
+            return true;
+        }
+        s = (s + 1) & smask;
+        cur = tab[s];
+    }
+    return false;
+}
+
+constexpr uint32_t BIN_NONE = (uint32_t)HASH_CMASK;          // a slot's count field after the counts have become bins: bin + 1, or this
+
+__global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
+                                                               const unsigned long long *__restrict__ off, MiniView t,
+                                                               uint32_t window, uint32_t vsize, int vbits, uint32_t *__restrict__ words,
+                                                               unsigned long long *__restrict__ word_cursor, unsigned long long *__restrict__ wbeg,
+                                                               unsigned long long *__restrict__ emit_end, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ uint32_t emitted;
+    __shared__ unsigned long long n_lookups, wbase;
+    const uint32_t n_slots = 1u << t.log2_bucket;
+    const uint32_t smask = n_slots - 1;
+    const uint32_t limit = n_slots < MAX_PROBE ? n_slots : MAX_PROBE;
+    const int k = t.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    const int rc_sh0 = 2 * (32 - k);
+    uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = 0ull;
+    if (threadIdx.x == 0) { emitted = 0; n_lookups = 0; }
+    __syncthreads();
+    bool full = false;
+    unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
+    for (int64_t i0 = r0; i0 < r1; i0 += BIG_BLOCK) {            // ---- count
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < r1;
+        const uint64_t R = live ? bases[i] : 0ull;
+        const uint32_t m = live ? meta[i] : 0u;
+        const int n = live ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
+        if (live && (m >> META_ROW_SHIFT) != MINI_ROW_NONE) mine += (unsigned long long)n;
+        const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
+        for (int j = 0; j < MINI_MAX_LEN; ++j) {
+            if (!__any(j < n)) break;
+            if (j < n) {
+                const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
+                const uint64_t code = fw < rc ? fw : rc;
+                full |= !mini_insert(tab, smask, limit, code, mini_slot_hash(code) & smask);
+            }
+        }
+    }
+    if (full) atomicOr(status, 1u);
+    if (window) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_lookups, mine);
+    }
+    __syncthreads();
+    // the packed slice (an empty table needs no clearing: every slot is written); then counts -> bins, in place
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+        const unsigned long long v = tab[i];
+        uint32_t c = (uint32_t)(v & HASH_CMASK);
+        if (c > HASH_SAT) c = HASH_SAT;
+        slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
+        if (window && v) {
+            const uint32_t bin = c / window;
+            tab[i] = (v & ~(unsigned long long)HASH_CMASK) | (bin < vsize ? bin + 1u : BIN_NONE);
+        }
+    }
+    if (!window) return;
+    // this bucket's words go to a range of the word buffer claimed with one global add (an upper bound: every k-mer inside a row)
+    if (threadIdx.x == 0) {
+        wbase = atomicAdd(word_cursor, n_lookups);
+        wbeg[blockIdx.x] = wbase;
+    }
+    __syncthreads();
+    const unsigned long long wb = wbase;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int64_t i0 = r0; i0 < r1; i0 += BIG_BLOCK) {            // ---- lookups of the same records
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < r1;
+        const uint64_t R = live ? bases[i] : 0ull;
+        const uint32_t m = live ? meta[i] : 0xffffffffu;
+        const uint32_t row = m >> META_ROW_SHIFT;
+        const int n = live && row != MINI_ROW_NONE ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
+        const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
+        for (int j = 0; j < MINI_MAX_LEN; ++j) {
+            if (!__any(j < n)) break;
+            uint32_t bin1 = BIN_NONE;
+            if (j < n) {
+                const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
+                const uint64_t code = fw < rc ? fw : rc;
+                uint32_t s = mini_slot_hash(code) & smask;
+                unsigned long long cur = tab[s];
+                for (uint32_t q = 0; q < limit && cur != 0; ++q) {
+                    if ((cur >> HASH_CBITS) == code) { bin1 = (uint32_t)(cur & HASH_CMASK); break; }
+                    s = (s + 1) & smask;
+                    cur = tab[s];
+                }
+            }
+            const bool put = bin1 != BIN_NONE;
+            const unsigned long long mask = __ballot(put);
+            if (mask) {
+                const int leader = __ffsll((long long)mask) - 1;
+                uint32_t at = 0;
+                if ((int)lane == leader) at = atomicAdd(&emitted, (uint32_t)__popcll(mask));
+                at = __shfl(at, leader);
+                if (put) words[wb + at + __popcll(mask & ((1ull << lane) - 1ull))] = (row << vbits) | (bin1 - 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) emit_end[blockIdx.x] = wb + emitted;
+}
+
+// ---- workspace of the plan: header | hist | off | cur2 | wbeg | round_row | chunk table
+struct MiniPlan {
+    int bits, bits1, bits2;
+    int64_t n_rounds, n_chunks, chunk_stride;
+    size_t header_off, hist_off, off_off, cur2_off, wbeg_off, round_off, chunk_off, total;
+};
+
+int check_mini(const pg_table *t, const char *who)
+{
+    if (!t || !t->data) return pg_fail(PG_EINVAL, "%s: table descriptor is null", who);
+    if (t->kind != PG_TABLE_MINI) return pg_fail(PG_EINVAL, "%s: needs a PG_TABLE_MINI table", who);
+    if (t->k < PG_MINI_MIN_K || t->k > PG_HASH_MAX_K) return pg_fail(PG_EINVAL, "%s: mini tables need %d <= k <= %d (got %d)", who, PG_MINI_MIN_K, PG_HASH_MAX_K, t->k);
+    if (t->log2_bucket_slots < 4 || t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS)
+        return pg_fail(PG_EINVAL, "%s: log2_bucket_slots %d out of range [4,%d]", who, t->log2_bucket_slots, PG_BUCKET_MAX_LOG2_SLOTS);
+    const int bits = t->log2_slots - t->log2_bucket_slots;
+    if (bits < 0 || bits > PG_MINI_MAX_LOG2_BUCKETS) return pg_fail(PG_EINVAL, "%s: 2^%d buckets (at most 2^%d)", who, bits, PG_MINI_MAX_LOG2_BUCKETS);
+    return PG_OK;
+}
+
+int plan_mini(const pg_table *t, int64_t n_words, MiniPlan *p)
+{
+    p->bits = t->log2_slots - t->log2_bucket_slots;
+    p->bits1 = p->bits < MINI_BITS1 ? p->bits : MINI_BITS1;
+    p->bits2 = p->bits - p->bits1;
+    p->n_rounds = (n_words + ROUND_WORDS - 1) / ROUND_WORDS;
+    p->n_chunks = (n_words + MINI_CHUNK_WORDS - 1) / MINI_CHUNK_WORDS;
+    if (p->n_chunks < 1) p->n_chunks = 1;
+    // golden-ratio stride, made coprime to the chunk count: regions hold the stream in scrambled chunk order, so the bucket
+    // workgroups (and the row shuffle behind them) do not all see the same rows at the same time
+    p->chunk_stride = (int64_t)((double)p->n_chunks * 0.6180339887) | 1;
+    auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t r = a % b; a = b; b = r; } return a; };
+    while (gcd(p->chunk_stride, p->n_chunks) != 1) p->chunk_stride += 2;
+    const size_t nb = (size_t)1 << p->bits;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    p->header_off = take(256);
+    p->hist_off = take(nb * 8);
+    p->off_off = take((nb + 1) * 8);
+    p->cur2_off = take(nb * 8);
+    p->wbeg_off = take(nb * 8);
+    p->round_off = take((size_t)(p->n_rounds + 1) * 4);
+    p->chunk_off = take(((size_t)p->n_chunks << p->bits1) * 8);
+    p->total = o;
+    return PG_OK;
+}
+
+MiniView mini_view(const pg_table *t)
+{
+    MiniView v;
+    v.slots = (uint64_t *)t->data;
+    v.log2_slots = t->log2_slots;
+    v.log2_bucket = t->log2_bucket_slots;
+    v.k = t->k;
+    return v;
+}
+
+int check_mini_rows(const pg_rows *rows, const char *who)
+{
+    if (!rows) return PG_OK;
+    if (rows->n_rows < 0 || rows->n_rows > PG_MINI_MAX_ROWS) return pg_fail(PG_EINVAL, "%s: %lld rows (at most %d per launch)", who, (long long)rows->n_rows, PG_MINI_MAX_ROWS);
+    if (rows->n_rows > 0 && (!rows->row_start || !rows->row_end)) return pg_fail(PG_EINVAL, "%s: null row arrays", who);
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t pg_mini_plan_bytes(int64_t n_words, const pg_table *t)
+{
+    if (n_words < 0) return pg_fail(PG_EINVAL, "negative word count");
+    int rc = check_mini(t, "pg_mini_plan_bytes");
+    if (rc) return rc;
+    MiniPlan p;
+    plan_mini(t, n_words, &p);
+    return (int64_t)p.total;
+}
+
+extern "C" int64_t pg_mini_records_bytes(int64_t n_records)
+{
+    if (n_records < 0) return pg_fail(PG_EINVAL, "negative record count");
+    const size_t n = ((size_t)n_records + 255) / 256 * 256 + 256;
+    return (int64_t)(2 * n * 12);
+}
+
+extern "C" int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize)
+{
+    if (n_words < 0 || n_rows < 0) return pg_fail(PG_EINVAL, "negative size");
+    pg_shuffle_layout sl;
+    int rc = pg_internal_shuffle_layout(n_words * 32, n_rows, vsize, &sl);
+    if (rc) return rc;
+    return (int64_t)sl.total;
+}
+
+#define PG_MINI_DISPATCH_W(W_, CALL)                                                                                        \
+    switch (W_) {                                                                                                           \
+    case 4: { constexpr int W = 4; CALL; } break;                                                                           \
+    case 5: { constexpr int W = 5; CALL; } break;                                                                           \
+    case 6: { constexpr int W = 6; CALL; } break;                                                                           \
+    case 7: { constexpr int W = 7; CALL; } break;                                                                           \
+    case 8: { constexpr int W = 8; CALL; } break;                                                                           \
+    default: { constexpr int W = 9; CALL; } break;                                                                          \
+    }
+
+extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                            const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *stream)
+{
+    if (!codes || !valid || !plan_ws) return pg_fail(PG_EINVAL, "pg_mini_plan: null argument");
+    if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_mini_plan: bad word range");
+    int rc = check_mini(t, "pg_mini_plan");
+    if (rc) return rc;
+    if ((rc = check_mini_rows(rows, "pg_mini_plan"))) return rc;
+    MiniPlan p;
+    plan_mini(t, word_end - word_begin, &p);
+    if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_plan: workspace of %lld bytes, %lld needed", (long long)plan_ws_bytes, (long long)p.total);
+    if ((reinterpret_cast<uintptr_t>(plan_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_plan: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)plan_ws;
+    auto *header = (unsigned long long *)(ws + p.header_off);
+    auto *hist = (unsigned long long *)(ws + p.hist_off);
+    auto *off = (unsigned long long *)(ws + p.off_off);
+    auto *round_row = (int32_t *)(ws + p.round_off);
+    auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
+    const int nb = 1 << p.bits;
+    if (hipMemsetAsync(ws, 0, p.round_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_mini_plan: memset failed");
+    if (hipMemsetAsync(chunk_tab, 0, ((size_t)p.n_chunks << p.bits1) * 8, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_mini_plan: memset failed");
+    const bool with_rows = rows && rows->n_rows > 0;
+    if (word_end > word_begin) {
+        if (with_rows)
+            hipLaunchKernelGGL(round_rows_kernel, dim3((unsigned)((p.n_rounds + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_end, rows->n_rows,
+                               word_begin, p.n_rounds, round_row);
+        const size_t lds = (size_t)nb * 4 + 1024;
+        const int grid = (int)(p.n_chunks < 512 ? p.n_chunks : 512);
+        PG_MINI_DISPATCH_W(t->k - PG_MINI_M + 1,
+            if ((rc = raise_lds_limit((const void *)mini_plan_kernel<W>, lds, "pg_mini_plan"))) return rc;
+            hipLaunchKernelGGL(mini_plan_kernel<W>, dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, p.bits, p.bits2,
+                               with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
+                               with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
+                               (const int32_t *)round_row, hist, chunk_tab, p.n_chunks, p.chunk_stride))
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)hist, (int64_t)nb, off);
+    hipLaunchKernelGGL(digit_scan_kernel, dim3(1u << p.bits1), dim3(BIG_BLOCK), 0, s, chunk_tab, p.n_chunks, (const unsigned long long *)off,
+                       p.bits2, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(mini_total_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long *)off, nb, header);
+    return check_launch("pg_mini_plan");
+}
+
+extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                             const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                             int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream)
+{
+    if (!codes || !valid || !plan_ws || !rec_ws || !status) return pg_fail(PG_EINVAL, "pg_mini_count: null argument");
+    if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_mini_count: bad word range");
+    int rc = check_mini(t, "pg_mini_count");
+    if (rc) return rc;
+    if ((rc = check_mini_rows(rows, "pg_mini_count"))) return rc;
+    const bool with_rows = rows && rows->n_rows > 0;
+    if (window < 0 || vsize < 0 || (window > 0) != (vsize > 0)) return pg_fail(PG_EINVAL, "pg_mini_count: window %d / vector size %d", window, vsize);
+    if (window > 0) {
+        if (!with_rows) return pg_fail(PG_EINVAL, "pg_mini_count: the lookup pass needs rows");
+        if (!shuffle_ws) return pg_fail(PG_EINVAL, "pg_mini_count: null shuffle workspace");
+        if (vsize > PG_SHUFFLE_MAX_VSIZE || (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
+            return pg_fail(PG_EINVAL, "pg_mini_count: window %d x vector size %d outside the exact range of the table", window, vsize);
+    }
+    MiniPlan p;
+    plan_mini(t, word_end - word_begin, &p);
+    if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_count: plan workspace of %lld bytes, %lld needed", (long long)plan_ws_bytes, (long long)p.total);
+    if ((reinterpret_cast<uintptr_t>(plan_ws) & 255) != 0 || (reinterpret_cast<uintptr_t>(rec_ws) & 255) != 0)
+        return pg_fail(PG_EINVAL, "pg_mini_count: workspaces must be 256-byte aligned");
+    if (rec_ws_bytes < 24 * 256 || rec_ws_bytes % 24 != 0) return pg_fail(PG_EINVAL, "pg_mini_count: record workspace size %lld", (long long)rec_ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)plan_ws;
+    auto *header = (unsigned long long *)(ws + p.header_off);
+    auto *off = (unsigned long long *)(ws + p.off_off);
+    auto *cur2 = (unsigned long long *)(ws + p.cur2_off);
+    auto *wbeg = (unsigned long long *)(ws + p.wbeg_off);
+    auto *round_row = (int32_t *)(ws + p.round_off);
+    auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
+    const int nb = 1 << p.bits;
+    // record buffers: [bases A | bases B | meta A | meta B], cap records each
+    const size_t cap = (size_t)rec_ws_bytes / 24;
+    auto *bases_a = (uint64_t *)rec_ws;
+    auto *bases_b = bases_a + cap;
+    auto *meta_a = (uint32_t *)(bases_b + cap);
+    auto *meta_b = meta_a + cap;
+    if (hipMemsetAsync(cur2, 0, (size_t)nb * 8, s) != hipSuccess || hipMemsetAsync(header + 1, 0, 8, s) != hipSuccess)
+        return pg_fail(PG_EHIP, "pg_mini_count: memset failed");
+    pg_shuffle_layout sl{0, 0, 0, 0};
+    if (window > 0) {
+        if ((rc = pg_internal_shuffle_layout((word_end - word_begin) * 32, rows->n_rows, vsize, &sl))) return rc;
+        if ((int64_t)sl.total > shuffle_ws_bytes || (reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0)
+            return pg_fail(PG_EINVAL, "pg_mini_count: shuffle workspace of %lld bytes (256-byte aligned), %lld needed", (long long)shuffle_ws_bytes, (long long)sl.total);
+    }
+    const size_t slice_lds = (size_t)8 << t->log2_bucket_slots;
+    if (word_end > word_begin) {
+        const size_t lds1 = sizeof(Scatter1Lds);
+        PG_MINI_DISPATCH_W(t->k - PG_MINI_M + 1,
+            if ((rc = raise_lds_limit((const void *)mini_scatter_kernel<W>, lds1, "pg_mini_count"))) return rc;
+            hipLaunchKernelGGL(mini_scatter_kernel<W>, dim3((unsigned)p.n_chunks), dim3(S1_BLOCK), lds1, s, codes, valid, word_begin, word_end, t->k, p.bits,
+                               p.bits2, with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
+                               with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
+                               (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride))
+        if (p.bits2) {
+            const int tiles_x = 96;
+            hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
+                               (const unsigned long long *)off, p.bits2, tiles_x, bases_b, meta_b, cur2);
+        }
+    }
+    if ((rc = raise_lds_limit((const void *)mini_count_kernel, slice_lds, "pg_mini_count"))) return rc;
+    hipLaunchKernelGGL(mini_count_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)(p.bits2 ? bases_b : bases_a),
+                       (const uint32_t *)(p.bits2 ? meta_b : meta_a), (const unsigned long long *)off, mini_view(t), (uint32_t)window, (uint32_t)vsize,
+                       sl.vbits, window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr, header + 1, wbeg,
+                       window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr, status);
+    return check_launch("pg_mini_count");
+}
+
+extern "C" int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int vsize, int32_t *abd_out,
+                                              const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
+                                              void *shuffle_ws, int64_t shuffle_ws_bytes, void *stream)
+{
+    int rc = check_mini(t, "pg_mini_abundance_from_emitted");
+    if (rc) return rc;
+    if (!rows || !abd_out || !plan_ws || !shuffle_ws) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: null argument");
+    if ((rc = check_mini_rows(rows, "pg_mini_abundance_from_emitted"))) return rc;
+    MiniPlan p;
+    plan_mini(t, n_words_counted, &p);
+    if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: plan workspace does not match n_words_counted");
+    if ((reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: workspace must be 256-byte aligned");
+    const auto *wbeg = (const unsigned long long *)((const char *)plan_ws + p.wbeg_off);
+    return pg_internal_shuffle_rows(wbeg, 1 << p.bits, n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
+}

@@ -100,6 +100,57 @@ __global__ __launch_bounds__(BIG_BLOCK) void scan_kernel(const unsigned long lon
 }
 
 
+// -------------------------------------------------------------------------------- minimizer buckets (PG_TABLE_MINI)
+//
+// A MINI table places a canonical k-mer by the MINIMIZER of its M-mers (M = 13: odd, so no M-mer is its own reverse
+// complement): bucket = a hash of the smallest mhash(canonical M-mer) over the k - M + 1 M-mers of the k-mer.  Consecutive
+// k-mers of a read mostly share their minimizer, so the occurrences that go to one bucket travel as SUPER-k-mers: one
+// 12-byte record (32 bases + row + length) for a run of up to 16 k-mers instead of 8 bytes per occurrence.  Inside the
+// bucket the home slot is slot_hash(code); slots hold (canonical code << 22) | count, 0 = empty.
+constexpr int MINI_M = PG_MINI_M;
+constexpr uint32_t MINI_MMASK = (1u << (2 * MINI_M)) - 1u;
+constexpr uint32_t MINI_MCOMP = 0xAAAAAAAAu & MINI_MMASK;
+
+// a bijection of 32-bit words (odd multipliers, xorshifts): distinct canonical M-mers have distinct values, so "the
+// smallest value" picks the same M-mer on both strands
+__device__ __forceinline__ uint32_t mhash(uint32_t x)
+{
+    x *= 0x9E3779B1u; x ^= x >> 15;
+    x *= 0x85EBCA77u; x ^= x >> 13;
+    return x;
+}
+// bucket of a minimizer value (the value itself is biased towards small numbers: mix once more, take the top bits)
+__device__ __forceinline__ uint32_t mini_bucket(uint32_t minv, int bits)
+{
+    return bits ? (minv * 0xC2B2AE3Du) >> (32 - bits) : 0u;
+}
+__device__ __forceinline__ uint32_t swap_pairs32(uint32_t x) { return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
+// order of the 32 two-bit characters of a word reversed
+__device__ __forceinline__ uint64_t rev2_64(uint64_t x)
+{
+    const uint32_t lo = swap_pairs32(__brev((uint32_t)x)), hi = swap_pairs32(__brev((uint32_t)(x >> 32)));
+    return ((uint64_t)lo << 32) | hi;
+}
+__device__ __forceinline__ uint32_t mini_slot_hash(uint64_t code)
+{
+    uint32_t x = (uint32_t)code ^ ((uint32_t)(code >> 32) * 0x9E3779B1u);
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 16;
+    return x;
+}
+// minimizer value of one k-mer given as a (forward or canonical) code, newest character in the low bits
+__device__ __forceinline__ uint32_t mini_minimizer_of(uint64_t code, int k)
+{
+    uint32_t best = 0xffffffffu;
+    for (int t = 0; t + MINI_M <= k; ++t) {
+        const uint32_t fw = (uint32_t)(code >> (2 * t)) & MINI_MMASK;
+        const uint32_t rc = (swap_pairs32(__brev(fw)) >> (32 - 2 * MINI_M)) ^ MINI_MCOMP;
+        const uint32_t h = mhash(fw < rc ? fw : rc);
+        best = h < best ? h : best;
+    }
+    return best;
+}
+
 int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -107,7 +158,7 @@ int check_launch(const char *what)
     return PG_OK;
 }
 
-int grid_for(int64_t items, int block = BLOCK)
+__attribute__((unused)) int grid_for(int64_t items, int block = BLOCK)
 {
     int64_t blocks = (items + block - 1) / block;
     const int64_t cap = 256 * 16;     // 256 CUs x 16 resident workgroups' worth, grid-stride beyond

@@ -6,4 +6,15 @@
 // records the message for pg_last_error() on this thread and returns `code`
 int pg_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+
+// the row shuffle of kernels.hip (S2 + S3), for the pipelines of other translation units: the (row, bin) words of bucket b
+// lie at words_e[in_begin[b] .. emit_end[b]) inside `workspace` (layout below; emit_end at emit_off, uint64 per bucket)
+struct pg_shuffle_layout {
+    int vbits;
+    size_t emit_off, words_e_off, total;
+};
+int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out);
+int pg_internal_shuffle_rows(const unsigned long long *in_begin, int nb, int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out,
+                             void *workspace, int64_t workspace_bytes, void *stream);
+
 #endif

@@ -47,7 +47,7 @@ class KmerTable:
     def __init__(self, k: int, kind: str, data: torch.Tensor, log2_slots: int = 0, log2_bucket: int = 0):
         self.k, self.kind, self.data, self.log2_slots, self.log2_bucket = int(k), kind, data, int(log2_slots), int(log2_bucket)
         self.status = torch.zeros(2, dtype=torch.int32, device=data.device)
-        code = {"dense": _lib.TABLE_DENSE, "hash": _lib.TABLE_HASH, "wide": _lib.TABLE_WIDE}[kind]
+        code = {"dense": _lib.TABLE_DENSE, "hash": _lib.TABLE_HASH, "wide": _lib.TABLE_WIDE, "mini": _lib.TABLE_MINI}[kind]
         self._desc = _lib.pg_table(code, self.k, self.log2_slots, self.log2_bucket, data.data_ptr())
         self._empty = True               # nothing counted since allocation / reset()
         self._workspace = None
@@ -55,6 +55,8 @@ class KmerTable:
         self._records = None             # (plan, n_words) while the workspace holds the row-tagged records of ONE count
         self._deferred = None            # (fill, n_words) after a deferred count: entries wait in the workspace, slots unwritten
         self._emitted = None             # (window, vsize) while the shuffle workspace holds the words of a fused count + lookup
+        self._mini_plan = None           # (key, plan workspace, n_records) of the last pg_mini_plan: reused while the key matches
+        self._mini_rec_ws = None
 
     # ------------------------------------------------------------------ construction
 
@@ -86,6 +88,9 @@ class KmerTable:
             if k > _lib.DENSE_MAX_K:
                 raise ValueError(f"dense tables need k <= {_lib.DENSE_MAX_K}")
             return cls(k, "dense", torch.zeros(4 ** k, dtype=torch.int32, device=device))
+        if kind == "mini":
+            want = max(1024, int((distinct_hint or 1 << 20) / load))
+            return cls.mini_with_slots(k, device, max(10, math.ceil(math.log2(want))), log2_bucket)
         if kind not in ("hash", "wide"):
             raise ValueError(f"unknown table kind {kind!r}")
         if kind == "hash" and k > _lib.HASH_MAX_K:
@@ -95,6 +100,21 @@ class KmerTable:
         if kind == "wide":
             return cls.wide_with_slots(k, device, log2)
         return cls.with_slots(k, device, log2, log2_bucket)
+
+    @staticmethod
+    def mini_applies(k: int, log2_slots: int, log2_bucket: int | None = None) -> bool:
+        """can a MINI table (minimizer buckets, built from super-k-mers) hold 2^log2_slots slots for this k?"""
+        lb = min(_lib.BUCKET_MAX_LOG2_SLOTS, log2_slots) if log2_bucket is None else log2_bucket
+        return (_lib.MINI_MIN_K <= k <= _lib.HASH_MAX_K and 4 <= lb <= _lib.BUCKET_MAX_LOG2_SLOTS
+                and 0 <= log2_slots - lb <= _lib.MINI_MAX_LOG2_BUCKETS)
+
+    @classmethod
+    def mini_with_slots(cls, k: int, device, log2_slots: int, log2_bucket: int | None = None) -> "KmerTable":
+        lb = min(_lib.BUCKET_MAX_LOG2_SLOTS, log2_slots) if log2_bucket is None else log2_bucket
+        if not cls.mini_applies(k, log2_slots, lb):
+            raise ValueError(f"mini tables need {_lib.MINI_MIN_K} <= k <= {_lib.HASH_MAX_K} and at most 2^{_lib.MINI_MAX_LOG2_BUCKETS} buckets "
+                             f"of at most 2^{_lib.BUCKET_MAX_LOG2_SLOTS} slots (k {k}, 2^{log2_slots} slots, buckets of 2^{lb})")
+        return cls(k, "mini", torch.zeros(1 << log2_slots, dtype=torch.int64, device=device), log2_slots, lb)
 
     @classmethod
     def wide_with_slots(cls, k: int, device, log2_slots: int) -> "KmerTable":
@@ -127,6 +147,9 @@ class KmerTable:
             table.check_status()
         elif table.kind == "dense":
             table.data[codes.to(table.device)] = counts.to(table.device, torch.int32)
+        elif table.kind == "mini":                     # the slots hold the codes themselves
+            sat = torch.clamp(counts, max=_lib.HASH_COUNT_SAT)
+            table.merge(((codes << _lib.HASH_COUNT_BITS) | sat)[sat > 0])
         else:
             sat = torch.clamp(counts, max=_lib.HASH_COUNT_SAT)
             keys = torch.from_numpy(key42(codes.numpy().view(np.uint64)).view(np.int64))
@@ -148,7 +171,7 @@ class KmerTable:
 
     def reset(self) -> "KmerTable":
         """forget every count.  Bucketed tables are not even cleared: the next count overwrites every slice."""
-        if not (self.kind == "hash" and self.log2_bucket):
+        if not (self.kind in ("hash", "mini") and self.log2_bucket):
             self.data.zero_()
         self.status.zero_()
         self._empty = True
@@ -214,6 +237,10 @@ class KmerTable:
             self._rows_desc_keepalive = desc
             return C.byref(desc)
 
+        if self.kind == "mini":
+            if deferred_group is not None:
+                raise ValueError("mini tables have no deferred form")
+            return self._count_mini(stream, word_begin, word_end, valid_ptr, rows, rows_arg, emit, lenient, check)
         if deferred_group is not None:
             if not self.can_defer(word_end - word_begin):
                 raise ValueError("deferred counting needs a fresh bucketed table with more than 256 buckets and a single pass")
@@ -272,16 +299,75 @@ class KmerTable:
             self.check_status()
         return self
 
+    def _count_mini(self, stream, word_begin, word_end, valid_ptr, rows, rows_arg, emit, lenient, check):
+        """the super-k-mer pipeline (pg_mini_plan + pg_mini_count): a fresh table, one piece.  The partition plan depends on
+        the stream, the rows and the geometry only and is kept: counting the same range again skips pg_mini_plan."""
+        if not self._empty:
+            raise ValueError("mini tables are built by ONE count of a fresh (or reset) table")
+        L = _lib.load()
+        n_words = word_end - word_begin
+        keep = rows if (rows is not None and rows.shuffle_ok and rows.n_rows <= _lib.MINI_MAX_ROWS) else None
+        if rows is not None and keep is None:
+            raise ValueError("mini tables need sorted, disjoint, non-empty rows (at most 2^21 - 2 of them)")
+        fuse = (emit is not None and keep is not None and n_words > 0 and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1
+                and emit[0] * emit[1] <= _lib.HASH_COUNT_SAT)
+        key = (stream.codes.data_ptr(), valid_ptr, word_begin, word_end, id(keep), bool(lenient), self.log2_slots, self.log2_bucket)
+        with torch.cuda.device(self.device):
+            if self._mini_plan is None or self._mini_plan[0] != key:
+                need = _lib.check(L.pg_mini_plan_bytes(n_words, self.desc()))
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _lib.check(L.pg_mini_plan(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
+                                          ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
+                n_records = int(ws[:8].view(torch.int64).item())          # (host sync; once per plan)
+                self._mini_plan = (key, ws, n_records, keep)
+            _, plan_ws, n_records, _ = self._mini_plan
+            need = _lib.check(L.pg_mini_records_bytes(n_records))
+            if self._mini_rec_ws is None or self._mini_rec_ws.numel() != need:
+                self._mini_rec_ws = None
+                self._mini_rec_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            window, vsize, sws_ptr, sws_n = 0, 0, None, 0
+            if fuse:
+                window, vsize = int(emit[0]), int(emit[1])
+                need = _lib.check(L.pg_mini_shuffle_bytes(n_words, keep.n_rows, vsize))
+                if self._shuffle_ws is None or self._shuffle_ws.numel() < need:
+                    self._shuffle_ws = None
+                    self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                sws_ptr, sws_n = self._shuffle_ws.data_ptr(), self._shuffle_ws.numel()
+            _lib.check(L.pg_mini_count(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
+                                       plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
+                                       window, vsize, sws_ptr, sws_n, self.status.data_ptr(), _stream_ptr(self.device)))
+        self._empty = False
+        self._records = (keep, n_words) if fuse else None
+        self._emitted = (window, vsize) if fuse else None
+        if check:
+            self.check_status()
+        return self
+
+    def can_shuffle(self, plan: "Plan", window: int, vsize: int) -> bool:
+        """can ``abundance_from_records`` build the rows of this plan (instead of table lookups)?"""
+        if self.kind == "mini":
+            return self._records is not None and self._records[0] is plan and self._emitted == (int(window), int(vsize))
+        return self.has_records_for(plan, vsize)
+
     def has_records_for(self, plan: "Plan", vsize: int) -> bool:
         return (self._records is not None and self._records[0] is plan and vsize <= _lib.SHUFFLE_MAX_VSIZE
                 and self.kind == "hash" and bool(self.log2_bucket))
 
     def abundance_from_records(self, plan: "Plan", window: int, vsize: int, out: torch.Tensor) -> torch.Tensor:
         """abundance rows by shuffle: bucket-wise LDS lookups of the kept records + row-group scatter + LDS row histograms"""
-        if not self.has_records_for(plan, vsize):
+        if not self.can_shuffle(plan, window, vsize):
             raise RuntimeError("no partition records for these rows: count(stream, rows=plan) first")
         n_words = self._records[1]
         L = _lib.load()
+        if self.kind == "mini":
+            plan_ws = self._mini_plan[1]
+            with torch.cuda.device(self.device):
+                _lib.check(L.pg_mini_abundance_from_emitted(self.desc(), C.byref(plan.rows_desc), vsize, out.data_ptr(), plan_ws.data_ptr(),
+                                                            plan_ws.numel(), n_words, self._shuffle_ws.data_ptr(), self._shuffle_ws.numel(),
+                                                            _stream_ptr(self.device)))
+            self._emitted = None        # the row shuffle reuses the emitted words' buffer
+            self._records = None
+            return out
         emitted = self._emitted == (int(window), int(vsize))          # the lookup pass already ran inside the count
         sws = self._shuffle_ws if emitted else self._shuffle_workspace_for(n_words, plan.n_rows, vsize)
         fn = L.pg_abundance_from_emitted if emitted else L.pg_abundance_from_records
@@ -299,10 +385,10 @@ class KmerTable:
         """add (key << 22 | count) pairs (slot format, key = key42(code)), e.g. the compacted table of another GPU"""
         if not pending_ok:
             self._require_counts()
-        if self.kind != "hash":
-            raise ValueError("merge() is for hash tables; dense tables are summed with all_reduce")
+        if self.kind not in ("hash", "mini"):
+            raise ValueError("merge() is for hash and mini tables; dense tables are summed with all_reduce")
         pairs = pairs.to(self.device, torch.int64).contiguous()
-        if self._empty and self.kind == "hash" and self.log2_bucket:
+        if self._empty and self.log2_bucket:
             self.data.zero_()            # a reset() bucketed table is only logically empty
         self._empty = False
         with torch.cuda.device(self.device):
@@ -314,7 +400,7 @@ class KmerTable:
 
     @property
     def n_buckets(self) -> int:
-        return 1 << (self.log2_slots - self.log2_bucket) if self.kind == "hash" and self.log2_bucket else 1
+        return 1 << (self.log2_slots - self.log2_bucket) if self.kind in ("hash", "mini") and self.log2_bucket else 1
 
     def bucket_counts(self) -> torch.Tensor:
         """occupied slots per bucket, int64 [n_buckets] -- the segment lengths of ``compact()`` (slot order = bucket order)"""
@@ -484,8 +570,8 @@ class KmerTable:
     def compact(self) -> torch.Tensor:
         """occupied slots of a hash table as an int64 vector (slot format)"""
         self._require_counts()
-        if self.kind != "hash":
-            raise ValueError("compact() is for hash tables")
+        if self.kind not in ("hash", "mini"):
+            raise ValueError("compact() is for hash and mini tables")
         step = 1 << 30                       # torch's masked select overflows its 32-bit indexing at 2^31 elements
         if self.data.numel() <= step:
             return self.data[self.data != 0]
@@ -495,7 +581,7 @@ class KmerTable:
         self._require_counts()
         if self.kind == "wide":
             return float(torch.count_nonzero(self._wide_parts()[0]).item()) / (1 << self.log2_slots)
-        if self.kind != "hash":
+        if self.kind not in ("hash", "mini"):
             return float("nan")
         return float(torch.count_nonzero(self.data).item()) / self.data.numel()
 
@@ -514,6 +600,10 @@ class KmerTable:
             order = np.argsort(codes)
             return codes[order], counts[order]
         s = self.compact().cpu().numpy().view(np.uint64)
+        if self.kind == "mini":
+            codes, counts = s >> np.uint64(_lib.HASH_COUNT_BITS), s & np.uint64((1 << _lib.HASH_COUNT_BITS) - 1)
+            order = np.argsort(codes)
+            return codes[order], counts[order]
         codes, counts = key42_inverse(s >> np.uint64(_lib.HASH_COUNT_BITS)), s & np.uint64((1 << _lib.HASH_COUNT_BITS) - 1)
         order = np.argsort(codes)
         return codes[order], counts[order]
@@ -595,6 +685,12 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
             if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
                 raise
             log2 = min(max_log2_slots, table.log2_slots + 2)
+            if table.kind == "mini":
+                lb = min(_lib.BUCKET_MAX_LOG2_SLOTS, table.log2_bucket + 2)
+                del table
+                table = (KmerTable.mini_with_slots(k, stream.device, log2, lb) if KmerTable.mini_applies(k, log2, lb)
+                         else KmerTable.with_slots(k, stream.device, log2))
+                continue
             if table.kind == "wide":
                 del table
                 table = KmerTable.wide_with_slots(k, stream.device, log2)
@@ -683,7 +779,7 @@ def features(stream: ReadStream, rows: Rows | Plan, k_tnf: int | None = 4, table
         colmap, _ = tnf_colmap(k_tnf, dev)
         colmap_ptr = colmap.data_ptr()
         tnf = out_tnf.zero_() if out_tnf is not None else torch.zeros((n, tnf_ncols(k_tnf)), dtype=torch.int32, device=dev)
-    shuffle = table is not None and table.has_records_for(plan, vsize)
+    shuffle = table is not None and table.can_shuffle(plan, window, vsize)
     if table is not None:
         table._require_counts()
         if table.device != dev:

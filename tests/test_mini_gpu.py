@@ -1,0 +1,164 @@
+"""The super-k-mer pipeline (PG_TABLE_MINI: pg_mini_plan + pg_mini_count) against the oracle and against the other HIP paths.
+
+Bit-exact throughout (integer counts).  The table must be the oracle's exact canonical k-mer multiplicities
+(jellyfish count -C, src/feature.py:94) and the abundance rows those of count_kmer.cpp:55-108, whatever the minimizer
+buckets, record boundaries and round / window structure of the kernels are.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from pangaea_amd import _lib, kmer, synth
+from pangaea_amd.reads import ReadStream, Rows
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle(s, rows, k, window, vsize, k_tnf=4):
+    text = s.decode()
+    table = oracle.Table(k, threads=4).count(text)
+    tnf = np.stack([oracle.tnf_row(text[a:b], k_tnf) for a, b in zip(rows.start, rows.end)]) if len(rows) else None
+    abd = np.stack([oracle.abd_row(text[a:b], k, table, window, vsize) for a, b in zip(rows.start, rows.end)]) if len(rows) else None
+    return table, tnf, abd
+
+
+def _same_items(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("k,log2_slots,log2_bucket,window,vsize,min_len,n_pairs", [
+    (21, 19, 14, 10, 400, 2000, 3000),      # 32 buckets: first pass only
+    (21, 22, 10, 10, 400, 2000, 3000),      # 4096 buckets: both passes
+    (21, 18, 14, 1, 6, 302, 800),           # 16 buckets
+    (21, 14, 14, 3, 64, 0, 40),             # one bucket, every run a row
+    (16, 20, 9, 2, 50, 2000, 3000),         # the smallest k, windows of 4 M-mers, 16 k-mers per record
+    (17, 20, 8, 7, 33, 600, 3000),
+    (19, 21, 12, 25, 512, 2000, 3000),
+    (20, 20, 11, 1, 512, 2000, 3000),
+])
+def test_mini_table_and_rows_against_oracle(k, log2_slots, log2_bucket, window, vsize, min_len, n_pairs):
+    cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=min(37, max(1, n_pairs // 20)), n_genomes=3, genome_len=30_000, fragment=8_000,
+                            sub_rate=0.01, n_rate=0.2, seed=500 + k)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(min_len)
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.KmerTable.mini_with_slots(k, DEV, log2_slots, log2_bucket)
+    t.data.fill_(0x7FFF_FFFF_FFFF)                      # a fresh table is never cleared: every slot must be overwritten
+    t.count(s, rows=plan, emit=(window, vsize))
+    assert t.kind == "mini" and t._emitted == (window, vsize)
+    otab, otnf, oabd = _oracle(s, rows, k, window, vsize)
+    assert _same_items(t.items(), otab.items())
+    tnf, abd = kmer.features(s, plan, k_tnf=4, table=t, window=window, vsize=vsize)                 # from the emitted words
+    assert t._emitted is None
+    assert np.array_equal(tnf.cpu().numpy(), otnf) and np.array_equal(abd.cpu().numpy(), oabd)
+    _, abd_l = kmer.features(s, rows, k_tnf=None, table=t, window=window, vsize=vsize, seg_chars=64)  # by lookups in the mini table
+    assert torch.equal(abd_l, abd)
+    _, abd_o = kmer.features(s, plan, k_tnf=None, table=t, window=window + 1, vsize=vsize)          # other parameters: lookups too
+    h = kmer.count_kmers(s, k, kind="hash")
+    _, want = kmer.features(s, rows, k_tnf=None, table=h, window=window + 1, vsize=vsize)
+    assert torch.equal(abd_o, want)
+    # counting again (reset) reuses the partition plan and gives the same table and rows
+    plan_ws = t._mini_plan[1]
+    t.reset().count(s, rows=plan, emit=(window, vsize))
+    assert t._mini_plan[1] is plan_ws
+    _, abd2 = kmer.features(s, plan, k_tnf=None, table=t, window=window, vsize=vsize)
+    assert torch.equal(abd2, abd) and _same_items(t.items(), otab.items())
+
+
+def test_mini_table_only_and_from_items():
+    cfg = synth.SynthConfig(n_pairs=1500, n_barcodes=11, n_genomes=2, genome_len=20_000, fragment=5_000, sub_rate=0.02, n_rate=0.3, seed=77)
+    s = synth.generate(cfg, device=DEV)
+    t = kmer.count_kmers(s, 21, kind="mini")                       # no rows, no lookups
+    otab = oracle.Table(21, threads=4).count(s.decode())
+    assert t.kind == "mini" and _same_items(t.items(), otab.items())
+    codes, counts = otab.items()
+    u = kmer.KmerTable.from_items(21, codes, counts, DEV, "mini")   # entries of a dump, placed by pg_kmer_merge
+    assert _same_items(u.items(), otab.items())
+    rows = s.rows(2000)
+    _, a = kmer.features(s, rows, k_tnf=None, table=u, window=2, vsize=100)
+    _, b = kmer.features(s, rows, k_tnf=None, table=t, window=2, vsize=100)
+    assert torch.equal(a, b) and int(a.sum()) > 0
+    with pytest.raises(ValueError):
+        t.count(s)                                                  # one count per fresh table
+    with pytest.raises(ValueError):
+        kmer.KmerTable.mini_with_slots(15, DEV, 20)
+
+
+def test_mini_every_kmer_its_own_record():
+    """rows of one character cut every record to a single k-mer: 32 records per word, rounds that do not fit the LDS stage and
+    are laid out in four windows; the rows are those of the lookup kernel on a key-partitioned table"""
+    rng = np.random.RandomState(5)
+    n = 40_000
+    text = bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8))
+    text = text[:7000] + b"N" + text[7001:19000] + b"NN" + text[19002:]
+    s = ReadStream.from_runs([("x", text)], device=DEV)
+    start = np.arange(100, n - 100, dtype=np.int64)
+    rows = Rows(np.zeros(len(start), dtype=np.int64), [f"r{i}" for i in range(len(start))], start, start + 1)
+    plan = kmer.Plan(rows, DEV)
+    assert plan.shuffle_ok
+    t = kmer.KmerTable.mini_with_slots(21, DEV, 20, 10).count(s, rows=plan, emit=(1, 8))
+    assert t._mini_plan[2] >= len(start) - 200                      # (about) one record per row
+    otab = oracle.Table(21, threads=2).count(text)
+    assert _same_items(t.items(), otab.items())
+    _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=1, vsize=8)
+    h = kmer.count_kmers(s, 21, kind="hash")
+    _, want = kmer.features(s, rows, k_tnf=None, table=h, window=1, vsize=8, seg_chars=32)
+    assert torch.equal(abd, want) and int(abd.sum()) > 30_000
+
+
+def test_mini_rows_that_cut_reads_and_lowercase():
+    """arbitrary row ranges (starting and ending inside reads, with gaps) and soft-masked bases: k-mers that are only valid under
+    jellyfish's rule are counted but belong to no row"""
+    rng = np.random.RandomState(11)
+    runs = []
+    for b in range(9):
+        seq = bytearray(rng.choice(list(b"ACGT"), size=rng.randint(2500, 6000)).astype(np.uint8).tobytes())
+        for _ in range(rng.randint(0, 6)):
+            a = rng.randint(0, len(seq)); e = min(len(seq), a + rng.randint(1, 80))
+            seq[a:e] = bytes(seq[a:e]).lower()
+        for _ in range(3):
+            seq[rng.randint(0, len(seq))] = ord("N")
+        runs.append((f"bc{b}", bytes(seq) + b"N"))
+    s = ReadStream.from_runs(runs, device=DEV)
+    text = b"".join(t for _, t in runs)
+    lenient = oracle.Table(21, threads=2).count(text.upper())
+    cuts = np.sort(rng.choice(np.arange(1, len(text) - 1), size=60, replace=False))
+    start, end = cuts[0::2].astype(np.int64), cuts[1::2].astype(np.int64)
+    rows = Rows(np.zeros(len(start), dtype=np.int64), [f"r{i}" for i in range(len(start))], start, end)
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.KmerTable.mini_with_slots(21, DEV, 19, 12).count(s, rows=plan, emit=(1, 64), lowercase_is_base=True)
+    assert _same_items(t.items(), lenient.items())
+    _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=1, vsize=64)
+    _, want = kmer.features(s, rows, k_tnf=None, table=t, window=1, vsize=64, seg_chars=32)       # the lookup kernel: strict by construction
+    assert torch.equal(abd, want) and int(abd.sum()) > 0
+    strict = kmer.KmerTable.mini_with_slots(21, DEV, 19, 12).count(s, rows=plan, emit=(1, 64))
+    assert _same_items(strict.items(), oracle.Table(21, threads=2).count(text).items())
+
+
+def test_mini_full_bucket_is_reported_and_count_kmers_regrows():
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=10, n_genomes=3, genome_len=60_000, fragment=8_000, seed=9)
+    s = synth.generate(cfg, device=DEV)
+    small = kmer.KmerTable.mini_with_slots(21, DEV, 12, 8)          # 4096 slots for ~200 k distinct 21-mers
+    with pytest.raises(_lib.PangaeaError):
+        small.count(s)
+    t = kmer.count_kmers(s, 21, kind="mini", distinct_hint=2000)
+    assert _same_items(t.items(), oracle.Table(21, threads=4).count(s.decode()).items())
+
+
+def test_mini_mid_scale_against_oracle():
+    """200 k pairs at the bench's geometry (2^15 buckets of 2^14 slots): the whole table and a spread of rows"""
+    cfg = synth.SynthConfig(n_pairs=200_000, n_barcodes=1000, n_genomes=8, genome_len=400_000, fragment=40_000, sub_rate=0.002, n_rate=0.01, seed=71)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.KmerTable.mini_with_slots(21, DEV, 29, 14).count(s, rows=plan, emit=(10, 400))
+    tnf, abd = kmer.features(s, plan, k_tnf=4, table=t, window=10, vsize=400)
+    text = s.decode()
+    otab = oracle.Table(21, threads=8).count(text)
+    assert _same_items(t.items(), otab.items())
+    for i in range(0, len(rows), max(1, len(rows) // 25)):
+        seq = text[int(rows.start[i]):int(rows.end[i])]
+        assert np.array_equal(tnf[i].cpu().numpy(), oracle.tnf_row(seq, 4))
+        assert np.array_equal(abd[i].cpu().numpy(), oracle.abd_row(seq, 21, otab, 10, 400))
