@@ -570,7 +570,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
-            if (i < r1) {
+            // (an all-ones word is a hole: a lookup pass that keeps its words in place marks dropped ones that way)
+            if (i < r1 && !(DIG == DIG_ROW && (uint32_t)rec[j] == 0xffffffffu)) {
                 const uint32_t d = digit_of(rec[j]);
                 dr[j] = (d << 16) | atomicAdd(&L.cnt()[d], 1u);
             }
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
 #pragma unroll
         for (int j = 0; j < REC_PER_LANE; ++j) {
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
-            if (i < r1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
+            if (i < r1 && !(DIG == DIG_ROW && (uint32_t)rec[j] == 0xffffffffu)) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
         }
 #pragma unroll
         for (int q = 0; q < DPL; ++q) {
@@ -2183,6 +2184,7 @@ int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffl
     out->vbits = sp.vbits;
     out->emit_off = sp.emit_off;
     out->words_e_off = sp.words_e_off;
+    out->words_a_off = sp.words_a_off;
     out->total = sp.total;
     return PG_OK;
 }

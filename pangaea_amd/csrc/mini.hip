@@ -23,6 +23,8 @@
 //   mini_count_kernel     B' + S1': one workgroup per bucket, 8-byte LDS slots (canonical code << 22 | count); the packed
 //                         slice is written once; then the counts become bins in place and the records are read again
 //                         (L2 / MALL) and looked up: (row, bin) words for the row shuffle of kernels.hip
+#include <type_traits>
+
 #include "pg_device.hpp"
 
 namespace {
@@ -165,7 +167,7 @@ __device__ __forceinline__ LaneWord load_lane_word(const uint64_t *__restrict__ 
 // ---- plan: records per bucket (hist) and, per chunk, records per first-pass region (chunk_hist[d * n_chunks + slot(chunk)])
 template <int W>
 __global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                              int64_t word_begin, int64_t word_end, int k, int bits, int bits2,
+                                                              int64_t word_begin, int64_t word_end, int k, int bits, int bits2, int cap,
                                                               const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
                                                               const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
                                                               unsigned long long *__restrict__ hist, unsigned long long *__restrict__ chunk_hist,
@@ -175,7 +177,6 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__
     const int nb = 1 << bits;
     uint32_t *coarse = lds + nb;                                    // [256]
     for (int i = threadIdx.x; i < nb; i += BIG_BLOCK) lds[i] = 0;
-    const int cap = 33 - k < MINI_MAX_LEN ? 33 - k : MINI_MAX_LEN;
     const int n_dig = 1 << (bits - bits2);
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         if (threadIdx.x < 256) coarse[threadIdx.x] = 0;
@@ -247,7 +248,7 @@ struct Scatter1Lds {
 
 template <int W>
 __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                                 int64_t word_begin, int64_t word_end, int k, int bits, int bits2,
+                                                                 int64_t word_begin, int64_t word_end, int k, int bits, int bits2, int cap,
                                                                  const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
                                                                  const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
                                                                  uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
@@ -257,7 +258,6 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
     Scatter1Lds &L = *reinterpret_cast<Scatter1Lds *>(lds_raw);
     const int n_dig = 1 << (bits - bits2);
     const uint32_t d2mask = (1u << bits2) - 1u;
-    const int cap = 33 - k < MINI_MAX_LEN ? 33 - k : MINI_MAX_LEN;
     const int64_t chunk = blockIdx.x;
     const int64_t slot = (int64_t)(((__int128)chunk * chunk_stride) % n_chunks);
     if (threadIdx.x < 256) L.cur[threadIdx.x] = (int)threadIdx.x < n_dig ? chunk_off[(int64_t)threadIdx.x * n_chunks + slot] : 0ull;
@@ -338,21 +338,24 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
 }
 
 // ---- A2': region -> buckets.  Region = blockIdx.x / tiles_x, its records are [off[region << bits2], off[(region + 1) << bits2]);
-// digit = the low bits2 bits of meta; bucket (region << bits2) + d starts at off[...] and fills through cursor[...].
+// digit = the low bits2 bits of meta (+ 128 for a LONG record: more than short_max k-mers).  Inside its bucket's range
+// [off[b], off[b + 1]) the short records fill from the front (cursor[b]) and the long ones from the back (cursor_l[b]): the
+// bucket workgroups treat a record in as many unrolled steps as its class can have k-mers, so sorting the two classes apart
+// saves them the steps that short records would leave idle.  cursor[b] is the number of short records afterwards.
 constexpr int S2_RPL = 16;
 constexpr int S2_TILE = BLOCK * S2_RPL;
 struct Scatter2Lds {
     uint64_t bases[S2_TILE];
     uint32_t meta[S2_TILE];
-    uint32_t cnt[128];
-    uint32_t start[129];
-    unsigned long long gbase[128];
+    uint32_t cnt[256];
+    uint32_t start[257];
+    unsigned long long gbase[256];
     uint32_t wave_tot[WAVES];
 };
 __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__restrict__ in_bases, const uint32_t *__restrict__ in_meta,
-                                                              const unsigned long long *__restrict__ off, int bits2, int tiles_x,
+                                                              const unsigned long long *__restrict__ off, int bits2, int tiles_x, int short_max,
                                                               uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
-                                                              unsigned long long *__restrict__ cursor)
+                                                              unsigned long long *__restrict__ cursor, unsigned long long *__restrict__ cursor_l)
 {
     __shared__ Scatter2Lds L;
     const int n_dig = 1 << bits2;
@@ -361,8 +364,12 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
     const int64_t b0 = region << bits2;
     const int64_t r0 = (int64_t)off[b0], r1 = (int64_t)off[b0 + n_dig];
     const int64_t n_tiles = (r1 - r0 + S2_TILE - 1) / S2_TILE;
+    auto digit_of = [&](uint32_t m) -> uint32_t {
+        const int n = (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1;
+        return (m & dmask) | (n > short_max ? 128u : 0u);
+    };
     for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
-        if (threadIdx.x < 128) L.cnt[threadIdx.x] = 0;
+        L.cnt[threadIdx.x] = 0;
         __syncthreads();
         const int64_t t0 = r0 + tile * S2_TILE;
         uint64_t rb[S2_RPL];
@@ -377,17 +384,22 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
         for (int j = 0; j < S2_RPL; ++j) {
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) {
-                const uint32_t d = rm[j] & dmask;
+                const uint32_t d = digit_of(rm[j]);
                 dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
             }
         }
         __syncthreads();
-        scan_digits<128>(L.cnt, L.start, L.wave_tot);
+        scan_digits<256>(L.cnt, L.start, L.wave_tot);
         // the returning cursor adds (one per digit and tile) are issued first and consumed after the placement
         unsigned long long gpos = 0;
-        if ((int)threadIdx.x < n_dig) {
-            const uint32_t c = L.start[threadIdx.x + 1] - L.start[threadIdx.x];
-            if (c) gpos = off[b0 + threadIdx.x] + atomicAdd(&cursor[b0 + threadIdx.x], (unsigned long long)c) - L.start[threadIdx.x];
+        {
+            const uint32_t d = threadIdx.x;
+            const uint32_t c = L.start[d + 1] - L.start[d];
+            if (c) {
+                const int64_t b = b0 + (d & 127u);
+                gpos = d < 128 ? off[b] + atomicAdd(&cursor[b], (unsigned long long)c) - L.start[d]
+                               : off[b + 1] - (atomicAdd(&cursor_l[b], (unsigned long long)c) + c) - L.start[d];
+            }
         }
 #pragma unroll
         for (int j = 0; j < S2_RPL; ++j) {
@@ -398,12 +410,12 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
                 L.meta[at] = rm[j];
             }
         }
-        if ((int)threadIdx.x < n_dig) L.gbase[threadIdx.x] = gpos;
+        L.gbase[threadIdx.x] = gpos;
         __syncthreads();
-        const uint32_t total = L.start[128];
+        const uint32_t total = L.start[256];
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {     // flat sweep: the digit is in the record
             const uint32_t m = L.meta[i];
-            const unsigned long long g = L.gbase[m & dmask] + i;
+            const unsigned long long g = L.gbase[digit_of(m)] + i;
             out_bases[g] = L.bases[i];
             out_meta[g] = m;
         }
@@ -412,71 +424,239 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
 }
 
 // ---- B' + S1': one workgroup per bucket
-__device__ __forceinline__ bool mini_insert(unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code, uint32_t s)
-{
-    unsigned long long cur = tab[s];
-    for (uint32_t i = 0; i < limit; ++i) {
-        if (cur == 0) {
-            cur = atomicCAS(&tab[s], 0ull, (unsigned long long)((code << HASH_CBITS) | 1ull));
-            if (cur == 0) return true;
-        }
-        if ((cur >> HASH_CBITS) == code) {
-            // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
-            if ((uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
-            return true;
-        }
-        s = (s + 1) & smask;
-        cur = tab[s];
-    }
-    return false;
-}
-
+//
+// Count pass.  A lane owns one record per batch and treats its (up to CAP) k-mers in straight-line, fully unrolled code: all
+// codes, all home slots and all first LDS probes of the record are issued before any is resolved (CAP independent LDS reads in
+// flight per lane; the slots beyond the record's length are predicated off).  What the first probe does not settle -- a k-mer
+// seen for the first time, a collision -- goes onto a small per-wavefront ring in LDS and is worked off 64 at a time by the
+// general probing loop, so that loop always runs with every lane busy.
+// Lookups.  An occurrence that lies in a row needs the FINAL count of its k-mer, which exists only when the bucket has been
+// counted.  SLOTS form (rows < 2^(32 - log2 bucket slots)): the count pass leaves a provisional word (row, slot index) per
+// occurrence -- it knows the slot when the insert is done -- and once the counts have become bins in place, the provisional
+// words are streamed back (they are fresh in L2 / MALL) and turned into (row, bin) words by ONE LDS read each: no second
+// derivation of the k-mers, no second probing.  General form: the records are read and probed a second time.
+constexpr int RING = 128;                                    // entries per wavefront ring: < 64 waiting + <= 64 pushed per step
+constexpr int COUNT_WAVES = BIG_BLOCK / 64;
 constexpr uint32_t BIN_NONE = (uint32_t)HASH_CMASK;          // a slot's count field after the counts have become bins: bin + 1, or this
 
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// the general insert; returns the slot the k-mer lives in, or 0xffffffff when the bucket is full (inactive lanes: 0).
+// Written as ONE wave-uniform loop with two short predicated regions per round (claim an empty slot / add to a match): the
+// structurizer's rendering of the obvious per-lane loop with early returns spends several times as many scalar
+// instructions on mask bookkeeping, and those -- not the LDS -- were the cost of this path.
+__device__ __forceinline__ uint32_t mini_insert_slow(unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code, bool act)
+{
+    uint32_t s = mini_slot_hash(code) & smask;
+    uint32_t res = act ? 0xffffffffu : 0u;
+    bool todo = act;
+    const unsigned long long fresh = (unsigned long long)((code << HASH_CBITS) | 1ull);
+    for (uint32_t i = 0; i < limit; ++i) {
+        if (!__any(todo)) break;
+        unsigned long long cur = tab[s];                        // (settled lanes read their last slot again: harmless)
+        if (todo && cur == 0) cur = atomicCAS(&tab[s], 0ull, fresh);
+        const bool claimed = todo && cur == 0;
+        const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
+        // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
+        if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
+        if (claimed || match) { res = s; todo = false; }
+        s = todo ? (s + 1) & smask : s;
+    }
+    return res;
+}
+
+// the general lookup: count field of `code` (BIN_NONE if absent)
+__device__ __forceinline__ uint32_t mini_lookup_slow(const unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code, bool act)
+{
+    uint32_t s = mini_slot_hash(code) & smask;
+    uint32_t res = BIN_NONE;
+    bool todo = act;
+    for (uint32_t q = 0; q < limit; ++q) {
+        if (!__any(todo)) break;
+        const unsigned long long cur = tab[s];
+        const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
+        if (match) res = (uint32_t)(cur & HASH_CMASK);
+        if (match || cur == 0) todo = false;
+        s = todo ? (s + 1) & smask : s;
+    }
+    return res;
+}
+
+#ifndef PG_SHORT_MAX
+#define PG_SHORT_MAX 4
+#endif
+constexpr int SHORT_MAX = PG_SHORT_MAX;                                 // a record with at most this many k-mers is "short"
+
+template <int CAP, bool SLOTS>
 __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
-                                                               const unsigned long long *__restrict__ off, MiniView t,
+                                                               const unsigned long long *__restrict__ off,
+                                                               const unsigned long long *__restrict__ n_short, MiniView t,
                                                                uint32_t window, uint32_t vsize, int vbits, uint32_t *__restrict__ words,
-                                                               unsigned long long *__restrict__ word_cursor, unsigned long long *__restrict__ wbeg,
-                                                               unsigned long long *__restrict__ emit_end, uint32_t *status)
+                                                               uint32_t *__restrict__ prov, unsigned long long *__restrict__ word_cursor,
+                                                               unsigned long long *__restrict__ wbeg, unsigned long long *__restrict__ emit_end,
+                                                               uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ uint32_t emitted;
     __shared__ unsigned long long n_lookups, wbase;
+    __shared__ unsigned long long wave_words[COUNT_WAVES];
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = n_slots < MAX_PROBE ? n_slots : MAX_PROBE;
-    const int k = t.k;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long *ring = tab + n_slots + wave * RING;                          // [RING] codes of this wavefront
+    uint32_t *ring_row = reinterpret_cast<uint32_t *>(tab + n_slots + COUNT_WAVES * RING) + wave * RING;
+    const int k = t.k, lb = t.log2_bucket;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const int rc_sh0 = 2 * (32 - k);
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    // [r0, rs) short records (at most SHORT_MAX k-mers; the second scatter pass put them first), [rs, r1) the others
+    const int64_t rs = n_short && CAP > SHORT_MAX ? r0 + (int64_t)n_short[blockIdx.x] : r0;
+    const bool emit_slots = SLOTS && window != 0;
+#ifdef PG_MINI_STAMPS
+    unsigned long long *dbg = word_cursor + 7;                   // header[8..]: phase cycle sums (diagnostic build only)
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#define PG_STAMP(K) do { __syncthreads(); if (threadIdx.x == 0) atomicAdd(&dbg[K], (unsigned long long)(__builtin_amdgcn_s_memtime() - st0)); } while (0)
+#else
+#define PG_STAMP(K) do { } while (0)
+#endif
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = 0ull;
     if (threadIdx.x == 0) { emitted = 0; n_lookups = 0; }
-    __syncthreads();
-    bool full = false;
-    unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
-    for (int64_t i0 = r0; i0 < r1; i0 += BIG_BLOCK) {            // ---- count
-        const int64_t i = i0 + threadIdx.x;
-        const bool live = i < r1;
-        const uint64_t R = live ? bases[i] : 0ull;
-        const uint32_t m = live ? meta[i] : 0u;
-        const int n = live ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
-        if (live && (m >> META_ROW_SHIFT) != MINI_ROW_NONE) mine += (unsigned long long)n;
-        const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
-        for (int j = 0; j < MINI_MAX_LEN; ++j) {
-            if (!__any(j < n)) break;
-            if (j < n) {
-                const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
-                const uint64_t code = fw < rc ? fw : rc;
-                full |= !mini_insert(tab, smask, limit, code, mini_slot_hash(code) & smask);
+    if (emit_slots) {
+        // every occurrence that lies in a row leaves exactly one word, and a wavefront knows its records in advance (batches
+        // w, w + 16, ... of either class): the bucket's word range and every wavefront's part of it are fixed before the first
+        // word is written, so words are placed with a wave-local running position -- no counter in LDS, no returning atomic
+        unsigned long long mine = 0;
+        auto tally = [&](int64_t ra, int64_t rb) {
+            for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += 4 * BIG_BLOCK) {
+                uint32_t m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = i0 + u * BIG_BLOCK + lane;
+                    m[u] = i < rb ? meta[i] : 0xffffffffu;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((m[u] >> META_ROW_SHIFT) != MINI_ROW_NONE) mine += ((m[u] >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1;
             }
-        }
-    }
-    if (full) atomicOr(status, 1u);
-    if (window) {
+        };
+        tally(r0, rs);
+        tally(rs, r1);
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
-        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_lookups, mine);
+        if (lane == 0) wave_words[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long run = 0;
+            for (int w = 0; w < COUNT_WAVES; ++w) { const unsigned long long v = wave_words[w]; wave_words[w] = run; run += v; }
+            n_lookups = run;
+            wbase = atomicAdd(word_cursor, run);
+            wbeg[blockIdx.x] = wbase;
+        }
+    }
+    __syncthreads();
+    unsigned long long wb = emit_slots ? wbase : 0ull;
+    uint32_t *const prov_b = prov + wb;                          // the bucket's words (32-bit positions from here on)
+    uint32_t wpos = emit_slots ? (uint32_t)wave_words[wave] : 0u;  // this wavefront's next word (wave-uniform)
+    PG_STAMP(0);
+    bool full = false;
+    unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
+    uint32_t head = 0, tail = 0;                                 // ring positions (wave-uniform)
+    // one pending occurrence per lane off the ring: the general insert, and its word
+    auto slow_round = [&](bool act) {
+        const uint32_t at = (head + lane) & (RING - 1);
+        const uint64_t c = act ? ring[at] : 0ull;
+        const uint32_t rw = act && emit_slots ? ring_row[at] : MINI_ROW_NONE;
+        const uint32_t sl = mini_insert_slow(tab, smask, limit, c, act);
+        full |= act && sl == 0xffffffffu;
+        if (emit_slots) {
+            // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
+            const bool put = rw != MINI_ROW_NONE;
+            const unsigned long long qm = __ballot(put);
+            if (put) prov_b[wpos + lanes_below(qm)] = (rw << lb) | (sl & smask);
+            wpos += (uint32_t)__popcll(qm);
+        }
+    };
+    // ---- count: wavefront w takes the batches [ra + 64 (w + 16 t), + 64) of a class; CX = k-mers per record at most there
+    auto count_range = [&](auto cx, int64_t ra, int64_t rb) {
+        constexpr int CX = decltype(cx)::value;
+        int64_t i = ra + (int64_t)wave * 64 + lane;
+        uint64_t R = i < rb ? bases[i] : 0ull;
+        uint32_t m = i < rb ? meta[i] : 0xffffffffu;
+        for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BIG_BLOCK) {
+            const bool live = i0 + lane < rb;
+            const int n = live ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
+            const uint32_t row = m >> META_ROW_SHIFT;
+            const bool in_row = live && row != MINI_ROW_NONE;
+            if (in_row) mine += (unsigned long long)n;
+            const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
+            i = i0 + BIG_BLOCK + lane;                           // the next batch's loads fly during this one
+            R = i < rb ? bases[i] : 0ull;
+            m = i < rb ? meta[i] : 0xffffffffu;
+            uint64_t code[CX];
+            uint32_t sl[CX];
+            unsigned long long cur[CX];
+#pragma unroll
+            for (int j = 0; j < CX; ++j) {                       // every first probe of the record in flight
+                const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
+                code[j] = fw < rc ? fw : rc;
+                sl[j] = mini_slot_hash(code[j]) & smask;
+                cur[j] = j < n ? tab[sl[j]] : 0ull;
+            }
+            uint32_t hits = 0;                                   // bit j: settled by the first probe
+#pragma unroll
+            for (int j = 0; j < CX; ++j) {
+                const bool hit = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j];
+                if (hit && (uint32_t)(cur[j] & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[sl[j]], 1ull);
+                if (hit) hits |= 1u << j;
+            }
+            if (emit_slots) {
+                // provisional words of the hits, slot by slot (neighbours in the buffer come from different records: the row
+                // histograms behind the shuffle do not like runs of equal words)
+#pragma unroll
+                for (int j = 0; j < CX; ++j) {
+                    const bool put = in_row && ((hits >> j) & 1u);
+                    const unsigned long long pm = __ballot(put);
+                    if (put) prov_b[wpos + lanes_below(pm)] = (row << lb) | sl[j];
+                    wpos += (uint32_t)__popcll(pm);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CX; ++j) {
+                const bool pend = j < n && !((hits >> j) & 1u);
+                const unsigned long long mask = __ballot(pend);
+                if (mask) {                                      // (uniform)
+                    if (pend) {
+                        const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
+                        ring[at] = code[j];
+                        if (emit_slots) ring_row[at] = row;
+                    }
+                    tail += (uint32_t)__popcll(mask);
+                    if (tail - head >= 64) {
+                        slow_round(true);
+                        head += 64;
+                    }
+                }
+            }
+        }
+    };
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? SHORT_MAX : CAP)>{}, r0, rs);
+    count_range(std::integral_constant<int, CAP>{}, rs, r1);
+    if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
+#ifdef PG_MINI_STAMPS
+    if (lane == 0) atomicAdd(&dbg[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - st0));     // per-wave end of the count loop
+#endif
+    PG_STAMP(1);
+    if (full) atomicOr(status, 1u);
+    if (window && !emit_slots) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+        if (lane == 0 && mine) atomicAdd(&n_lookups, mine);
     }
     __syncthreads();
     // the packed slice (an empty table needs no clearing: every slot is written); then counts -> bins, in place
@@ -490,46 +670,122 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             tab[i] = (v & ~(unsigned long long)HASH_CMASK) | (bin < vsize ? bin + 1u : BIN_NONE);
         }
     }
+    PG_STAMP(2);
     if (!window) return;
-    // this bucket's words go to a range of the word buffer claimed with one global add (an upper bound: every k-mer inside a row)
-    if (threadIdx.x == 0) {
+    // (general form) this bucket's words go to a range of the word buffer claimed with one global add: an upper bound, every
+    // k-mer inside a row
+    if (!emit_slots && threadIdx.x == 0) {
         wbase = atomicAdd(word_cursor, n_lookups);
         wbeg[blockIdx.x] = wbase;
     }
     __syncthreads();
-    const unsigned long long wb = wbase;
-    const uint32_t lane = threadIdx.x & 63;
-    for (int64_t i0 = r0; i0 < r1; i0 += BIG_BLOCK) {            // ---- lookups of the same records
-        const int64_t i = i0 + threadIdx.x;
-        const bool live = i < r1;
-        const uint64_t R = live ? bases[i] : 0ull;
-        const uint32_t m = live ? meta[i] : 0xffffffffu;
-        const uint32_t row = m >> META_ROW_SHIFT;
-        const int n = live && row != MINI_ROW_NONE ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
-        const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
-        for (int j = 0; j < MINI_MAX_LEN; ++j) {
-            if (!__any(j < n)) break;
-            uint32_t bin1 = BIN_NONE;
-            if (j < n) {
+    wb = wbase;
+    if (emit_slots) {
+        // ---- provisional (row, slot) words -> (row, bin) words: a stream with one LDS read per word.  A word whose bin is out
+        // of range becomes a hole (all ones) that the row shuffle skips: positions stay, nothing is compacted.
+        const uint32_t np = (uint32_t)n_lookups;
+        uint32_t *const words_b = words + wb;
+        for (uint32_t i0 = 0; i0 < np; i0 += 8 * BIG_BLOCK) {
+            uint32_t w[8], b1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * BIG_BLOCK + threadIdx.x;
+                w[u] = i < np ? prov_b[i] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) b1[u] = (uint32_t)(tab[w[u] & smask] & HASH_CMASK);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * BIG_BLOCK + threadIdx.x;
+                // (a slot that was never filled -- a full bucket -- reads as count 0: a hole too)
+                if (i < np) words_b[i] = b1[u] != BIN_NONE && b1[u] != 0 ? ((w[u] >> lb) << vbits) | (b1[u] - 1u) : 0xffffffffu;
+            }
+        }
+        if (threadIdx.x == 0) emit_end[blockIdx.x] = wb + np;
+        PG_STAMP(3);
+        return;
+    }
+    // ---- general form: the records are read and probed a second time
+    // (row, bin) words of 64 lanes -> the bucket's word range: one LDS add per call, the stores are contiguous
+    auto emit = [&](bool put, uint32_t row, uint32_t bin1) {
+        const unsigned long long pm = __ballot(put);
+        if (pm) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&emitted, (uint32_t)__popcll(pm));
+            at = __shfl(at, 0);
+            if (put) words[wb + at + lanes_below(pm)] = (row << vbits) | (bin1 - 1u);
+        }
+    };
+    {
+        head = tail = 0;
+        int64_t i = r0 + (int64_t)wave * 64 + lane;
+        uint64_t R = i < r1 ? bases[i] : 0ull;
+        uint32_t m = i < r1 ? meta[i] : 0xffffffffu;
+        for (int64_t i0 = r0 + (int64_t)wave * 64; i0 < r1; i0 += BIG_BLOCK) {
+            const bool live = i0 + lane < r1;
+            const uint32_t row = m >> META_ROW_SHIFT;
+            const int n = live && row != MINI_ROW_NONE ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
+            const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
+            i = i0 + BIG_BLOCK + lane;
+            R = i < r1 ? bases[i] : 0ull;
+            m = i < r1 ? meta[i] : 0xffffffffu;
+            uint64_t code[CAP];
+            unsigned long long cur[CAP];
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) {
                 const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
-                const uint64_t code = fw < rc ? fw : rc;
-                uint32_t s = mini_slot_hash(code) & smask;
-                unsigned long long cur = tab[s];
-                for (uint32_t q = 0; q < limit && cur != 0; ++q) {
-                    if ((cur >> HASH_CBITS) == code) { bin1 = (uint32_t)(cur & HASH_CMASK); break; }
-                    s = (s + 1) & smask;
-                    cur = tab[s];
+                code[j] = fw < rc ? fw : rc;
+                cur[j] = j < n ? tab[mini_slot_hash(code[j]) & smask] : 0ull;
+            }
+            // settled by the first probe: a hit (emit, unless its bin is out of range) or an empty slot (cannot happen for a
+            // counted k-mer; nothing to emit).  Slot by slot, ONE add on the bucket's counter per batch.
+            unsigned long long pm[CAP];
+            uint32_t total = 0;
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) {
+                const bool hit = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j];
+                pm[j] = __ballot(hit && (uint32_t)(cur[j] & HASH_CMASK) != BIN_NONE);
+                total += (uint32_t)__popcll(pm[j]);
+            }
+            if (total) {                                         // (uniform)
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&emitted, total);
+                at = __shfl(at, 0);
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) {
+                    if ((pm[j] >> lane) & 1ull) words[wb + at + lanes_below(pm[j])] = (row << vbits) | ((uint32_t)(cur[j] & HASH_CMASK) - 1u);
+                    at += (uint32_t)__popcll(pm[j]);
                 }
             }
-            const bool put = bin1 != BIN_NONE;
-            const unsigned long long mask = __ballot(put);
-            if (mask) {
-                const int leader = __ffsll((long long)mask) - 1;
-                uint32_t at = 0;
-                if ((int)lane == leader) at = atomicAdd(&emitted, (uint32_t)__popcll(mask));
-                at = __shfl(at, leader);
-                if (put) words[wb + at + __popcll(mask & ((1ull << lane) - 1ull))] = (row << vbits) | (bin1 - 1u);
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) {                      // collisions: onto the ring
+                const bool pend = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) != code[j];
+                const unsigned long long mask = __ballot(pend);
+                if (mask) {
+                    if (pend) {
+                        const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
+                        ring[at] = code[j];
+                        ring_row[at] = row;
+                    }
+                    tail += (uint32_t)__popcll(mask);
+                    if (tail - head >= 64) {
+                        const uint32_t at = (head + lane) & (RING - 1);
+                        const uint64_t c = ring[at];
+                        const uint32_t rw = ring_row[at];
+                        head += 64;
+                        const uint32_t b1 = mini_lookup_slow(tab, smask, limit, c, true);
+                        emit(b1 != BIN_NONE, rw, b1);
+                    }
+                }
             }
+        }
+        if (tail != head) {
+            const bool act = lane < tail - head;
+            const uint32_t at = (head + lane) & (RING - 1);
+            const uint64_t c = act ? ring[at] : 0ull;
+            const uint32_t rw = act ? ring_row[at] : 0u;
+            const uint32_t b1 = mini_lookup_slow(tab, smask, limit, c, act);
+            emit(b1 != BIN_NONE, rw, b1);
         }
     }
     __syncthreads();
@@ -540,8 +796,19 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
 struct MiniPlan {
     int bits, bits1, bits2;
     int64_t n_rounds, n_chunks, chunk_stride;
-    size_t header_off, hist_off, off_off, cur2_off, wbeg_off, round_off, chunk_off, total;
+    size_t header_off, hist_off, off_off, cur2_off, cur2l_off, wbeg_off, round_off, chunk_off, total;
 };
+
+// k-mers per record at most: what fits the 32 characters of a record, the 4-bit length field -- and what the bucket
+// workgroups want: they treat every record in `cap` unrolled, predicated steps, so short records waste fewer of them when the
+// cap is low, while a low cap makes more records (12 bytes each).  PG_MINI_CAP overrides (tuning).
+int mini_cap(int k)
+{
+    int cap = 33 - k < MINI_MAX_LEN ? 33 - k : MINI_MAX_LEN;
+    static const int forced = getenv("PG_MINI_CAP") ? atoi(getenv("PG_MINI_CAP")) : 0;
+    if (forced >= 1 && forced < cap) cap = forced;
+    return cap;
+}
 
 int check_mini(const pg_table *t, const char *who)
 {
@@ -575,6 +842,7 @@ int plan_mini(const pg_table *t, int64_t n_words, MiniPlan *p)
     p->hist_off = take(nb * 8);
     p->off_off = take((nb + 1) * 8);
     p->cur2_off = take(nb * 8);
+    p->cur2l_off = take(nb * 8);
     p->wbeg_off = take(nb * 8);
     p->round_off = take((size_t)(p->n_rounds + 1) * 4);
     p->chunk_off = take(((size_t)p->n_chunks << p->bits1) * 8);
@@ -669,7 +937,7 @@ extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_
         const int grid = (int)(p.n_chunks < 512 ? p.n_chunks : 512);
         PG_MINI_DISPATCH_W(t->k - PG_MINI_M + 1,
             if ((rc = raise_lds_limit((const void *)mini_plan_kernel<W>, lds, "pg_mini_plan"))) return rc;
-            hipLaunchKernelGGL(mini_plan_kernel<W>, dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, p.bits, p.bits2,
+            hipLaunchKernelGGL(mini_plan_kernel<W>, dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, p.bits, p.bits2, mini_cap(t->k),
                                with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
                                with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
                                (const int32_t *)round_row, hist, chunk_tab, p.n_chunks, p.chunk_stride))
@@ -709,6 +977,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     auto *header = (unsigned long long *)(ws + p.header_off);
     auto *off = (unsigned long long *)(ws + p.off_off);
     auto *cur2 = (unsigned long long *)(ws + p.cur2_off);
+    auto *cur2l = (unsigned long long *)(ws + p.cur2l_off);
     auto *wbeg = (unsigned long long *)(ws + p.wbeg_off);
     auto *round_row = (int32_t *)(ws + p.round_off);
     auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
@@ -719,34 +988,64 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     auto *bases_b = bases_a + cap;
     auto *meta_a = (uint32_t *)(bases_b + cap);
     auto *meta_b = meta_a + cap;
-    if (hipMemsetAsync(cur2, 0, (size_t)nb * 8, s) != hipSuccess || hipMemsetAsync(header + 1, 0, 8, s) != hipSuccess)
+    if (hipMemsetAsync(cur2, 0, p.wbeg_off - p.cur2_off, s) != hipSuccess || hipMemsetAsync(header + 1, 0, 8, s) != hipSuccess)
         return pg_fail(PG_EHIP, "pg_mini_count: memset failed");
-    pg_shuffle_layout sl{0, 0, 0, 0};
+    pg_shuffle_layout sl{0, 0, 0, 0, 0};
     if (window > 0) {
         if ((rc = pg_internal_shuffle_layout((word_end - word_begin) * 32, rows->n_rows, vsize, &sl))) return rc;
         if ((int64_t)sl.total > shuffle_ws_bytes || (reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0)
             return pg_fail(PG_EINVAL, "pg_mini_count: shuffle workspace of %lld bytes (256-byte aligned), %lld needed", (long long)shuffle_ws_bytes, (long long)sl.total);
     }
-    const size_t slice_lds = (size_t)8 << t->log2_bucket_slots;
+    const size_t slice_lds = ((size_t)8 << t->log2_bucket_slots) + (size_t)COUNT_WAVES * RING * 12;      // table + the wavefronts' rings
     if (word_end > word_begin) {
         const size_t lds1 = sizeof(Scatter1Lds);
         PG_MINI_DISPATCH_W(t->k - PG_MINI_M + 1,
             if ((rc = raise_lds_limit((const void *)mini_scatter_kernel<W>, lds1, "pg_mini_count"))) return rc;
             hipLaunchKernelGGL(mini_scatter_kernel<W>, dim3((unsigned)p.n_chunks), dim3(S1_BLOCK), lds1, s, codes, valid, word_begin, word_end, t->k, p.bits,
-                               p.bits2, with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
+                               p.bits2, mini_cap(t->k), with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
                                with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
                                (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride))
         if (p.bits2) {
             const int tiles_x = 96;
             hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
-                               (const unsigned long long *)off, p.bits2, tiles_x, bases_b, meta_b, cur2);
+                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l);
         }
     }
-    if ((rc = raise_lds_limit((const void *)mini_count_kernel, slice_lds, "pg_mini_count"))) return rc;
-    hipLaunchKernelGGL(mini_count_kernel, dim3(nb), dim3(BIG_BLOCK), slice_lds, s, (const uint64_t *)(p.bits2 ? bases_b : bases_a),
-                       (const uint32_t *)(p.bits2 ? meta_b : meta_a), (const unsigned long long *)off, mini_view(t), (uint32_t)window, (uint32_t)vsize,
-                       sl.vbits, window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr, header + 1, wbeg,
-                       window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr, status);
+    // the SLOTS form of the lookups needs a row and a slot index in one 32-bit word
+    const bool slots_form = window > 0 && rows->n_rows < ((int64_t)1 << (32 - t->log2_bucket_slots)) - 1 && !getenv("PG_MINI_PROBE_TWICE");
+    // (the classes are sorted apart by the second scatter pass: without it -- at most 256 buckets -- every record counts as long)
+    const unsigned long long *n_short = p.bits2 && mini_cap(t->k) > SHORT_MAX ? (const unsigned long long *)cur2 : (const unsigned long long *)nullptr;
+    uint32_t *words_e = window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr;
+    uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
+    unsigned long long *emit_end = window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
+#define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \
+    do {                                                                                                                    \
+        if (slots_form) {                                                                                                   \
+            if ((rc = raise_lds_limit((const void *)mini_count_kernel<CAP_, true>, slice_lds, "pg_mini_count"))) return rc;   \
+            hipLaunchKernelGGL((mini_count_kernel<CAP_, true>), dim3(nb), dim3(BIG_BLOCK), slice_lds, s,                    \
+                               (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a), \
+                               (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,    \
+                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, status);                             \
+        } else {                                                                                                            \
+            if ((rc = raise_lds_limit((const void *)mini_count_kernel<CAP_, false>, slice_lds, "pg_mini_count"))) return rc;  \
+            hipLaunchKernelGGL((mini_count_kernel<CAP_, false>), dim3(nb), dim3(BIG_BLOCK), slice_lds, s,                   \
+                               (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a), \
+                               (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,    \
+                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, status);                             \
+        }                                                                                                                   \
+    } while (0)
+    switch (mini_cap(t->k)) {                                          // k-mers per record at most (as the first pass cuts them)
+    case 1: case 2: case 3: case 4: PG_MINI_LAUNCH_COUNT(4); break;
+    case 5: case 6: PG_MINI_LAUNCH_COUNT(6); break;
+    case 7: case 8: PG_MINI_LAUNCH_COUNT(8); break;
+    case 9: case 10: PG_MINI_LAUNCH_COUNT(10); break;
+    case 11: case 12: PG_MINI_LAUNCH_COUNT(12); break;
+    case 13: PG_MINI_LAUNCH_COUNT(13); break;
+    case 14: PG_MINI_LAUNCH_COUNT(14); break;
+    case 15: PG_MINI_LAUNCH_COUNT(15); break;
+    default: PG_MINI_LAUNCH_COUNT(16); break;
+    }
+#undef PG_MINI_LAUNCH_COUNT
     return check_launch("pg_mini_count");
 }
 

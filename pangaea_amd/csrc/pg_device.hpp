@@ -170,7 +170,9 @@ __attribute__((unused)) int grid_for(int64_t items, int block = BLOCK)
 int raise_lds_limit(const void *kernel, size_t bytes, const char *who)
 {
     if (bytes <= 64 * 1024) return PG_OK;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+    // (the CU has 160 KiB; kernels here keep a few hundred bytes of static LDS besides)
+    const int want = bytes <= 144 * 1024 ? 144 * 1024 : (int)bytes;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
         return pg_fail(PG_EHIP, "%s: cannot raise the dynamic LDS limit", who);
     return PG_OK;
 }

@@ -67,6 +67,24 @@ def test_mini_table_and_rows_against_oracle(k, log2_slots, log2_bucket, window, 
     assert torch.equal(abd2, abd) and _same_items(t.items(), otab.items())
 
 
+@pytest.mark.parametrize("k,log2_slots,log2_bucket", [(21, 22, 10), (18, 19, 14)])
+def test_mini_general_lookup_form(k, log2_slots, log2_bucket, monkeypatch):
+    """the lookups' general form (records read and probed a second time: what row sets too large for the (row, slot) words
+    take) gives the same rows as the slot form"""
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=37, n_genomes=3, genome_len=30_000, fragment=8_000, sub_rate=0.01, n_rate=0.2, seed=600 + k)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.KmerTable.mini_with_slots(k, DEV, log2_slots, log2_bucket).count(s, rows=plan, emit=(3, 200))
+    _, want = kmer.features(s, plan, k_tnf=None, table=t, window=3, vsize=200)
+    monkeypatch.setenv("PG_MINI_PROBE_TWICE", "1")
+    u = kmer.KmerTable.mini_with_slots(k, DEV, log2_slots, log2_bucket).count(s, rows=plan, emit=(3, 200))
+    _, got = kmer.features(s, plan, k_tnf=None, table=u, window=3, vsize=200)
+    assert torch.equal(got, want) and _same_items(t.items(), u.items())
+    _, _, oabd = _oracle(s, rows, k, 3, 200)
+    assert np.array_equal(got.cpu().numpy(), oabd)
+
+
 def test_mini_table_only_and_from_items():
     cfg = synth.SynthConfig(n_pairs=1500, n_barcodes=11, n_genomes=2, genome_len=20_000, fragment=5_000, sub_rate=0.02, n_rate=0.3, seed=77)
     s = synth.generate(cfg, device=DEV)

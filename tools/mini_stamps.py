@@ -1,0 +1,14 @@
+import sys, torch
+sys.path.insert(0, '.')
+from pangaea_amd import kmer, synth
+dev = 'cuda:0'
+cfg = synth.SynthConfig(n_pairs=10_000_000, n_barcodes=50_000, seed=2022)
+s = synth.generate(cfg, device=dev, chunk_pairs=1 << 17, with_names=False)
+rows = s.rows(2000); plan = kmer.Plan(rows, dev)
+t = kmer.KmerTable.mini_with_slots(21, dev, 29, 14)
+for it in range(2):
+    t.reset(); t.count(s, rows=plan, emit=(10, 400), check=False)
+    torch.cuda.synchronize()
+    h = t._mini_plan[1][:256].view(torch.int64).cpu().numpy()
+    print('records', h[0], 'words', h[1], 'phase cycle sums (per WG avg, cycles at 100MHz?):', [int(x) // 32768 for x in h[8:12]], 'wave-end avg', int(h[13]) // (32768 * 16), 'laps per wave (reads, atomics, prov, ring+slow):', [int(x) // (32768 * 16) for x in h[16:20]])
+    t._mini_plan[1][64:256].zero_()
