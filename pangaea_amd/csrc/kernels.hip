@@ -1504,9 +1504,19 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const uint32_t *__r
             const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
             e[j] = i < b ? words[i] : 0xffffffffu;
         }
+        // equal words in neighbouring lanes are added once: consecutive k-mers of a read share their row and, mostly, their bin,
+        // and a lookup pass that works on super-k-mers leaves them next to each other -- as single adds they would queue up on
+        // one LDS address
+        const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (e[j] != 0xffffffffu) atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e[j] & bmask)], 1u);
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t prev = __shfl_up(e[j], 1);
+            const bool head = lane == 0 || e[j] != prev;
+            const unsigned long long hm = __ballot(head);
+            const unsigned long long above = lane == 63 ? 0ull : hm >> (lane + 1);
+            const uint32_t run = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+            if (head && e[j] != 0xffffffffu) atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e[j] & bmask)], run);
+        }
     }
     __syncthreads();
     int32_t *dst = abd_out + row0 * (int64_t)vsize;
