@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
         "orc_table_new": (vp, [C.c_int, C.c_int]),
         "orc_table_free": (None, [vp]),
         "orc_table_count_seq": (C.c_int, [vp, vp, i64, C.c_int]),
+        "orc_table_count_known": (C.c_int, [vp, vp, i64, C.c_int]),
         "orc_table_size": (i64, [vp]),
         "orc_table_get": (C.c_uint64, [vp, C.c_uint64, C.POINTER(C.c_int)]),
         "orc_table_export": (None, [vp, vp, vp]),
@@ -202,6 +203,27 @@ class Table:
         if self._L.orc_table_count_seq(self._h, ptr, n, int(lowercase_is_base)):
             raise MemoryError("oracle: table growth failed")
         return self
+
+    def count_known(self, seq: bytes | np.ndarray, lowercase_is_base: bool = False) -> "Table":
+        """add the occurrences in ``seq`` of the k-mers that are keys already; no key is created.  ``zeroed_keys_of`` + this =
+        exact global multiplicities of a chosen few k-mers over a text too large to count whole"""
+        if isinstance(seq, np.ndarray):
+            ptr, n = seq.ctypes.data, seq.size
+        else:
+            buf = C.create_string_buffer(seq, len(seq))
+            ptr, n = C.addressof(buf), len(seq)
+        self._L.orc_table_count_known(self._h, ptr, n, int(lowercase_is_base))
+        return self
+
+    @classmethod
+    def zeroed_keys_of(cls, k: int, seqs, threads: int = 1) -> "Table":
+        """table whose keys are the canonical k-mers of the given texts, all with count 0"""
+        t = cls(k, threads)
+        for q in seqs:
+            t.count(q)
+        for key in t.items()[0]:
+            t.set(int(key), 0)
+        return t
 
     def __len__(self) -> int:
         return int(self._L.orc_table_size(self._h))

@@ -571,6 +571,38 @@ int orc_table_count_seq(orc_table *T, const char *seq, int64_t n, int lowercase_
     return fail ? -1 : 0;
 }
 
+/* the same scan, but only k-mers that are ALREADY keys of the table are counted (nothing is created): with the keys of a few
+ * rows set to 0 beforehand this gives their exact global multiplicities over a text far too large to count whole --
+ * how the full-size tests check abundance rows against the reference's definition (count_kmer.cpp:86-96) */
+int orc_table_count_known(orc_table *T, const char *seq, int64_t n, int lowercase_is_base)
+{
+#pragma omp parallel num_threads(T->nsub)
+    {
+#ifdef _OPENMP
+        int me = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int me = 0, nt = 1;
+#endif
+        for (int s = me; s < T->nsub; s += nt) {
+            roll_t r;
+            roll_init(&r, T->k);
+            uint64_t canon;
+            for (int64_t i = 0; i < n; ++i) {
+                unsigned char c = (unsigned char)seq[i];
+                if (lowercase_is_base && c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+                if (roll_feed(&r, c, &canon)) {
+                    uint64_t h = mix64(canon);
+                    if (sub_of(T, h) == s) {
+                        uint64_t *v = sub_slot(&T->sub[s], canon + 1, h, 0);
+                        if (v) ++*v;
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 int64_t orc_table_size(const orc_table *T)
 {
     int64_t n = 0;

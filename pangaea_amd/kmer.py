@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -670,6 +671,10 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
     """build the table of one stream; a full hash table is re-built with four times the slots.  ``emit`` = (window,
     vector_size) fuses the lookup pass of the abundance rows into the count where that applies (``KmerTable.count``)."""
     resolved = kind or KmerTable.default_kind(k)
+    auto_mini = (kind is None and resolved == "hash" and rows is not None and emit is not None and rows.shuffle_ok
+                 and rows.n_rows <= _lib.MINI_MAX_ROWS and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1
+                 and emit[0] * emit[1] <= _lib.HASH_COUNT_SAT and _lib.MINI_MIN_K <= k <= _lib.HASH_MAX_K
+                 and os.environ.get("PANGAEA_NO_MINI", "0") in ("", "0"))
     if distinct_hint is None and resolved != "dense":
         # size from a HyperLogLog pass (as cheap as the bucket histogram) instead of guessing the coverage; +10 % covers
         # the estimator's error, load 0.4 leaves room for per-bucket variance
@@ -677,6 +682,12 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
         load = 0.4
     else:
         load = 0.5
+    if auto_mini and log2_bucket is None:
+        # one GPU, rows and abundance parameters known: the super-k-mer pipeline (table by minimizer buckets) where its geometry
+        # (at most 2^15 buckets of 2^14 slots) holds the table
+        want = max(1024, int(distinct_hint / load))
+        if KmerTable.mini_applies(k, max(10, math.ceil(math.log2(want)))):
+            kind = "mini"
     table = KmerTable.alloc(k, stream.device, kind, distinct_hint, load=load, log2_bucket=log2_bucket)
     while True:
         try:

@@ -51,6 +51,8 @@ class SynthConfig:
     unbarcoded: float = 0.02
     seed: int = 2021
     first_pair: int = 0          # global index of this shard's first pair (multi-GPU shards of one data set)
+    poisson_mean: float = 0.0    # > 0: pairs per barcode ~ Poisson(mean) (at least 1) instead of a fixed number -- the long reads of
+                                 # the hybrid mode, whose names serve as barcodes (assign_barcodes.cpp:156); n_barcodes then follows
 
     @property
     def chars_per_pair(self) -> int:
@@ -65,6 +67,28 @@ class SynthConfig:
         return max(1, self.n_barcoded_pairs // self.n_barcodes)
 
 
+_BOUNDS_CACHE: dict = {}
+
+
+def barcode_bounds(cfg: SynthConfig) -> np.ndarray | None:
+    """Poisson mode: cumulative pair counts [n_barcodes + 1] of the barcoded pairs (None in the fixed-size mode)"""
+    if cfg.poisson_mean <= 0:
+        return None
+    if cfg.first_pair:
+        raise ValueError("Poisson barcode sizes are for single-shard data sets")
+    key = (cfg.seed, cfg.poisson_mean, cfg.n_barcoded_pairs)
+    if key not in _BOUNDS_CACHE:
+        rs = np.random.RandomState(cfg.seed + 7)
+        target = cfg.n_barcoded_pairs
+        sizes = np.maximum(1, rs.poisson(cfg.poisson_mean, size=int(target / cfg.poisson_mean * 1.3) + 64)).astype(np.int64)
+        cum = np.concatenate([[0], np.cumsum(sizes)])
+        n = int(np.searchsorted(cum, target, side="left"))
+        cum = cum[:n + 1].copy()
+        cum[-1] = target
+        _BOUNDS_CACHE[key] = cum
+    return _BOUNDS_CACHE[key]
+
+
 def barcode_name(cfg: SynthConfig, b: int) -> str:
     h = int(_mix(torch.tensor([cfg.seed * 7919 + 13 * b + 5], dtype=torch.int64))[0]) & ((1 << 64) - 1)
     return "".join("ACGT"[(h >> (2 * i)) & 3] for i in range(16)) + f"{b:07d}"
@@ -76,8 +100,14 @@ def _chunk_chars(cfg: SynthConfig, p0: int, p1: int, device) -> tuple[torch.Tens
     P = cfg.pairs_per_barcode
     p = torch.arange(p0, p1, dtype=torch.int64, device=device) + cfg.first_pair
     local = torch.arange(p0, p1, dtype=torch.int64, device=device)
-    barcoded = local < (P * cfg.n_barcodes)
-    bc = torch.where(barcoded, p // P, -1 - p)       # unbarcoded pairs behave as their own one-pair barcodes
+    bounds = barcode_bounds(cfg)
+    if bounds is None:
+        barcoded = local < (P * cfg.n_barcodes)
+        bc = torch.where(barcoded, p // P, -1 - p)       # unbarcoded pairs behave as their own one-pair barcodes
+    else:
+        barcoded = local < int(bounds[-1])
+        which = torch.searchsorted(torch.from_numpy(bounds[1:]).to(device), local, right=True)
+        bc = torch.where(barcoded, which, -1 - p)
     hb = _mix(bc * 0x2545F491 + cfg.seed)
     # genome by inverse CDF of the log-normal abundances
     rs = np.random.RandomState(cfg.seed)
@@ -161,14 +191,19 @@ def generate(cfg: SynthConfig, device="cpu", chunk_pairs: int = 1 << 16, with_na
     # runs, assembled as the reference does: a run is closed by the first pair of the NEXT barcode, the
     # first pair of the file falls into the leading ""-run, the accumulator left at EOF is one more run
     P, nb = cfg.pairs_per_barcode, cfg.n_barcodes
-    n_bc_pairs = min(P * nb, cfg.n_pairs)
-    n_bc = (n_bc_pairs + P - 1) // P
+    bounds = barcode_bounds(cfg)
+    if bounds is None:
+        n_bc_pairs = min(P * nb, cfg.n_pairs)
+        n_bc = (n_bc_pairs + P - 1) // P
+        ends = [1] + [min((b + 1) * P + 1, cfg.n_pairs) for b in range(n_bc)]
+    else:
+        n_bc_pairs, n_bc = int(bounds[-1]), len(bounds) - 1
+        ends = [1] + np.minimum(bounds[1:] + 1, cfg.n_pairs).tolist()
     has_tail = n_bc_pairs < cfg.n_pairs
-    ends = [1] + [min((b + 1) * P + 1, cfg.n_pairs) for b in range(n_bc)]
     if not has_tail:
         ends[-1] = cfg.n_pairs
     b0 = cfg.first_pair // P
-    names = [""] + [barcode_name(cfg, b0 + b) if with_names else f"b{b0 + b}" for b in range(n_bc)]
+    names = [""] + [(f"lr_{b:07d}" if bounds is not None else barcode_name(cfg, b0 + b)) if with_names else f"b{b0 + b}" for b in range(n_bc)]
     if has_tail:
         ends.append(cfg.n_pairs)
         names.append("")
@@ -184,6 +219,7 @@ def write_fastq(stream: ReadStream, cfg: SynthConfig, path: str, n_pairs: int | 
     n = cfg.n_pairs if n_pairs is None else min(n_pairs, cfg.n_pairs)
     cpp, L, P = cfg.chars_per_pair, cfg.read_len, cfg.pairs_per_barcode
     qual = "I" * L
+    bounds = barcode_bounds(cfg)
     with open(path, "w") as f:
         step = 1 << 14
         for p0 in range(0, n, step):
@@ -192,13 +228,17 @@ def write_fastq(stream: ReadStream, cfg: SynthConfig, path: str, n_pairs: int | 
             out = []
             for p in range(p0, p1):
                 o = (p - p0) * cpp
-                b = cfg.first_pair // P + p // P
-                has_bc = p < P * cfg.n_barcodes
+                if bounds is None:
+                    b = cfg.first_pair // P + p // P
+                    has_bc = p < P * cfg.n_barcodes
+                else:
+                    b = int(np.searchsorted(bounds[1:], p, side="right"))
+                    has_bc = p < int(bounds[-1])
                 if style == "stlfr":
                     tag = f"#{b % 1536 + 1}_{(b // 1536) % 1536 + 1}_{b // (1536 * 1536) + 1}" if has_bc else "#0_0_0"
                     h1, h2 = f"@r{p}{tag}/1", f"@r{p}{tag}/2"
                 else:
-                    name = barcode_name(cfg, b) if style == "10x" else f"lr_{b:07d}"
+                    name = barcode_name(cfg, b) if (style == "10x" and bounds is None) else f"lr_{b:07d}"
                     h1 = h2 = f"@r{p} BX:Z:{name}-1" if has_bc else f"@r{p}"
                 out.append(f"{h1}\n{txt[o:o + L]}\n+\n{qual}\n{h2}\n{txt[o + L + 1:o + 2 * L + 1]}\n+\n{qual}\n")
             f.write("".join(out))
