@@ -91,6 +91,12 @@ const uint32_t *pg_reads_valid(const pg_reads *r);
  * codes are in `codes` all the same, and a caller that wants jellyfish's table counts with valid | lower (and gives the
  * strict plane in pg_rows.strict_valid). */
 const uint32_t *pg_reads_lower(const pg_reads *r);
+/* NULL, or the plane of bases (either case) whose quality character is below '?' -- paired (-1/-2) input only: there the
+ * reference runs jellyfish with --min-qual-char=? (feature.py:76-83), which counts such bases as N, while count_tnf /
+ * count_kmer never read the quality lines.  The multiplicity table is therefore counted with (valid | lower) & ~lowq and
+ * the rows with `valid`: a row's k-mer may be missing from the table (count_kmer.cpp:87 skips it), so these inputs take
+ * the lookup form of pg_features. */
+const uint32_t *pg_reads_lowq(const pg_reads *r);
 const int64_t *pg_reads_run_off(const pg_reads *r); /* [n_runs + 1] */
 const char *pg_reads_run_name(const pg_reads *r, int64_t i);
 /* "" (undecided), "10x" or "stLFR": the header mode the file latched (count_tnf.cpp:27-32) */

@@ -279,13 +279,21 @@ orc_reads *orc_parse_fastq(const char *r1, const char *r2)
         if (slurp(r2, &f2) || split_lines(&f2, &L2)) goto done;
         buf_t n1 = {0}, n2 = {0}, b1 = {0}, b2 = {0};
         int bad = 0;
-        /* jellyfish sees every sequence line of both files */
-        for (size_t i = 1; i < L1.start.n; i += 4)
-            if (buf_add(&R->all_seq, f1.p + L1.start.p[i], (size_t)L1.len.p[i]) ||
-                buf_addc(&R->all_seq, 'N')) bad = 1;
-        for (size_t i = 1; i < L2.start.n; i += 4)
-            if (buf_add(&R->all_seq, f2.p + L2.start.p[i], (size_t)L2.len.p[i]) ||
-                buf_addc(&R->all_seq, 'N')) bad = 1;
+        /* jellyfish sees every sequence line of both files -- run with --min-qual-char=? in this branch (feature.py:76-83):
+         * a base whose quality character is below '?' reads as N */
+        for (int which = 0; which < 2; ++which) {
+            const buf_t *f = which ? &f2 : &f1;
+            const lines_t *L = which ? &L2 : &L1;
+            for (size_t i = 1; i < L->start.n; i += 4) {
+                const char *sq = f->p + L->start.p[i];
+                const size_t sn = (size_t)L->len.p[i];
+                const char *q = i + 2 < L->start.n ? f->p + L->start.p[i + 2] : "";
+                const size_t qn = i + 2 < L->start.n ? (size_t)L->len.p[i + 2] : 0;
+                for (size_t j = 0; j < sn; ++j)
+                    if (buf_addc(&R->all_seq, j < qn && (unsigned char)q[j] < (unsigned char)'?' ? 'N' : sq[j])) bad = 1;
+                if (buf_addc(&R->all_seq, 'N')) bad = 1;
+            }
+        }
         for (size_t i = 0; i < L1.start.n && !bad; ++i) {
             const char *s1 = f1.p + L1.start.p[i];
             size_t l1 = (size_t)L1.len.p[i];

@@ -56,9 +56,13 @@ struct StreamWriter {
     std::vector<uint32_t> valid;
     std::vector<uint32_t> lower;   // bit set for a LOWER-case a c g t: a base for jellyfish, a reset for the reference's own counters
     bool any_lower = false;
+    // bit set for a base (either case) whose quality character is below '?': jellyfish is run with --min-qual-char=? on
+    // paired files (feature.py:76-83) and turns such bases into N, the reference's own counters never look at qualities
+    std::vector<uint32_t> lowq;
+    bool any_lowq = false;
     int64_t n = 0;          // characters written
     uint64_t cw = 0;        // word under construction
-    uint32_t vw = 0, lw = 0;
+    uint32_t vw = 0, lw = 0, qw = 0;
 
     inline void put(unsigned char c)
     {
@@ -70,22 +74,33 @@ struct StreamWriter {
         if (ok | lo) cw |= (uint64_t)((c >> 1) & 3) << (2 * sh);
         if (ok) vw |= 1u << sh;
         if (lo) { lw |= 1u << sh; any_lower = true; }
-        if (sh == 31) { codes.push_back(cw); valid.push_back(vw); lower.push_back(lw); cw = 0; vw = 0; lw = 0; }
+        if (sh == 31) { codes.push_back(cw); valid.push_back(vw); lower.push_back(lw); lowq.push_back(qw); cw = 0; vw = 0; lw = 0; qw = 0; }
         ++n;
     }
     void put_span(const char *s, size_t len)
     {
         for (size_t i = 0; i < len; ++i) put((unsigned char)s[i]);
     }
+    // a read with its quality line (paired files): bases below '?' are marked (a missing quality character marks nothing)
+    void put_span_q(const char *s, size_t len, const char *q, size_t qlen)
+    {
+        for (size_t i = 0; i < len; ++i) {
+            const unsigned char c = (unsigned char)s[i];
+            const bool base = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T') | (c == 'a') | (c == 'c') | (c == 'g') | (c == 't');
+            if (base && i < qlen && (unsigned char)q[i] < (unsigned char)'?') { qw |= 1u << (int)(n & 31); any_lowq = true; }
+            put(c);
+        }
+    }
     void finish()
     {
-        if (n & 31) { codes.push_back(cw); valid.push_back(vw); lower.push_back(lw); cw = 0; vw = 0; lw = 0; }
+        if (n & 31) { codes.push_back(cw); valid.push_back(vw); lower.push_back(lw); lowq.push_back(qw); cw = 0; vw = 0; lw = 0; qw = 0; }
         size_t words = codes.size();
         size_t padded = (words + PG_WORD_ALIGN - 1) / PG_WORD_ALIGN * PG_WORD_ALIGN;
         if (padded == 0) padded = PG_WORD_ALIGN;
         codes.resize(padded, 0);
         valid.resize(padded, 0);
         if (any_lower) lower.resize(padded, 0); else std::vector<uint32_t>().swap(lower);
+        if (any_lowq) lowq.resize(padded, 0); else std::vector<uint32_t>().swap(lowq);
     }
 };
 
@@ -258,6 +273,7 @@ struct pg_reads {
     uint64_t *codes_w = nullptr;
     uint32_t *valid_w = nullptr;
     uint32_t *lower_w = nullptr;                 // NULL unless the input has lower-case bases
+    uint32_t *lowq_w = nullptr;                  // NULL unless paired input has bases of quality below '?'
     std::vector<uint32_t> lower_plane;           // (the threaded path keeps the rare plane here)
     int64_t n_words = 0, n_chars = 0;
     std::vector<int64_t> run_off;      // [n_runs + 1]
@@ -274,6 +290,7 @@ struct pg_reads {
         st.finish();
         codes_w = st.codes.data(); valid_w = st.valid.data();
         lower_w = st.any_lower ? st.lower.data() : nullptr;
+        lowq_w = st.any_lowq ? st.lowq.data() : nullptr;
         n_words = (int64_t)st.codes.size(); n_chars = st.n;
     }
     bool alloc_stream(int64_t total_chars)
@@ -788,8 +805,28 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
             Lines L1(f1), L2(f2);
             uint64_t line_no = 0;
             std::string n1, n2, b1, b2;
-            std::vector<std::pair<const char *, size_t>> orphans;   // reads of skipped pairs (still counted globally)
+            struct ReadQ { const char *s; size_t n; const char *q; size_t qn; };
+            std::vector<ReadQ> orphans;                             // reads of skipped pairs (still counted globally)
             const char *c; size_t clen;
+            const char *s1 = "", *s2 = ""; size_t l1 = 0, l2 = 0;    // the pair's sequence lines, written when its quality lines are known
+            bool have_pair = false, keep_pair = false;
+            auto flush_pair = [&](const char *q1, size_t q1n, const char *q2, size_t q2n) {
+                if (!have_pair) return;
+                have_pair = false;
+                if (!keep_pair) {
+                    orphans.push_back(ReadQ{s1, l1, q1, q1n});
+                    orphans.push_back(ReadQ{s2, l2, q2, q2n});
+                    return;
+                }
+                R->st.put_span_q(s1, l1, q1, q1n); R->st.put('N');
+                R->st.put_span_q(s2, l2, q2, q2n); R->st.put('N');
+                R->n_pairs++;
+                if (b1 != last) {
+                    R->run_off.push_back(R->st.n);
+                    R->run_name.push_back(last);
+                    last = b1;
+                }
+            };
             while (L1.next(b, len)) {
                 if (!L2.next(c, clen)) { c = ""; clen = 0; }        // a short R2 reads as empty lines
                 switch (++line_no % 4) {
@@ -804,31 +841,31 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
                     break;
                 }
                 case 2:
-                    if (n1 != n2 || b1 != b2) {
-                        R->n_unpaired++;
-                        orphans.emplace_back(b, len);
-                        orphans.emplace_back(c, clen);
-                    } else {
-                        R->st.put_span(b, len); R->st.put('N');
-                        R->st.put_span(c, clen); R->st.put('N');
-                        R->n_pairs++;
-                        if (b1 != last) {
-                            R->run_off.push_back(R->st.n);
-                            R->run_name.push_back(last);
-                            last = b1;
-                        }
-                    }
+                    flush_pair("", 0, "", 0);                       // (a record cut short of its quality line)
+                    keep_pair = !(n1 != n2 || b1 != b2);
+                    if (!keep_pair) R->n_unpaired++;
+                    s1 = b; l1 = len; s2 = c; l2 = clen;
+                    have_pair = true;
+                    break;
+                case 0:
+                    flush_pair(b, len, c, clen);
                     break;
                 default: break;
                 }
             }
+            flush_pair("", 0, "", 0);
             // R2 records beyond the end of R1 are still input of the global counter
-            uint64_t l2 = line_no;
-            while (L2.next(c, clen))
-                if (++l2 % 4 == 2) orphans.emplace_back(c, clen);
+            uint64_t ln2 = line_no;
+            const char *os = nullptr; size_t on = 0;
+            while (L2.next(c, clen)) {
+                ++ln2;
+                if (ln2 % 4 == 2) { if (os) orphans.push_back(ReadQ{os, on, "", 0}); os = c; on = clen; }
+                else if (ln2 % 4 == 0 && os) { orphans.push_back(ReadQ{os, on, c, clen}); os = nullptr; }
+            }
+            if (os) orphans.push_back(ReadQ{os, on, "", 0});
             R->run_off.push_back(R->st.n);
             R->run_name.push_back(last);
-            for (auto &o : orphans) { R->st.put_span(o.first, o.second); R->st.put('N'); }
+            for (auto &o : orphans) { R->st.put_span_q(o.s, o.n, o.q, o.qn); R->st.put('N'); }
         }
         R->seal_serial();
     } catch (const std::bad_alloc &) {
@@ -973,6 +1010,7 @@ extern "C" int64_t pg_reads_n_runs(const pg_reads *r) { return (int64_t)r->run_n
 extern "C" const uint64_t *pg_reads_codes(const pg_reads *r) { return r->codes_w; }
 extern "C" const uint32_t *pg_reads_valid(const pg_reads *r) { return r->valid_w; }
 extern "C" const uint32_t *pg_reads_lower(const pg_reads *r) { return r->lower_w; }
+extern "C" const uint32_t *pg_reads_lowq(const pg_reads *r) { return r->lowq_w; }
 extern "C" const int64_t *pg_reads_run_off(const pg_reads *r) { return r->run_off.data(); }
 extern "C" const char *pg_reads_run_name(const pg_reads *r, int64_t i)
 {

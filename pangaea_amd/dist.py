@@ -77,8 +77,18 @@ def shard_stream(stream: ReadStream, rank: int, world: int) -> ReadStream:
             lower = torch.where(lv >= (1 << 31), lv - (1 << 32), lv).to(torch.int32)
         if pad:
             lower = torch.cat([lower, lower.new_zeros(pad)])
+    lowq = None
+    if stream.valid_lowq is not None:           # the quality plane too
+        lowq = stream.valid_lowq[w0:w1].clone()
+        if lowq.numel():
+            qv = lowq.to(torch.int64) & 0xFFFFFFFF
+            qv[0] &= keep_first
+            qv[-1] &= keep_last
+            lowq = torch.where(qv >= (1 << 31), qv - (1 << 32), qv).to(torch.int32)
+        if pad:
+            lowq = torch.cat([lowq, lowq.new_zeros(pad)])
     return ReadStream(codes, valid, c1 - 32 * w0, run_off.astype(np.int64), stream.run_names[first:last], mode=stream.mode,
-                      valid_lower=lower)
+                      valid_lower=lower, valid_lowq=lowq)
 
 
 def ingest_shard(reads1: str, reads2: str | None = None, group=None) -> ReadStream:

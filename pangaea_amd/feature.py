@@ -86,7 +86,7 @@ def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | Non
 
 def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window: int, vsize: int, min_len: int,
                      device=None, want_tnf: bool = True, want_abd: bool = True, table: KmerTable | None = None,
-                     stream_cache: str | None = None, lowercase_is_base: bool = False):
+                     stream_cache: str | None = None, lowercase_is_base: bool = True):
     """(names, tnf int32 ndarray or None, abd int32 ndarray or None) of a barcode-sorted FASTQ, on the GPU.
     Under an initialised ``torch.distributed`` group every rank takes a contiguous range of runs, the table is
     exchanged once, and the rows are gathered so every rank returns the full matrices."""
@@ -153,8 +153,10 @@ class Feature:
             self._cache = compute_features(r1, r2, int(self.kmer), int(self.tnf_k), int(self.ws), int(self.vs), int(self.minl),
                                            device=getattr(self.args, "device", None), want_tnf=want_tnf, want_abd=want_abd,
                                            stream_cache=cache,
-                                           # jellyfish's rule for the multiplicity table (soft-masked input only)
-                                           lowercase_is_base=os.environ.get("PANGAEA_LOWERCASE_IS_BASE", "0") not in ("", "0"))
+                                           # jellyfish's rules for the multiplicity table (feature.py:76-94): lower-case bases
+                                           # count (soft-masked input; PANGAEA_LOWERCASE_IS_BASE=0 turns that off), bases
+                                           # below --min-qual-char=? of paired files do not (ReadStream.table_valid)
+                                           lowercase_is_base=os.environ.get("PANGAEA_LOWERCASE_IS_BASE", "1") not in ("", "0"))
         return self._cache
 
     # ------------------------------------------------------------------ the reference's public methods

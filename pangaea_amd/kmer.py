@@ -219,14 +219,23 @@ class KmerTable:
 
         ``lowercase_is_base``: count lower-case a c g t as bases, as ``jellyfish count`` does (src/feature.py:94) -- the
         reference's own row counters reset on them (count_kmer.cpp:73-78), so k-mers that are only valid under this rule
-        enter the table but belong to no row.  Only matters for soft-masked input (``stream.valid_lower`` is not None)."""
+        enter the table but belong to no row.  Only matters for soft-masked input (``stream.valid_lower`` is not None).
+        Paired input with bases below the quality threshold (``stream.valid_lowq``, jellyfish's --min-qual-char=? of
+        feature.py:76-83) is always counted without them, and without ``rows`` / ``emit`` (see ``ReadStream.table_valid``)."""
         _require_gpu(stream.codes, "the read stream")
         if stream.device != self.device:
             raise ValueError("stream and table are on different devices")
         word_end = stream.n_words if word_end is None else word_end
         L = _lib.load()
-        lenient = lowercase_is_base and stream.valid_lower is not None
-        valid_ptr = (stream.lenient_valid() if lenient else stream.valid).data_ptr()
+        # the table is counted with jellyfish's view of the reads (lower-case bases count when asked for, bases below the
+        # quality threshold of paired input never do); rows keep the reference's own rule, the strict plane
+        table_plane = stream.table_valid(lowercase_is_base)
+        lenient = table_plane is not stream.valid
+        valid_ptr = table_plane.data_ptr()
+        if not stream.rows_inside_table:
+            # quality-masked bases: a row's k-mer may be missing from the table, which only the lookup form of ``features``
+            # expresses (count_kmer.cpp:87) -- no row-tagged records, no fused lookups
+            rows = emit = None
 
         def rows_arg(plan):
             # the rows' own validity rule stays the strict one: with a lenient counting plane the strict plane rides along
@@ -642,7 +651,7 @@ def distinct_sketch(stream: ReadStream, k: int, word_begin: int = 0, word_end: i
     regs = torch.zeros(_lib.HLL_REGISTERS, dtype=torch.int32, device=dev)
     word_end = stream.n_words if word_end is None else word_end
     with torch.cuda.device(dev):
-        valid = stream.lenient_valid() if lowercase_is_base else stream.valid
+        valid = stream.table_valid(lowercase_is_base)
         _lib.check(_lib.load().pg_kmer_distinct_sketch(stream.codes.data_ptr(), valid.data_ptr(), word_begin, word_end, k,
                                                        regs.data_ptr(), _stream_ptr(dev)))
     return regs

@@ -59,6 +59,11 @@ class ReadStream:
     # reference's own counters reset on them: `valid` excludes them (their 2-bit codes are in `codes` all the same) and
     # ``KmerTable.count(..., lowercase_is_base=True)`` counts with ``valid | valid_lower``.  None: the input has none.
     valid_lower: torch.Tensor | None = None
+    # int32 [n_words] or None: bit j set iff character j is a base (either case) with a quality character below '?'.  Only
+    # paired (-1/-2) input has it: there the reference runs jellyfish with --min-qual-char=? (feature.py:76-83), which reads
+    # such bases as N, while its own counters never look at qualities.  The TABLE is counted with ``table_valid()``, rows
+    # with ``valid``.
+    valid_lowq: torch.Tensor | None = None
 
     @property
     def n_words(self) -> int:
@@ -75,6 +80,23 @@ class ReadStream:
         if getattr(self, "_lenient", None) is None:
             self._lenient = self.valid | self.valid_lower
         return self._lenient
+
+    def table_valid(self, lowercase_is_base: bool = True) -> torch.Tensor:
+        """the validity plane the multiplicity table is counted with -- jellyfish's view of the reads: lower-case bases count
+        (``lowercase_is_base``), bases below the quality threshold of paired input do not"""
+        v = self.lenient_valid() if lowercase_is_base else self.valid
+        if self.valid_lowq is None:
+            return v
+        key = "_table_valid_lc" if lowercase_is_base else "_table_valid"
+        if getattr(self, key, None) is None:
+            setattr(self, key, v & ~self.valid_lowq)
+        return getattr(self, key)
+
+    @property
+    def rows_inside_table(self) -> bool:
+        """is every k-mer of a row also a k-mer of the table's view?  (not when qualities mask bases: then the abundance
+        rows are built by table lookups, the only form in which a row's k-mer may be absent from the table)"""
+        return self.valid_lowq is None
 
     # ------------------------------------------------------------------ constructors
 
@@ -119,11 +141,13 @@ class ReadStream:
         valid = np.ctypeslib.as_array(C.cast(L.pg_reads_valid(h), C.POINTER(C.c_int32)), shape=(nw,))
         lower_ptr = L.pg_reads_lower(h)
         lower = torch.from_numpy(np.ctypeslib.as_array(C.cast(lower_ptr, C.POINTER(C.c_int32)), shape=(nw,))) if lower_ptr else None
+        lowq_ptr = L.pg_reads_lowq(h)
+        lowq = torch.from_numpy(np.ctypeslib.as_array(C.cast(lowq_ptr, C.POINTER(C.c_int32)), shape=(nw,))) if lowq_ptr else None
         run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
         names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
         out = cls(torch.from_numpy(codes), torch.from_numpy(valid), int(L.pg_reads_n_chars(h)), run_off, names,
                   int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode(), _owner=owner,
-                  valid_lower=lower)
+                  valid_lower=lower, valid_lowq=lowq)
         return out
 
     @classmethod
@@ -154,7 +178,7 @@ class ReadStream:
         valid = self.valid.cpu().numpy()
         names = b"".join(n.encode() + b"\0" for n in self.run_names)
         mode = self.mode.encode()
-        has_lower = int(self.valid_lower is not None)
+        has_lower = int(self.valid_lower is not None) | (2 if self.valid_lowq is not None else 0)      # bit 0: lower plane, bit 1: lowq plane
         head = np.array([self.n_chars, codes.size, len(self.run_names), self.n_pairs, self.n_unpaired, len(names), len(mode), has_lower], dtype="<i8")
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
@@ -163,8 +187,10 @@ class ReadStream:
             f.write(b"\0" * (-f.tell() % 4096))
             codes.astype("<i8", copy=False).tofile(f)
             valid.astype("<i4", copy=False).tofile(f)
-            if has_lower:
+            if self.valid_lower is not None:
                 self.valid_lower.cpu().numpy().astype("<i4", copy=False).tofile(f)
+            if self.valid_lowq is not None:
+                self.valid_lowq.cpu().numpy().astype("<i4", copy=False).tofile(f)
         os.replace(tmp, path)
 
     @classmethod
@@ -178,16 +204,20 @@ class ReadStream:
             run_off = np.frombuffer(f.read(8 * (n_runs + 1)), dtype="<i8").astype(np.int64)
             names = f.read(names_bytes).split(b"\0")[:-1] if names_bytes else []
             at = f.tell() + (-f.tell() % 4096)
-        if len(names) != n_runs or os.path.getsize(path) != at + (16 if has_lower else 12) * n_words or n_words != words_for(n_chars):
+        n_extra = (has_lower & 1) + ((has_lower >> 1) & 1)
+        if len(names) != n_runs or os.path.getsize(path) != at + (12 + 4 * n_extra) * n_words or n_words != words_for(n_chars):
             raise ValueError(f"{path} is truncated or inconsistent")
         codes = np.memmap(path, dtype="<i8", mode="r", offset=at, shape=(n_words,))
         valid = np.memmap(path, dtype="<i4", mode="r", offset=at + 8 * n_words, shape=(n_words,))
-        lower = np.memmap(path, dtype="<i4", mode="r", offset=at + 12 * n_words, shape=(n_words,)) if has_lower else None
+        lower = np.memmap(path, dtype="<i4", mode="r", offset=at + 12 * n_words, shape=(n_words,)) if has_lower & 1 else None
+        lowq = np.memmap(path, dtype="<i4", mode="r", offset=at + (12 + 4 * (has_lower & 1)) * n_words, shape=(n_words,)) if has_lower & 2 else None
         device = torch.device(device)
         if device.type == "cpu":
-            codes, valid, lower = np.array(codes), np.array(valid), (None if lower is None else np.array(lower))
+            codes, valid = np.array(codes), np.array(valid)
+            lower, lowq = (None if lower is None else np.array(lower)), (None if lowq is None else np.array(lowq))
         return cls(torch.from_numpy(codes).to(device), torch.from_numpy(valid).to(device), n_chars, run_off, [n.decode() for n in names],
-                   n_pairs, n_unpaired, mode, valid_lower=None if lower is None else torch.from_numpy(lower).to(device))
+                   n_pairs, n_unpaired, mode, valid_lower=None if lower is None else torch.from_numpy(lower).to(device),
+                   valid_lowq=None if lowq is None else torch.from_numpy(lowq).to(device))
 
     def to(self, device) -> "ReadStream":
         device = torch.device(device)
@@ -195,7 +225,8 @@ class ReadStream:
             return self
         return ReadStream(self.codes.to(device), self.valid.to(device), self.n_chars, self.run_off, self.run_names,
                           self.n_pairs, self.n_unpaired, self.mode,
-                          valid_lower=None if self.valid_lower is None else self.valid_lower.to(device))
+                          valid_lower=None if self.valid_lower is None else self.valid_lower.to(device),
+                          valid_lowq=None if self.valid_lowq is None else self.valid_lowq.to(device))
 
     # ------------------------------------------------------------------ rows
 
@@ -207,12 +238,13 @@ class ReadStream:
 
     # ------------------------------------------------------------------ host decode (tests / FASTQ export)
 
-    def decode(self, start: int = 0, end: int | None = None) -> bytes:
-        """characters [start, end) as text: bases for valid positions, 'N' for everything else"""
+    def decode(self, start: int = 0, end: int | None = None, plane: torch.Tensor | None = None) -> bytes:
+        """characters [start, end) as text: bases for valid positions, 'N' for everything else (``plane``: another validity
+        plane than ``valid``, e.g. ``table_valid()`` -- the reads as the multiplicity table sees them)"""
         end = self.n_chars if end is None else end
         w0, w1 = start // 32, (end + 31) // 32
         c = self.codes[w0:w1].cpu().numpy().view(np.uint64)
-        v = self.valid[w0:w1].cpu().numpy().view(np.uint32)
+        v = (self.valid if plane is None else plane)[w0:w1].cpu().numpy().view(np.uint32)
         sh = np.arange(32, dtype=np.uint64)
         code = ((c[:, None] >> (2 * sh)[None, :]) & np.uint64(3)).astype(np.uint8).ravel()
         ok = ((v[:, None] >> sh.astype(np.uint32)[None, :]) & np.uint32(1)).astype(bool).ravel()

@@ -64,6 +64,50 @@ def test_feature_paired_inputs_and_exponent_counts(tmp_path):
     assert tnf.dtype == np.float64 and np.array_equal(tnf, ref_t.drop(columns=0).to_numpy())
 
 
+def test_feature_follows_jellyfish_rules_for_the_table(tmp_path, monkeypatch):
+    """-1/-2 input: the multiplicity table leaves out bases below '?' (jellyfish --min-qual-char=?, feature.py:76-83) while the
+    rows do not look at qualities; soft-masked reads: lower-case bases count for the table, reset the rows' counters.
+    Goldens = the reference's count_kmer / count_tnf on the same files, given the dump those rules produce."""
+    from oracle import oracle
+    from pangaea_amd import kmer
+    from pangaea_amd.feature import Feature
+    from pangaea_amd.reads import ReadStream
+    r1, r2 = os.path.join(GOLDEN, "pairq_R1.fq"), os.path.join(GOLDEN, "pairq_R2.fq")
+    for k, w, v in ((15, 1, 6), (21, 1, 6), (9, 2, 50)):
+        args = _args(tmp_path / f"q{k}", reads1=r1, reads2=r2, min_length=100, kmer=k, window_size=w, vector_size=v)
+        names, abd, tnf = Feature(args, ROOT).extract_features()
+        ref_a = pd.read_csv(os.path.join(GOLDEN, f"pairq.abd.k{k}.w{w}.v{v}.l100.csv"), header=None)
+        ref_t = pd.read_csv(os.path.join(GOLDEN, "pairq.tnf.k4.l100.csv"), header=None)
+        assert (names == ref_a[0].to_numpy()).all()
+        assert np.array_equal(abd, ref_a.drop(columns=0).to_numpy()) and np.array_equal(tnf, ref_t.drop(columns=0).to_numpy())
+    # the table itself, in every counting form, is the dump (rows and fused lookups are dropped for such streams)
+    s = ReadStream.from_fastq(r1, r2, device="cuda:0")
+    assert s.valid_lowq is not None and not s.rows_inside_table
+    want = oracle.Table.from_dump(os.path.join(GOLDEN, "pairq.k21.dump"), 21).items()
+    plan = kmer.Plan(s.rows(100), "cuda:0")
+    for t in (kmer.KmerTable.with_slots(21, "cuda:0", 16, 0).count(s),                                   # direct
+              kmer.KmerTable.with_slots(21, "cuda:0", 18, 6).count(s, rows=plan, emit=(1, 6)),          # bucketed (fusion dropped)
+              kmer.KmerTable.mini_with_slots(21, "cuda:0", 18, 10).count(s, rows=plan, emit=(1, 6)),     # super-k-mers
+              kmer.count_kmers(s, 21, rows=plan, emit=(1, 6))):
+        assert t._emitted is None and t._records is None
+        assert all(np.array_equal(x, y) for x, y in zip(t.items(), want))
+    # the unmasked table would be another one
+    monkeypatch.setattr(ReadStream, "table_valid", lambda self, lowercase_is_base=True: self.valid)
+    assert not all(np.array_equal(x, y) for x, y in zip(kmer.KmerTable.with_slots(21, "cuda:0", 16, 0).count(s).items(), want))
+    monkeypatch.undo()
+    # soft-masked reads, interleaved
+    for k in (15, 21):
+        args = _args(tmp_path / f"s{k}", interleaved_reads=os.path.join(GOLDEN, "soft.fq"), min_length=100, kmer=k, window_size=1, vector_size=6)
+        names, abd, tnf = Feature(args, ROOT).extract_features()
+        ref_a = pd.read_csv(os.path.join(GOLDEN, f"soft.abd.k{k}.w1.v6.l100.csv"), header=None)
+        ref_t = pd.read_csv(os.path.join(GOLDEN, "soft.tnf.k4.l100.csv"), header=None)
+        assert np.array_equal(abd, ref_a.drop(columns=0).to_numpy()) and np.array_equal(tnf, ref_t.drop(columns=0).to_numpy())
+    monkeypatch.setenv("PANGAEA_LOWERCASE_IS_BASE", "0")             # the strict table gives other rows on this input
+    args = _args(tmp_path / "strict", interleaved_reads=os.path.join(GOLDEN, "soft.fq"), min_length=100, kmer=15, window_size=1, vector_size=6)
+    _, abd_strict, _ = Feature(args, ROOT).extract_features()
+    assert not np.array_equal(abd_strict, pd.read_csv(os.path.join(GOLDEN, "soft.abd.k15.w1.v6.l100.csv"), header=None).drop(columns=0).to_numpy())
+
+
 def _run(tool, *argv):
     return subprocess.run([sys.executable, os.path.join(ROOT, "pangaea_amd", "bin", tool), *argv], capture_output=True, text=True)
 

@@ -59,11 +59,32 @@ def test_exact_counter_equals_dump_when_complete():
         if case["tool"] != "count_kmer" or case["holes"]:
             continue
         rd = _reads(case["input"])
-        direct = oracle.Table(case["k"], threads=3).count(rd.all_seq())
+        direct = oracle.Table(case["k"], threads=3).count(rd.all_seq(), lowercase_is_base=case.get("jellyfish_rules", False))
         loaded = oracle.Table.from_dump(os.path.join(GOLDEN, case["dump"]), case["k"])
         k1, v1 = direct.items()
         k2, v2 = loaded.items()
         assert np.array_equal(k1, k2) and np.array_equal(v1, v2), case["expect"]
+
+
+def test_jellyfish_rules_of_the_paired_branch_and_of_soft_masked_reads():
+    """what jellyfish sees differs from what count_tnf / count_kmer see in two ways (feature.py:76-94): --min-qual-char=? on
+    paired files turns bases below '?' into N (all_seq carries that), and lower-case bases count"""
+    rd = _reads({"1": "pairq_R1.fq", "2": "pairq_R2.fq"})
+    seen = rd.all_seq()
+    raw = b"".join(ln.rstrip(b"\n") + b"N" for fn in ("pairq_R1.fq", "pairq_R2.fq")
+                   for i, ln in enumerate(open(os.path.join(GOLDEN, fn), "rb")) if i % 4 == 1)
+    qual = b"".join(ln.rstrip(b"\n") + b"I" for fn in ("pairq_R1.fq", "pairq_R2.fq")
+                    for i, ln in enumerate(open(os.path.join(GOLDEN, fn), "rb")) if i % 4 == 3)
+    assert len(seen) == len(raw) == len(qual)
+    want = bytes(ord("N") if q < ord("?") else c for c, q in zip(raw, qual))
+    assert seen == want and seen != raw and b"N" * 45 in seen          # (one read has no trusted base at all)
+    masked = oracle.Table(15).count(seen)
+    unmasked = oracle.Table(15).count(raw)
+    assert 0 < len(masked) < len(unmasked)
+    sm = _reads({"i": "soft.fq"})
+    strict, lenient = oracle.Table(15).count(sm.all_seq()), oracle.Table(15).count(sm.all_seq(), lowercase_is_base=True)
+    assert int(strict.items()[1].sum()) < int(lenient.items()[1].sum())
+    assert all(np.array_equal(a, b) for a, b in zip(lenient.items(), oracle.Table(15).count(sm.all_seq().upper()).items()))
 
 
 def test_tnf_column_order_anchor(manifest):
