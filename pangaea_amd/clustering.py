@@ -8,16 +8,18 @@ clustering.py:14-19).  The algorithm is the vendored library's (third_parties/rp
                                                                                _point_reducer_cy_lib.cpp:5-28, .h:52-68)
   * weighted k-means on the skeleton -> initial centres                        (rph_kmeans_.py:116-129)
   * Lloyd iterations on ALL points from those centres, best inertia of n_init (rph_kmeans_.py:143-162)
-Where it runs: projections, bucketing (``torch.unique`` over the 5-integer rows), weighted merges and the Lloyd
-distance / assignment / update steps are torch-ROCm ops on the device (the [N,32]x[k,32] distance step is a GEMM +
-row argmin); the <= 2 000-point skeleton k-means stays sklearn on the host, as in the reference.  Random draws
-come from numpy's global generator in the reference's order (``init_all`` seeds it), but bucket numbering follows
+Where it runs: everything on the device -- projections, bucketing (``torch.unique`` over the 5-integer rows), weighted
+merges, the weighted skeleton k-means (greedy k-means++ seeding with sklearn's 2 + ln k local trials, then weighted
+Lloyd) and the Lloyd distance / assignment / update steps over all points (the [N,32]x[k,32] distance step is a GEMM +
+row argmin).  Nothing but the final labels returns to the host.  Random draws come from numpy's global generator in the
+reference's order (``init_all`` seeds it; the device generator of the k-means++ seeding is seeded from it), but bucket numbering follows
 ``torch.unique`` instead of ``unordered_map`` iteration, so labels are NOT bit-comparable with the reference
  -- parity is by inertia and adjusted Rand index.
 """
 from __future__ import annotations
 
 import logging
+import math
 import os
 import warnings
 from collections import defaultdict
@@ -76,12 +78,55 @@ def lloyd(x: torch.Tensor, centers: torch.Tensor, max_iter: int = 300, tol: floa
     return labels, centers, inertia, n_iter
 
 
+@torch.no_grad()
+def kmeans_plusplus(x: torch.Tensor, w: torch.Tensor, k: int, gen: torch.Generator) -> torch.Tensor:
+    """greedy k-means++ seeding with sample weights, as sklearn's ``_kmeans_plusplus`` (the seeding inside the reference's
+    ``KMeans(n_clusters=k).fit_predict(reduced_X, sample_weight)``, rph_kmeans_.py:121-124): the first centre is drawn in
+    proportion to the weights, every further one is the best of 2 + ln k candidates drawn in proportion to weight x squared
+    distance to the nearest centre so far.  Returns centres [k, D]."""
+    n_trials = 2 + int(math.log(k))
+    centers = torch.empty((k, x.shape[1]), dtype=x.dtype, device=x.device)
+    first = torch.multinomial(w / w.sum(), 1, generator=gen)
+    centers[0] = x[first[0]]
+    x2 = (x * x).sum(1, keepdim=True)
+    closest = _sq_dists(x, centers[0:1], x2).squeeze(1)
+    for c in range(1, k):
+        p = closest * w
+        total = p.sum()
+        # (every point already a centre: fall back to the weights, as sklearn's searchsorted on a flat cumsum would)
+        p = torch.where(total > 0, p / total.clamp(min=1e-300), w / w.sum())
+        cand = torch.multinomial(p, n_trials, replacement=True, generator=gen)
+        d = torch.minimum(_sq_dists(x, x[cand], x2), closest[:, None])          # [G, n_trials]
+        best = (d * w[:, None]).sum(0).argmin()
+        closest = d[:, best]
+        centers[c] = x[cand[best]]
+    return centers
+
+
+@torch.no_grad()
+def weighted_kmeans(x: torch.Tensor, w: torch.Tensor, k: int, n_init: int = 1, max_iter: int = 300, tol: float = 1e-4,
+                    gen: torch.Generator | None = None):
+    """weighted k-means on the device (the skeleton step): best of ``n_init`` k-means++ seedings + Lloyd runs.
+    Returns (centers [k,D], labels int64 [G], inertia)."""
+    if gen is None:
+        gen = torch.Generator(device=x.device)
+        gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+    best = None
+    for _ in range(max(1, n_init)):
+        c0 = kmeans_plusplus(x, w, k, gen)
+        labels, centers, inertia, _ = lloyd(x, c0, max_iter=max_iter, tol=tol, sample_weight=w)
+        if best is None or inertia < best[2]:
+            best = (centers, labels, inertia)
+    return best
+
+
 class RPHKMeans:
     """device-resident ``rph_kmeans.RPHKMeans`` (constructor arguments and fitted attributes as the library's)"""
 
     def __init__(self, n_clusters=8, n_init=1, w=None, max_point=2000, proj_num=5, max_iter=1000, sample_dist_num=1000,
-                 verbose=0, device=None):
+                 verbose=0, device=None, skeleton_n_init=1):
         self.n_clusters, self.n_init, self.w = n_clusters, n_init, w
+        self.skeleton_n_init = skeleton_n_init          # k-means++ restarts of the skeleton step (sklearn's n_init="auto" is 1)
         self.max_point, self.proj_num, self.max_iter, self.sample_dist_num = max_point, proj_num, max_iter, int(sample_dist_num)
         self.verbose = verbose
         if device is None:
@@ -130,13 +175,13 @@ class RPHKMeans:
         return red, weight, labels, it
 
     def init_centers(self, x: torch.Tensor):
-        from sklearn.cluster import KMeans
+        """(initial centres, reduced points, their weights, sample -> reduced point, reducer iterations, skeleton inertia,
+        skeleton labels) -- the weighted skeleton k-means of rph_kmeans_.py:116-129, on the device"""
         red, weight, labels, it = self.reduce_points(x)
         if red.shape[0] < self.n_clusters:
             raise RuntimeError("Number of reduced points is too small, please try smaller w or larger proj_num")
-        skeleton = KMeans(n_clusters=self.n_clusters)
-        pred = skeleton.fit_predict(red.cpu().numpy(), sample_weight=weight.cpu().numpy())
-        return skeleton.cluster_centers_, red, weight, labels, it, skeleton.inertia_, pred
+        centers, pred, inertia = weighted_kmeans(red, weight, self.n_clusters, n_init=self.skeleton_n_init)
+        return centers, red, weight, labels, it, inertia, pred
 
     # -------------------------------------------------------------- fit
 
@@ -147,11 +192,11 @@ class RPHKMeans:
         self.inertia_ = np.inf
         for _ in range(self.n_init):
             centers0, red, weight, rp_labels, rp_iter, _, _ = self.init_centers(x)
-            labels, centers, inertia, n_iter = lloyd(x, torch.from_numpy(np.asarray(centers0)).to(x))
+            labels, centers, inertia, n_iter = lloyd(x, centers0.to(x))
             if inertia < self.inertia_:
                 self.inertia_ = inertia
                 self.labels_, self.cluster_centers_, self.n_iter_ = labels.cpu().numpy().astype(np.int32), centers.cpu().numpy(), n_iter
-                self.init_centers_, self.reduced_X_, self.reduced_X_weight_ = np.asarray(centers0), red.cpu().numpy(), weight.cpu().numpy()
+                self.init_centers_, self.reduced_X_, self.reduced_X_weight_ = centers0.cpu().numpy(), red.cpu().numpy(), weight.cpu().numpy()
                 self.rp_labels_, self.rp_iter_ = rp_labels.cpu().numpy(), rp_iter
         return self
 

@@ -47,16 +47,53 @@ def test_rph_kmeans_gpu_matches_reference_partition():
     assert len(np.unique(labels)) == k
 
 
-def test_lloyd_distance_step_equals_sklearn():
-    """same start centres -> same fixed point as sklearn's Lloyd (the reference's final step, rph_kmeans_.py:154-155)"""
+def _lloyd_vs_sklearn(device):
     rs = np.random.RandomState(0)
     X = np.concatenate([rs.randn(200, 32) * 0.3 + c for c in rs.randn(5, 32) * 2]).astype(np.float32)
     init = X[rs.choice(len(X), 5, replace=False)]
     sk = KMeans(n_clusters=5, init=init, n_init=1).fit(X)
-    labels, centers, inertia, _ = clustering.lloyd(torch.from_numpy(X), torch.from_numpy(init))
-    assert adjusted_rand_score(sk.labels_, labels.numpy()) == 1.0
-    assert np.allclose(centers.numpy(), sk.cluster_centers_, atol=1e-4)
+    labels, centers, inertia, _ = clustering.lloyd(torch.from_numpy(X).to(device), torch.from_numpy(init).to(device))
+    assert adjusted_rand_score(sk.labels_, labels.cpu().numpy()) == 1.0
+    assert np.allclose(centers.cpu().numpy(), sk.cluster_centers_, atol=1e-4)
     assert abs(inertia - sk.inertia_) <= 1e-3 * sk.inertia_
+
+
+def test_lloyd_distance_step_equals_sklearn():
+    """same start centres -> same fixed point as sklearn's Lloyd (the reference's final step, rph_kmeans_.py:154-155)"""
+    _lloyd_vs_sklearn("cpu")
+
+
+@pytest.mark.gpu
+def test_lloyd_distance_step_equals_sklearn_on_the_gpu():
+    _lloyd_vs_sklearn("cuda:0")
+
+
+def _skeleton_vs_sklearn(device):
+    """the weighted skeleton k-means (k-means++ seeding + weighted Lloyd on the device) against sklearn's weighted KMeans --
+    what the reference calls on the reduced points (rph_kmeans_.py:121-124): same partition, inertia within 2 %"""
+    rs = np.random.RandomState(5)
+    cen = rs.randn(12, 32) * 3
+    X = np.concatenate([rs.randn(150, 32) * 0.4 + c for c in cen]).astype(np.float32)
+    w = rs.randint(1, 60, size=len(X)).astype(np.float32)
+    sk = KMeans(n_clusters=12, n_init=10, random_state=0).fit(X, sample_weight=w)
+    np.random.seed(3)
+    centers, labels, inertia = clustering.weighted_kmeans(torch.from_numpy(X).to(device), torch.from_numpy(w).to(device), 12, n_init=3)
+    assert tuple(centers.shape) == (12, 32) and adjusted_rand_score(sk.labels_, labels.cpu().numpy()) >= 0.99
+    assert inertia <= 1.02 * sk.inertia_
+    # seeding alone already lands one centre per blob most of the time, and never on a zero-weight point
+    w0 = w.copy(); w0[:150] = 0
+    gen = torch.Generator(device=device); gen.manual_seed(1)
+    c0 = clustering.kmeans_plusplus(torch.from_numpy(X).to(device), torch.from_numpy(w0).to(device), 11, gen).cpu().numpy()
+    assert not any((np.abs(X[:150] - c).sum(1) == 0).any() for c in c0)
+
+
+def test_skeleton_kmeans_equals_sklearn():
+    _skeleton_vs_sklearn("cpu")
+
+
+@pytest.mark.gpu
+def test_skeleton_kmeans_equals_sklearn_on_the_gpu():
+    _skeleton_vs_sklearn("cuda:0")
 
 
 def test_cluster_barcode_reads_writes_the_bin_layout(tmp_path):

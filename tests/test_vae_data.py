@@ -141,3 +141,39 @@ def test_graph_captured_training_learns_like_the_eager_loop(tmp_path, monkeypatc
         want = oracle.vae_embedding(state, data.abd, data.tnf)
         assert np.abs(latent - want).max() <= 1e-5 * np.abs(want).max()
     assert abs(finals["1"] - finals["0"]) <= 0.1 * abs(finals["0"]), finals
+
+
+@pytest.mark.gpu
+def test_device_sampling_has_the_reference_distribution_and_numpy_mode_its_sequence(monkeypatch):
+    """device mode: weighted draws by torch.multinomial on the GPU (utils.py:13-21's distribution, another sequence), seeded from
+    numpy's generator; numpy mode: the reference's very sequence"""
+    from pangaea_amd.loader import weighted_batches
+    rs = np.random.RandomState(1)
+    n = 4000
+    w = rs.rand(n) ** 3 + 1e-3
+
+    class D:
+        weights, abd_dev, tnf_dev, bc = w, torch.zeros(n, 2, device="cuda:0"), torch.zeros(n, 2, device="cuda:0"), np.arange(n)
+        def __len__(self): return n
+    # with replacement: frequencies follow the weights
+    np.random.seed(3)
+    draws = np.concatenate([np.asarray(b["bc"]) for _ in range(50) for b in weighted_batches(D(), 512, mode="device")])
+    freq = np.bincount(draws, minlength=n) / len(draws)
+    p = w / w.sum()
+    top = np.argsort(p)[-200:]
+    assert abs(freq[top].sum() - p[top].sum()) < 0.01 and np.corrcoef(freq, p)[0, 1] > 0.97
+    # without replacement: distinct rows, heavy rows come early (successive sampling), reproducible under the numpy seed
+    np.random.seed(4)
+    a = np.concatenate([np.asarray(b["bc"]) for b in weighted_batches(D(), 512, num_samples=2800, replacement=False, mode="device")])
+    np.random.seed(4)
+    b = np.concatenate([np.asarray(b["bc"]) for b in weighted_batches(D(), 512, num_samples=2800, replacement=False, mode="device")])
+    assert len(a) == 2800 and len(set(a.tolist())) == 2800 and np.array_equal(a, b)
+    assert p[a[:400]].mean() > 2 * p[a[-400:]].mean()
+    heavy = np.argsort(p)[-100:]
+    assert np.isin(heavy, a).all()
+    # numpy mode keeps the reference's sequences (also selectable by the environment)
+    monkeypatch.setenv("PANGAEA_SAMPLING", "numpy")
+    np.random.seed(8)
+    got = np.concatenate([np.asarray(b["bc"]) for b in weighted_batches(D(), 512, num_samples=300, replacement=False)])
+    np.random.seed(8)
+    assert list(got) == list(np.random.choice(range(n), size=300, p=w / w.sum(), replace=False))
