@@ -158,6 +158,37 @@ def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
     return [o[:s].to(home) for o, s in zip(out, sizes)]
 
 
+def everyone(flag: bool, group=None) -> bool:
+    """the same answer on every rank: did ALL ranks say yes?  (decisions that select between collectives -- or between doing
+    one and not -- must not be taken rank by rank)"""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())
+
+
+def gather_rows(local: torch.Tensor, dst: int = 0, group=None) -> torch.Tensor | None:
+    """the ranks' row blocks [n_r, D] (any dtype, D equal) stacked in rank order ON RANK ``dst`` only (None elsewhere):
+    how the row-sharded matrices reach the one rank that writes the cache files -- nothing is replicated, nothing is
+    widened (rows travel as they are, padded to the longest block)"""
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    home = local.device
+    staged = _staged(local.contiguous(), group)
+    n = torch.tensor([staged.shape[0]], dtype=torch.int64, device=staged.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(v.item()) for v in sizes]
+    cap = max(max(sizes), 1)
+    buf = staged.new_zeros((cap,) + tuple(staged.shape[1:]))
+    buf[:staged.shape[0]] = staged
+    out = [torch.empty_like(buf) for _ in range(world)] if me == dst else None
+    dist.gather(buf, out, dst=dst, group=group)
+    if me != dst:
+        return None
+    return torch.cat([o[:n_r] for o, n_r in zip(out, sizes)]).to(home)
+
+
 def deferred_group_for(table: KmerTable, local_distinct: int) -> int | None:
     """g for ``table.count(deferred_group=g)``: how many times sparser this rank's keys are than the union the table is
     sized for (as a power of two), or None where the deferred form does not apply"""
@@ -188,7 +219,7 @@ def count_kmers_sharded(stream: ReadStream, k: int, rows=None, group=None, max_l
     def any_full() -> bool:
         # the same answer on every rank, so that all regrow together (a group table in LDS can be full on one rank only);
         # nothing between two collectives may raise on one rank alone
-        flag = (table.status[:1] != 0).to(torch.int32)
+        flag = ((table.status[:1] & 1) != 0).to(torch.int32)         # (bit 1 = overflow list of the exchange: handled there)
         flag = _staged(flag, group)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         return int(flag.item()) != 0
@@ -256,10 +287,7 @@ def _exchange_planes(table: KmerTable, group, me: int, world: int, seg, cuts, at
             works[c].wait()
         table.rebuild_from_planes(bufs[c], stride[c], caps[c], seg_c, (cuts[c], cuts[c + 1]))
     # counts beyond 0xffff: their remainders, from every rank (this one included), as whole entries
-    n = int(n_over.item())
-    if n > overflow.numel():
-        raise RuntimeError(f"exchange overflow list too small ({n} entries)")
-    for part in gather_pairs(overflow[:n].contiguous(), group):
+    for part in _gather_overflow(overflow, n_over, group):
         if part.numel():
             table.merge(part, check=False)
 
@@ -278,10 +306,13 @@ def _all_to_all_flat(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
 
 
 def _gather_overflow(overflow: torch.Tensor, n_over: torch.Tensor, group) -> list[torch.Tensor]:
+    """the ranks' overflow lists (remainders of counts >= 0xffff).  A list that ran over its capacity is an error -- raised on
+    EVERY rank and only after the collective, so no rank is left waiting in it"""
     n = int(n_over.item())
-    if n > overflow.numel():
-        raise RuntimeError(f"exchange overflow list too small ({n} entries)")
-    return gather_pairs(overflow[:n].contiguous(), group)
+    parts = gather_pairs(overflow[:min(n, overflow.numel())].contiguous(), group)
+    if not everyone(n <= overflow.numel(), group):
+        raise RuntimeError(f"exchange overflow list too small (this rank: {n} entries for {overflow.numel()} places)")
+    return parts
 
 
 def _exchange_owner(table: KmerTable, group, me: int, world: int, seg) -> None:

@@ -62,9 +62,27 @@ def frame_like_read_csv(names, mat: np.ndarray) -> pd.DataFrame:
 
 
 def write_csv_gz(path: str, names, mat: np.ndarray) -> None:
+    """the cache file, complete or absent: written next to its place and renamed (a reader -- or a later resume -- never sees
+    a half-written file)"""
     mat = np.ascontiguousarray(mat, dtype=np.int32)
     blob = b"".join(str(n).encode() + b"\0" for n in names)
-    _lib.check(_lib.load().pg_write_csv_gz(path.encode(), blob, mat.ctypes.data, mat.shape[0], mat.shape[1] if mat.ndim == 2 else 0))
+    tmp = f"{path}.tmp{os.getpid()}"
+    try:
+        _lib.check(_lib.load().pg_write_csv_gz(tmp.encode(), blob, mat.ctypes.data, mat.shape[0], mat.shape[1] if mat.ndim == 2 else 0))
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+def to_pickle_atomic(frame: pd.DataFrame, path: str) -> None:
+    tmp = f"{path}.tmp{os.getpid()}"
+    try:
+        frame.to_pickle(tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | None) -> ReadStream:
@@ -75,7 +93,10 @@ def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | Non
         rank = torch.distributed.get_rank() if world > 1 else 0
         cache = f"{stream_cache}.r{rank}of{world}.pgstream"
         newest = max(os.path.getmtime(p) for p in (reads1, reads2) if p)
-        if os.path.exists(cache) and os.path.getmtime(cache) >= newest:
+        fresh = os.path.exists(cache) and os.path.getmtime(cache) >= newest
+        if world > 1:
+            fresh = pdist.everyone(fresh)        # the sharded ingest is a collective: all ranks take the same branch
+        if fresh:
             logging.info(f"packed read stream from {cache}")
             return ReadStream.load(cache)
     part = pdist.ingest_shard(reads1, reads2) if world > 1 else ReadStream.from_fastq(reads1, reads2)
@@ -86,10 +107,15 @@ def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | Non
 
 def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window: int, vsize: int, min_len: int,
                      device=None, want_tnf: bool = True, want_abd: bool = True, table: KmerTable | None = None,
-                     stream_cache: str | None = None, lowercase_is_base: bool = True):
+                     stream_cache: str | None = None, lowercase_is_base: bool = True, gather: str = "all"):
     """(names, tnf int32 ndarray or None, abd int32 ndarray or None) of a barcode-sorted FASTQ, on the GPU.
-    Under an initialised ``torch.distributed`` group every rank takes a contiguous range of runs, the table is
-    exchanged once, and the rows are gathered so every rank returns the full matrices."""
+
+    Under an initialised ``torch.distributed`` group every rank takes a contiguous range of runs and the table is
+    exchanged once; the ROWS stay where they were made.  ``gather``:
+      "none"   every rank returns its own block of rows (rank order = file order);
+      "rank0"  rank 0 additionally receives all blocks (it writes the cache files) and returns
+               (names, tnf, abd, local) with ``local`` = its own block; the other ranks return their block;
+      "all"    every rank returns the full matrices (single-call convenience: the CLI tools)."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     world = torch.distributed.get_world_size() if pdist.is_distributed() else 1
@@ -102,15 +128,35 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     tnf, abd = features(stream, plan, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
                         window=window, vsize=vsize)
     names = list(rows.names)
-    if world > 1:
+    host = lambda t: t.cpu().numpy() if t is not None else None
+    if world == 1 or gather == "none":
+        return names, host(tnf), host(abd)
+    local = (names, host(tnf), host(abd))
+    rank = torch.distributed.get_rank()
+    if gather == "all":
         all_names = [None] * world
         torch.distributed.all_gather_object(all_names, names)
-        names = [n for part_names in all_names for n in part_names]
-        if tnf is not None:
-            tnf = torch.cat([p.view(-1, tnf.shape[1]) for p in pdist.gather_pairs(tnf.reshape(-1).to(torch.int64))]).to(torch.int32)
-        if abd is not None:
-            abd = torch.cat([p.view(-1, abd.shape[1]) for p in pdist.gather_pairs(abd.reshape(-1).to(torch.int64))]).to(torch.int32)
-    return names, (tnf.cpu().numpy() if tnf is not None else None), (abd.cpu().numpy() if abd is not None else None)
+        full_names = [n for part in all_names for n in part]
+        sizes = [len(part) for part in all_names]
+        full = []
+        for m in (tnf, abd):
+            if m is None:
+                full.append(None)
+                continue
+            got = None
+            for dst in range(world):                     # (rare path: one gather per destination, rows stay int32)
+                part = pdist.gather_rows(m, dst=dst)
+                got = part if dst == rank else got
+            assert got.shape[0] == sum(sizes)
+            full.append(host(got))
+        return full_names, full[0], full[1]
+    gathered_names = [None] * world if rank == 0 else None
+    torch.distributed.gather_object(names, gathered_names, dst=0)
+    g_tnf = pdist.gather_rows(tnf, dst=0) if tnf is not None else None
+    g_abd = pdist.gather_rows(abd, dst=0) if abd is not None else None
+    if rank != 0:
+        return local
+    return [n for part in gathered_names for n in part], host(g_tnf), host(g_abd), local
 
 
 class Feature:
@@ -126,6 +172,11 @@ class Feature:
         self.feature_dir = os.path.join(args.output, "1.features")
         os.makedirs(self.feature_dir, exist_ok=True)
         self._cache = None          # (names, tnf int32, abd int32) of the fused GPU pass
+        # several ranks (torchrun): every rank computes the rows of its own runs; rank 0 alone receives all rows and writes the
+        # cache files and the marker; ``local`` keeps this rank's block (names, tnf, abd) for the replicated encode of step 2
+        self.world = torch.distributed.get_world_size() if pdist.is_distributed() else 1
+        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        self.local = None
 
     # ------------------------------------------------------------------ paths (same names as the reference)
 
@@ -150,24 +201,56 @@ class Feature:
             logging.info("GPU feature pass: ingest + k-mer table + TNF/abundance rows")
             # PANGAEA_STREAM_CACHE=1 keeps the packed read stream next to the feature caches (1.features/reads.*.pgstream)
             cache = os.path.join(self.feature_dir, "reads") if os.environ.get("PANGAEA_STREAM_CACHE", "0") not in ("", "0") else None
-            self._cache = compute_features(r1, r2, int(self.kmer), int(self.tnf_k), int(self.ws), int(self.vs), int(self.minl),
+            out = compute_features(r1, r2, int(self.kmer), int(self.tnf_k), int(self.ws), int(self.vs), int(self.minl),
                                            device=getattr(self.args, "device", None), want_tnf=want_tnf, want_abd=want_abd,
-                                           stream_cache=cache,
+                                           stream_cache=cache, gather="rank0",
                                            # jellyfish's rules for the multiplicity table (feature.py:76-94): lower-case bases
                                            # count (soft-masked input; PANGAEA_LOWERCASE_IS_BASE=0 turns that off), bases
                                            # below --min-qual-char=? of paired files do not (ReadStream.table_valid)
                                            lowercase_is_base=os.environ.get("PANGAEA_LOWERCASE_IS_BASE", "1") not in ("", "0"))
+            if self.world > 1:
+                self.local = out[3] if self.rank == 0 else out
+                out = out[:3]
+            self._cache = out
         return self._cache
 
     # ------------------------------------------------------------------ the reference's public methods
 
     def extract_features(self):
+        if self.world > 1:
+            return self._extract_features_sharded()
         readnames1, abundance = self.run_jellyfish()
         readnames2, tnf = self.calcu_tnf()
         assert (readnames1 == readnames2).all()
         with open(os.path.join(self.feature_dir, "feature_finished"), "w") as f:
             f.write("feature finished")
         return readnames1, abundance, tnf
+
+    def _extract_features_sharded(self):
+        """several ranks: the GPU pass is collective (sharded ingest, one table exchange, rows gathered to rank 0); the files
+        are rank 0's business alone -- the others wait for the marker's barrier and return their own block of rows in the
+        reference's types (what pandas would have read back)"""
+        abd_gz, abd_pkl = self._abd_paths()
+        tnf_gz, tnf_pkl = self._tnf_paths()
+        have = all(os.path.isfile(p) for p in (abd_gz, abd_pkl, tnf_gz, tnf_pkl))
+        if not pdist.everyone(have):                 # (a collective decision: no rank may skip the pass on its own)
+            self._compute()
+        result = None
+        if self.rank == 0:
+            readnames1, abundance = self.run_jellyfish()
+            readnames2, tnf = self.calcu_tnf()
+            assert (readnames1 == readnames2).all()
+            with open(os.path.join(self.feature_dir, "feature_finished"), "w") as f:
+                f.write("feature finished")
+            result = (readnames1, abundance, tnf)
+        torch.distributed.barrier()                  # the caches and the marker are complete before anybody moves on
+        if self.rank != 0:
+            if self.local is None:
+                return np.zeros(0, dtype=object), np.zeros((0, int(self.vs)), dtype=np.int64), np.zeros((0, 0), dtype=np.int64)
+            names, tnf, abd = self.local
+            fa, ft = frame_like_read_csv(names, abd), frame_like_read_csv(names, tnf)
+            result = (fa[0].to_numpy(), fa.drop(columns=0).to_numpy(), ft.drop(columns=0).to_numpy())
+        return result
 
     def _materialise(self, gz: str, pkl: str, which: int, what: str):
         """the reference's per-artifact resume logic (feature.py:104-123, 129-146): write <cache>.gz unless it is
@@ -181,7 +264,7 @@ class Feature:
             fresh = frame_like_read_csv(names, mat)
         if not os.path.isfile(pkl):
             frame = fresh if fresh is not None else pd.read_csv(gz, header=None)
-            frame.to_pickle(pkl)
+            to_pickle_atomic(frame, pkl)
         else:
             logging.info(f"load {what}")
             frame = pd.read_pickle(pkl)

@@ -180,7 +180,15 @@ class VAENET:
 
     # ------------------------------------------------------------------ train (VAENET.py:31-149)
 
-    def train(self, train_loader, val_loader, dataloader, model_path, patience):
+    @staticmethod
+    def write_latent(model_path: str, embedding, barcodes) -> None:
+        """``latent.npz`` / ``barcodes.npz`` / ``model_finished`` as the reference's train() leaves them (VAENET.py:128-149)"""
+        np.savez(os.path.join(model_path, "barcodes.npz"), barcodes)
+        np.savez(os.path.join(model_path, "latent.npz"), embedding)
+        with open(os.path.join(model_path, "model_finished"), "w") as f:
+            f.write("model finished")
+
+    def train(self, train_loader, val_loader, dataloader, model_path, patience, encode: bool = True):
         if not os.path.isdir(model_path):
             raise Exception("model path not exist")
         train_model = os.path.join(model_path, "train_model.pk")
@@ -260,6 +268,8 @@ class VAENET:
         else:
             logging.info("trainning model already saved")
 
+        if not encode:                  # several ranks: the rows are encoded where they lie (pangaea.run), the files follow there
+            return
         latent_path = os.path.join(model_path, "latent.npz")
         barcodes_path = os.path.join(model_path, "barcodes.npz")
         if not os.path.exists(latent_path) or not os.path.exists(barcodes_path):

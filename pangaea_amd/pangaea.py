@@ -73,7 +73,50 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
+def _encode_sharded(args, feat, vae, model_path) -> None:
+    """step 2's encode on several ranks: the rows never left the rank that made them, so every rank normalises
+    and encodes its own block with a replica of the trained network (2.2 MB of weights travel, not gigabytes of count
+    matrices), and only ``mu`` [N, 32] and the names are gathered on rank 0, which writes the reference's files"""
+    import torch.distributed as dist
+    from . import dist as pdist
+    from .data import Data
+    from .models.VAENET import VAENET
+    rank = dist.get_rank()
+    names, tnf, abd = feat.local
+    if rank == 0:
+        state = {k: v.cpu() for k, v in torch.load(os.path.join(model_path, "train_model.pk"), map_location="cpu").items()}
+        box = [state]
+    else:
+        box = [None]
+        vae = VAENET(abd_dim=abd.shape[1], tnf_dim=tnf.shape[1], latent_size=args.latent_dim, num_classes=args.clusters,
+                     epochs=args.epochs, cuda=torch.cuda.is_available(), num_gpus=args.num_gpus, lr=args.lr, dropout=args.dropout,
+                     alpha=args.weight_alpha, w_kl=args.weight_kl, weight_decay=args.weight_decay)
+    dist.broadcast_object_list(box, src=0)
+    vae.network.load_state_dict(box[0])
+    vae.network.eval()
+    mu = vae.encode(Data(np.asarray(names, dtype=object), abd, tnf))
+    all_mu = pdist.gather_rows(mu, dst=0)
+    gathered = [None] * dist.get_world_size() if rank == 0 else None
+    dist.gather_object(list(names), gathered, dst=0)
+    if rank == 0:
+        VAENET.write_latent(model_path, all_mu.cpu().numpy(), [n for part in gathered for n in part])
+
+
 def run(args, script_path):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        torch.distributed.init_process_group(os.environ.get("PANGAEA_DIST_BACKEND", "nccl"))
+    try:
+        _run(args, script_path)
+    finally:
+        if torch.distributed.is_initialized():      # every rank leaves together, and leaves the group behind it
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+
+
+def _run(args, script_path):
+    from . import dist as pdist
     from .clustering import cluster_barcode_reads
     from .data import Data
     from .feature import Feature
@@ -81,51 +124,66 @@ def run(args, script_path):
     from .models.VAENET import VAENET
     from .utils import init_all
 
-    init_all(seed=2021, threads=min(args.threads, os.cpu_count() or 1), logfile="log", level=logging.INFO, outdir=args.output)
+    multi = pdist.is_distributed()
+    rank0 = not multi or torch.distributed.get_rank() == 0
+    init_all(seed=2021, threads=min(args.threads, os.cpu_count() or 1), logfile="log", level=logging.INFO, outdir=args.output,
+             file_log=rank0)
     logging.info("command: " + " ".join(sys.argv))
     logging.info(args)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group("nccl")
-    rank0 = not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0
 
     model_path = os.path.join(args.output, "2.vae")
     cluster_path = os.path.join(args.output, "3.clustering")
     assembly_path = os.path.join(args.output, "4.assembly")
     have_reads = (args.reads1 and args.reads2) or args.interleaved_reads
     read_specify = abundance = tnf = None
+    feat = None
 
-    # step 1: feature extraction (every rank takes part; the rest of the steps run on rank 0)
+    def agreed(flag: bool) -> bool:
+        """rank 0's reading of the output directory decides for everybody (the steps' collectives need all ranks)"""
+        if not multi:
+            return flag
+        box = [flag]
+        torch.distributed.broadcast_object_list(box, src=0)
+        return bool(box[0])
+
+    # step 1: feature extraction (every rank takes part: its own runs, one table exchange; rank 0 writes the caches)
     if not check_steps_required(args.steps, "1"):
         logging.info("skip step 1: feature extraction")
-    elif check_steps_finish(args, "1"):
+    elif agreed(check_steps_finish(args, "1")):
         logging.info("step 1: feature extraction finished")
     elif have_reads:
-        read_specify, abundance, tnf = Feature(args, script_path).extract_features()
+        feat = Feature(args, script_path)
+        read_specify, abundance, tnf = feat.extract_features()
     else:
         print("Please provide one or two input file(s):-1 and -2 for pair-end linked reads; -lr as long reads; -i for interleaved linked reads.")
         sys.exit()
-    if not rank0:
-        return
 
-    # step 2: training
+    # step 2: training (rank 0: the loop is small and sequential) + encode (every rank, its own rows)
     if not check_steps_required(args.steps, "2"):
         logging.info("skip step 2: training")
-    elif check_steps_finish(args, "2"):
+    elif agreed(check_steps_finish(args, "2")):
         logging.info("step 2: training finished")
     else:
-        if not all(isinstance(a, np.ndarray) for a in (read_specify, abundance, tnf)):
-            read_specify, abundance, tnf = Feature(args, script_path).load_features()
-        dataset = Data(read_specify, abundance, tnf)
-        test_size = min(int(len(dataset) * 0.7), 1000000)
-        train = weighted_batches(dataset, args.batch_size)
-        test = weighted_batches(dataset, args.batch_size, num_samples=test_size, replacement=False)
-        original = shuffled_batches(dataset, args.batch_size)
-        os.makedirs(model_path, exist_ok=True)
-        vae = VAENET(abd_dim=abundance.shape[1], tnf_dim=tnf.shape[1], latent_size=args.latent_dim, num_classes=args.clusters,
-                     epochs=args.epochs, cuda=True, num_gpus=args.num_gpus, lr=args.lr, dropout=args.dropout,
-                     alpha=args.weight_alpha, w_kl=args.weight_kl, weight_decay=args.weight_decay)
-        vae.train(train, test, original, model_path, args.patience)
+        # rows still sharded in memory on every rank -> replicated encode; otherwise (resume from the cache files) rank 0 alone
+        sharded = multi and pdist.everyone(feat is not None and feat.local is not None)
+        vae = None
+        if rank0:
+            if not all(isinstance(a, np.ndarray) for a in (read_specify, abundance, tnf)):
+                read_specify, abundance, tnf = Feature(args, script_path).load_features()
+            dataset = Data(read_specify, abundance, tnf)
+            test_size = min(int(len(dataset) * 0.7), 1000000)
+            train = weighted_batches(dataset, args.batch_size)
+            test = weighted_batches(dataset, args.batch_size, num_samples=test_size, replacement=False)
+            original = shuffled_batches(dataset, args.batch_size)
+            os.makedirs(model_path, exist_ok=True)
+            vae = VAENET(abd_dim=abundance.shape[1], tnf_dim=tnf.shape[1], latent_size=args.latent_dim, num_classes=args.clusters,
+                         epochs=args.epochs, cuda=True, num_gpus=args.num_gpus, lr=args.lr, dropout=args.dropout,
+                         alpha=args.weight_alpha, w_kl=args.weight_kl, weight_decay=args.weight_decay)
+            vae.train(train, test, original, model_path, args.patience, encode=not sharded)
+        if sharded:
+            _encode_sharded(args, feat, vae, model_path)
+    if not rank0:
+        return
 
     # step 3: clustering
     if not check_steps_required(args.steps, "3"):

@@ -68,9 +68,10 @@ def run_cmd(command, log_file=None) -> None:
     logging.info("finished: %s", line)
 
 
-def init_all(seed, threads, logfile, level, outdir) -> None:
+def init_all(seed, threads, logfile, level, outdir, file_log: bool = True) -> None:
     """seed numpy and torch (the samplers and the network initialisation take their randomness from there), bound torch's
-    host threads, create the output directory and send log records of ``level`` and above to ``outdir/logfile`` and stderr"""
+    host threads, create the output directory and send log records of ``level`` and above to ``outdir/logfile`` and stderr
+    (``file_log`` False: stderr only -- of several ranks sharing one output directory only the first writes the file)"""
     for seeder in (np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all):
         seeder(seed)
     torch.set_num_threads(threads)
@@ -78,7 +79,7 @@ def init_all(seed, threads, logfile, level, outdir) -> None:
     log = logging.getLogger()
     log.setLevel(level)
     layout = logging.Formatter("%(asctime)s (%(levelname)s): %(message)s", "%Y-%m-%d %H:%M:%S")
-    for sink in (logging.FileHandler(os.path.join(outdir, logfile)), logging.StreamHandler()):
+    for sink in ([logging.FileHandler(os.path.join(outdir, logfile))] if file_log else []) + [logging.StreamHandler()]:
         sink.setLevel(level)
         sink.setFormatter(layout)
         log.addHandler(sink)

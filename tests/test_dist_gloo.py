@@ -266,3 +266,108 @@ def test_owner_partitioned_exchange(tmp_path, world):
     """from four ranks on the partial tables are reduced at bucket-range owners (all-to-all, LDS rebuild of the owned range)
     and the merged ranges are all-gathered; every rank ends with the table of the whole stream (3 ranks: uneven ranges)"""
     _check_exchange(tmp_path, world, "planes")
+
+
+# ------------------------------------------------------------------ rows stay sharded; rank 0 writes; encode is replicated
+
+
+def _rows_worker(rank, world, port, tmp):
+    _init(rank, world, port)
+    try:
+        # blocks of different lengths and dtypes reach rank 0 as they are (no widening, no replication)
+        for dtype, width in ((torch.int32, 7), (torch.float32, 32), (torch.int64, 1)):
+            n = [5, 0, 9][rank % 3]
+            mine = (torch.arange(n * width).reshape(n, width) + 1000 * rank).to(dtype)
+            got = pdist.gather_rows(mine, dst=0)
+            if rank == 0:
+                want = torch.cat([(torch.arange([5, 0, 9][r % 3] * width).reshape(-1, width) + 1000 * r).to(dtype) for r in range(world)])
+                assert got.dtype == dtype and torch.equal(got, want)
+            else:
+                assert got is None
+        assert pdist.everyone(True) and not pdist.everyone(rank != 1)
+        # the replicated encode of pangaea.run: every rank encodes its own rows with rank 0's weights, mu gathered on rank 0
+        import argparse
+        from pangaea_amd import pangaea
+        from pangaea_amd.data import Data
+        from pangaea_amd.models.VAENET import VAENET
+        rs = np.random.RandomState(7)
+        abd = rs.poisson(2.0, size=(37, 400)).astype(np.int32)
+        tnf = rs.poisson(30.0, size=(37, 136)).astype(np.int32)
+        names = [f"bc{i:03d}" for i in range(37)]
+        cut = [0, 11, 37] if world == 2 else [0, 11, 20, 37]
+        args = argparse.Namespace(latent_dim=32, clusters=5, epochs=1, num_gpus=1, lr=0.005, dropout=0.2, weight_alpha=0.1,
+                                  weight_kl=0.015, weight_decay=0.0001)
+        model = os.path.join(tmp, "2.vae")
+        vae = None
+        if rank == 0:
+            os.makedirs(model, exist_ok=True)
+            torch.manual_seed(5)
+            vae = VAENET(400, 136, 32, 5, 1, False, 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+            torch.save(vae.network.state_dict(), os.path.join(model, "train_model.pk"))
+        dist.barrier()
+
+        class Feat:
+            local = (names[cut[rank]:cut[rank + 1]], tnf[cut[rank]:cut[rank + 1]], abd[cut[rank]:cut[rank + 1]])
+        pangaea._encode_sharded(args, Feat, vae, model)
+        dist.barrier()
+        if rank == 0:
+            latent = np.load(os.path.join(model, "latent.npz"))["arr_0"]
+            bcs = np.load(os.path.join(model, "barcodes.npz"))["arr_0"]
+            assert list(bcs) == names and os.path.isfile(os.path.join(model, "model_finished"))
+            vae.network.eval()
+            whole = vae.encode(Data(np.array(names, dtype=object), abd, tnf, device="cpu")).numpy()
+            assert latent.shape == (37, 32) and np.abs(latent - whole).max() <= 1e-5 * np.abs(whole).max()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rows_stay_sharded_and_the_encode_is_replicated(world, tmp_path):
+    _spawn(_rows_worker, world, str(tmp_path))
+
+
+def _pipeline_worker(rank, world, port, fq, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      PANGAEA_DIST_BACKEND="gloo")
+    from pangaea_amd import pangaea
+    pangaea.main(["-i", fq, "-o", out, "-c", "4", "-k", "21", "-l", "2000", "-e", "2", "-b", "32", "-st", "1,2,3", "-t", "2"])
+    assert not dist.is_initialized()                    # every rank left the group behind
+
+
+@pytest.mark.gpu
+def test_two_rank_pipeline_on_a_shared_output_directory(tmp_path):
+    """torchrun-style run of the orchestrator with two ranks (gloo, sharing cuda:0) into ONE output directory: the cache
+    files are those of a one-rank run (rank 0 alone writes them, complete), the rows are the oracle's, latent.npz holds
+    every barcode once in file order and equals the saved network's encode of the whole matrices"""
+    import pandas as pd
+    from pangaea_amd import pangaea
+    from pangaea_amd.data import Data
+    from pangaea_amd.models.VAENET import VAENET
+    cfg = synth.SynthConfig(n_pairs=6000, n_barcodes=120, n_genomes=4, genome_len=100_000, fragment=20_000, seed=3)
+    s = synth.generate(cfg)
+    fq = str(tmp_path / "reads.sorted.fastq")
+    synth.write_fastq(s, cfg, fq)
+    out2, out1 = str(tmp_path / "two"), str(tmp_path / "one")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), fq, out2), nprocs=2, join=True)
+    pangaea.main(["-i", fq, "-o", out1, "-c", "4", "-k", "21", "-l", "2000", "-e", "2", "-b", "32", "-st", "1", "-t", "2"])
+    for fn in ("tnf.m2000.gz", "abundance.k21.v400.w10.m2000.gz"):
+        a = pd.read_csv(os.path.join(out1, "1.features", fn), header=None)
+        b = pd.read_csv(os.path.join(out2, "1.features", fn), header=None)
+        assert a.equals(b), fn
+    assert not [f for f in os.listdir(os.path.join(out2, "1.features")) if ".tmp" in f]
+    rd = oracle.Reads(fq)
+    table = oracle.Table(21, threads=4).count(rd.all_seq())
+    onames, otnf, oabd = rd.features(2000, k_tnf=4, k_abd=21, table=table, window=10, vsize=400, threads=4)
+    abd = pd.read_pickle(os.path.join(out2, "1.features", "abundance.k21.v400.w10.m2000.pkl"))
+    tnf = pd.read_pickle(os.path.join(out2, "1.features", "tnf.m2000.pkl"))
+    assert list(abd[0]) == onames and np.array_equal(abd.drop(columns=0).to_numpy(), oabd) and np.array_equal(tnf.drop(columns=0).to_numpy(), otnf)
+    latent = np.load(os.path.join(out2, "2.vae/latent.npz"))["arr_0"]
+    bcs = np.load(os.path.join(out2, "2.vae/barcodes.npz"))["arr_0"]
+    assert list(bcs) == onames and latent.shape == (120, 32)
+    vae = VAENET(400, 136, 32, 4, 2, True, 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+    vae.network.load_state_dict(torch.load(os.path.join(out2, "2.vae/train_model.pk"), map_location="cuda:0"))
+    vae.network.eval()
+    whole = vae.encode(Data(np.array(onames, dtype=object), oabd, otnf)).cpu().numpy()
+    assert np.abs(latent - whole).max() <= 1e-5 * np.abs(whole).max()
+    for rel in ("3.clustering/clusters.tsv", "3.clustering/clustering_finished", "2.vae/model_finished", "log"):
+        assert os.path.isfile(os.path.join(out2, rel)), rel
