@@ -25,6 +25,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #   scatter_stream                  two lanes share each 8-byte word; reports the 1.13 GB as it is   -> x1
 #   features<HASH> / kmer_count     one random 8-byte slot per lane = one 64-B request each          -> x1
 KERNELS = [
+    # the super-k-mer pipeline (one GPU).  Factors by the same calibration: mini_scatter2 reads n_records x 12 B (8-B and 4-B
+    # coalesced loads: the 8-B plane is the bulk) and mini_count streams the same planes plus the 4-B provisional words
+    ("mini_plan_kernel", "plan (outside the step)", 2.0), ("round_rows_kernel", "plan (outside the step)", 1.0),
+    ("mini_total_kernel", "plan (outside the step)", 1.0), ("distinct_sketch_kernel", "plan (outside the step)", 2.0),
+    ("mini_scatter_kernel", "kmer_count+lookup", 2.0), ("mini_scatter2_kernel", "kmer_count+lookup", 2.0),
+    ("mini_count_kernel", "kmer_count+lookup", 2.0),
     ("bucket_hist_kernel", "kmer_count", 2.0), ("scan_kernel", "kmer_count", 1.0), ("digit_scan_kernel", "kmer_count", 1.0),
     ("tile_rows_kernel", "kmer_count", 1.0), ("scatter_stream_kernel", "kmer_count", 1.0),
     ("scatter_records_kernel<unsigned long", "kmer_count", 2.0), ("bucket_count_kernel", "kmer_count", 2.0),
@@ -54,6 +60,7 @@ def info(key):
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
     pairs = int(sys.argv[5]) if len(sys.argv) > 5 else 10_000_000
+    pipeline = sys.argv[6] if len(sys.argv) > 6 else "mini"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     rows = list(csv.DictReader(open(sorted(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")))[-1])))
@@ -78,16 +85,25 @@ def main():
     for k, e in detail.items():
         stage, corr = info(k)
         e["fetch_correction"] = corr
-        e["hbm_bytes"] = (e["FETCH_SIZE_KB"] * corr + e["WRITE_SIZE_KB"]) * 1024
+        e["raw_bytes"] = (e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024          # the counters as they are
+        e["hbm_bytes"] = (e["FETCH_SIZE_KB"] * corr + e["WRITE_SIZE_KB"]) * 1024    # an ESTIMATE: see the note
+        e["stage"] = stage
         stages[stage] = stages.get(stage, 0.0) + e["hbm_bytes"]
     if "kmer_count+lookup" in stages:                  # fused run: the stage is the whole K2 pipeline with the lookups inside
         stages["kmer_count+lookup"] += stages.pop("kmer_count", 0.0)
-    json.dump({"pairs": pairs, "tag": tag,
+    raw_stages = {}
+    for e in detail.values():
+        raw_stages[e["stage"]] = raw_stages.get(e["stage"], 0.0) + e["raw_bytes"]
+    if "kmer_count+lookup" in raw_stages and "kmer_count" in raw_stages:
+        raw_stages["kmer_count+lookup"] += raw_stages.pop("kmer_count")
+    json.dump({"pairs": pairs, "tag": tag, "pipeline": pipeline, "kernels_raw": raw_stages,
                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around bench.py --steps 1 --warmup 0",
-               "note": "counters are KiB; per kernel: hbm_bytes = (FETCH_SIZE x fetch_correction + WRITE_SIZE) x 1024; "
-                       "fetch_correction = 2 for kernels whose reads are coalesced streams (gfx950 FETCH_SIZE counts 64 B per "
-                       "128-B request; calibrated on known byte counts, see tools/collect_profiles.py), 1 otherwise; stages sum "
-                       "their kernels' launches of one step",
+               "note": "counters are KiB; per kernel: raw_bytes = (FETCH_SIZE + WRITE_SIZE) x 1024 as counted; hbm_bytes = (FETCH_SIZE x "
+                       "fetch_correction + WRITE_SIZE) x 1024 is an ESTIMATE: fetch_correction = 2 for kernels whose reads are "
+                       "coalesced streams (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced "
+                       "read), 1 otherwise; checked against byte counts that are known exactly -- mini_scatter2 reads n_records x 12 B, "
+                       "scatter_records<unsigned long> 2.6e9 x 8 B -- see tools/collect_profiles.py.  'kernels' = estimate per stage "
+                       "(what bench.py reports as roofline.traffic), 'kernels_raw' = the raw sum; stages sum their kernels' launches of one step",
                "detail": detail, "kernels": stages}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     for k, e in sorted(detail.items()):
         print(f"{k:40s} fetch {e['FETCH_SIZE_KB']*1024/1e9:8.2f} GB (x{e['fetch_correction']:.0f})  write {e['WRITE_SIZE_KB']*1024/1e9:8.2f} GB")
