@@ -11,7 +11,7 @@ from .conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("extra", [[], ["--no-fuse"], ["--rehearse-dist", "4"]])
+@pytest.mark.parametrize("extra", [[], ["--no-mini"], ["--no-fuse"], ["--rehearse-dist", "4"]])
 def test_bench_line_honours_the_contract(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "200000", "--steps", "2", "--warmup", "1", "--cpu-sample", "2000"] + extra
     if extra:
@@ -34,3 +34,23 @@ def test_bench_line_honours_the_contract(extra):
     if not extra:
         c = j["cpu_baseline"]
         assert c["unit"] == "pairs/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+        assert "super-k-mer" in j["config"]["pipeline"]
+    if extra in ([], ["--no-mini"]):
+        e = j["e2e"]                                    # the FASTQ -> mu leg, reported beside the device-resident value
+        assert e["unit"] == "pairs/s" and e["value"] > 0 and e["pairs"] == 200000 and e["host_threads"] >= 1
+        assert set(e["seconds"]) == {"ingest", "h2d", "table+rows", "normalise+encode"} and e["value"] < j["value"]
+
+
+def test_bench_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it: two rank processes, one JSON line with n_gpus 2 (gloo here: the
+    two ranks share the one GPU of the box, which RCCL does not allow)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "200000", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "exchange" in j["kernel_ms"]
+    assert abs(j["value"] - 2 * 200000 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
