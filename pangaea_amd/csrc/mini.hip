@@ -109,8 +109,14 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
     uint32_t win[W];                                            // win[0] = newest hashed canonical M-mer
 #pragma unroll
     for (int i = 0; i < W; ++i) win[i] = 0xffffffffu;
-    // pre-roll the k - 1 characters before the word; the M-mers that end at the last W - 1 of them are complete
-    for (int c = 33 - k; c < 32; ++c) {
+    // pre-roll the k - 1 characters before the word; only the M-mers that end at the last W - 1 of them are complete (and wanted)
+    for (int c = 33 - k; c < 33 - W; ++c) {
+        const uint32_t ch = (uint32_t)(x.pw >> (2 * c)) & 3u;
+        fwm = ((fwm << 2) | ch) & MINI_MMASK;
+        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
+    }
+#pragma unroll
+    for (int c = 33 - W; c < 32; ++c) {
         const uint32_t ch = (uint32_t)(x.pw >> (2 * c)) & 3u;
         fwm = ((fwm << 2) | ch) & MINI_MMASK;
         rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
@@ -119,10 +125,11 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
         win[0] = mhash(fwm < rcm ? fwm : rcm);
     }
     // a k-mer may continue the open record if it is valid, of the same kind (row-counting or not) as its predecessor and
-    // no row boundary lies at its last character
+    // no row boundary lies at its last character -- and if it has the same minimizer (its bucket follows from that: the bucket
+    // is computed once per record, not per character)
     const uint32_t same = ok & (ok << 1) & ~(ok_row ^ (ok_row << 1)) & ~cuts;
-    int n = 0;                                                  // k-mers of the open record (bucket cur_b)
-    uint32_t cur_b = 0;
+    int n = 0;                                                  // k-mers of the open record (minimizer value cur_mv)
+    uint32_t cur_mv = 0;
 #pragma unroll
     for (int p = 0; p < 32; ++p) {
         const uint32_t ch = (uint32_t)(x.cw >> (2 * p)) & 3u;
@@ -134,15 +141,14 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
         uint32_t mv = win[0];
 #pragma unroll
         for (int i = 1; i < W; ++i) mv = win[i] < mv ? win[i] : mv;
-        const uint32_t b = mini_bucket(mv, bits);
         const bool v = (ok >> p) & 1u;
         // the open record ends at p - 1 unless this k-mer continues it (a record cannot end before the word starts)
-        const bool cont = ((same >> p) & 1u) && n > 0 && b == cur_b && n < cap;
-        if (p > 0 && n > 0 && !cont) emit(p > 0 ? p - 1 : 0, n, cur_b);
+        const bool cont = ((same >> p) & 1u) && n > 0 && mv == cur_mv && n < cap;
+        if (p > 0 && n > 0 && !cont) emit(p > 0 ? p - 1 : 0, n, mini_bucket(cur_mv, bits));
         n = cont ? n + 1 : (v ? 1 : 0);
-        cur_b = b;
+        cur_mv = mv;
     }
-    if (n > 0) emit(31, n, cur_b);
+    if (n > 0) emit(31, n, mini_bucket(cur_mv, bits));
 }
 
 // what a lane needs to segment word w: the word, its valid k-mer ends under the counting rule and under the rows' strict rule

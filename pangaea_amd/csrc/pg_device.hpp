@@ -111,12 +111,15 @@ constexpr int MINI_M = PG_MINI_M;
 constexpr uint32_t MINI_MMASK = (1u << (2 * MINI_M)) - 1u;
 constexpr uint32_t MINI_MCOMP = 0xAAAAAAAAu & MINI_MMASK;
 
-// a bijection of 32-bit words (odd multipliers, xorshifts): distinct canonical M-mers have distinct values, so "the
-// smallest value" picks the same M-mer on both strands
+// a bijection of 32-bit words (xor with a constant, three xorshifts: every step is invertible): distinct canonical M-mers have
+// distinct values, so "the smallest value" picks the same M-mer on both strands.  No multiplies: this runs once per character
+// of the stream, and 32-bit integer multiplies issue at a quarter of the rate of shifts and xors.
 __device__ __forceinline__ uint32_t mhash(uint32_t x)
 {
-    x *= 0x9E3779B1u; x ^= x >> 15;
-    x *= 0x85EBCA77u; x ^= x >> 13;
+    x ^= 0x9E3779B9u;               // (poly-A must not be the smallest value of all)
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
     return x;
 }
 // bucket of a minimizer value (the value itself is biased towards small numbers: mix once more, take the top bits)
