@@ -2272,28 +2272,61 @@ static int abundance_impl(const pg_table *t, const pg_rows *rows, int window, in
     return shuffle_tail(sp, off, nb, rows, vsize, abd_out, ws, s);
 }
 
-// S2 + S3: the (row, bin) words of every bucket b, words_e[in_begin[b] .. emit_end[b]), -> rows of the abundance matrix
-static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begin, int nb, const pg_rows *rows, int vsize,
-                        int32_t *abd_out, char *ws, hipStream_t s)
+// S2 + S3: the (row, bin) words of every bucket b, words_e[in_begin[b] .. emit_end[b]), -> rows of the abundance matrix.
+// Three parts so that a lookup pass which scatters its words by row group itself (mini.hip) can take the first pass's place:
+//   prepare   row-group capacities -> offsets of the group regions, cursors cleared
+//   pass one  scatter by the first gb1 bits of the row group
+//   finish    the second pass (more than 2^10 groups only) and the LDS row histograms
+static int shuffle_prepare(const ShufflePlan &sp, const pg_rows *rows, char *ws, hipStream_t s)
 {
-    int rc;
-    auto *emit_end = (unsigned long long *)(ws + sp.emit_off);
     auto *caps = (unsigned long long *)(ws + sp.caps_off);
     auto *goff = (unsigned long long *)(ws + sp.goff_off);
-    auto *gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
-    auto *gcur2 = (unsigned long long *)(ws + sp.gcur2_off);
-    auto *words_e = (uint32_t *)(ws + sp.words_e_off);
-    auto *words_a = (uint32_t *)(ws + sp.words_a_off);
-    auto *words_b = (uint32_t *)(ws + sp.words_b_off);
-    const unsigned long long *off = in_begin;
-    const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
-    if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
     if (hipMemsetAsync(ws + sp.caps_off, 0, sp.dhist_off - sp.caps_off, s) != hipSuccess)
         return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
-    // row-group capacities -> offsets of the group regions
     hipLaunchKernelGGL(group_caps_kernel, dim3((unsigned)((sp.n_groups_padded + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_start, rows->row_end,
                        rows->n_rows, sp.n_groups_padded, caps);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)caps, sp.n_groups_padded, goff);
+    return check_launch("pg_abundance_from_records");
+}
+
+static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize, int32_t *abd_out, char *ws, hipStream_t s)
+{
+    int rc;
+    auto *goff = (unsigned long long *)(ws + sp.goff_off);
+    auto *gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
+    auto *gcur2 = (unsigned long long *)(ws + sp.gcur2_off);
+    auto *words_a = (uint32_t *)(ws + sp.words_a_off);
+    auto *words_b = (uint32_t *)(ws + sp.words_b_off);
+    const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
+    if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
+    const int gshift = sp.vbits + GROUP_ROWS_LOG2;
+    const unsigned long long *gcnt = gcur1;
+    const uint32_t *final_words = words_a;
+    if (sp.gb2) {
+        const int tiles_x = 64;
+        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32, MAX_FAN_BITS>), dim3((unsigned)(tiles_x << sp.gb1)), dim3(BLOCK), 0, s,
+                           (const uint32_t *)words_a, (const unsigned long long *)goff, (const unsigned long long *)nullptr, sp.gb2,
+                           (const unsigned long long *)gcur1, tiles_x, words_b, (const unsigned long long *)goff, gcur2, 0, 0, sp.gb2, gshift);
+        gcnt = gcur2;
+        final_words = words_b;
+    }
+    // S3: LDS row histograms -> rows of the matrix
+    hipLaunchKernelGGL(row_hist_kernel, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, final_words, (const unsigned long long *)goff, gcnt,
+                       sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
+    return check_launch("pg_abundance_from_records");
+}
+
+static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begin, int nb, const pg_rows *rows, int vsize,
+                        int32_t *abd_out, char *ws, hipStream_t s)
+{
+    int rc = shuffle_prepare(sp, rows, ws, s);
+    if (rc) return rc;
+    auto *emit_end = (unsigned long long *)(ws + sp.emit_off);
+    auto *goff = (unsigned long long *)(ws + sp.goff_off);
+    auto *gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
+    auto *words_e = (uint32_t *)(ws + sp.words_e_off);
+    auto *words_a = (uint32_t *)(ws + sp.words_a_off);
+    const unsigned long long *off = in_begin;
     const int gshift = sp.vbits + GROUP_ROWS_LOG2;
     // S2a: scatter the words by the first gb1 bits of their row group (destinations from global cursors, one add per digit
     // and tile)
@@ -2310,20 +2343,38 @@ static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begi
                            (const uint32_t *)words_e, off, (const unsigned long long *)emit_end, 0, (const unsigned long long *)nullptr, tiles_x,
                            words_a, (const unsigned long long *)goff, gcur1, sp.gb2, 1, sp.gb1, gshift + sp.gb2);
     }
-    const unsigned long long *gcnt = gcur1;
-    const uint32_t *final_words = words_a;
-    if (sp.gb2) {
-        const int tiles_x = 64;
-        hipLaunchKernelGGL((scatter_records_kernel<uint32_t, DIG_ROW, RPL32, MAX_FAN_BITS>), dim3((unsigned)(tiles_x << sp.gb1)), dim3(BLOCK), 0, s,
-                           (const uint32_t *)words_a, (const unsigned long long *)goff, (const unsigned long long *)nullptr, sp.gb2,
-                           (const unsigned long long *)gcur1, tiles_x, words_b, (const unsigned long long *)goff, gcur2, 0, 0, sp.gb2, gshift);
-        gcnt = gcur2;
-        final_words = words_b;
-    }
-    // S3: LDS row histograms -> rows of the matrix
-    hipLaunchKernelGGL(row_hist_kernel, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, final_words, (const unsigned long long *)goff, gcnt,
-                       sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
-    return check_launch("pg_abundance_from_records");
+    return shuffle_finish(sp, rows, vsize, abd_out, ws, s);
+}
+
+// the two outer parts for a lookup pass that does the first scatter itself: `ctx` tells it where the group regions are
+int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
+                                pg_shuffle_ctx *ctx)
+{
+    ShufflePlan sp;
+    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp);
+    if (rc) return rc;
+    if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
+    char *ws = (char *)workspace;
+    ctx->goff = (const unsigned long long *)(ws + sp.goff_off);
+    ctx->gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
+    ctx->words_in = (uint32_t *)(ws + sp.words_e_off);
+    ctx->words_out = (uint32_t *)(ws + sp.words_a_off);
+    ctx->vbits = sp.vbits;
+    ctx->gb1 = sp.gb1;
+    ctx->gb2 = sp.gb2;
+    ctx->dshift = sp.vbits + GROUP_ROWS_LOG2 + sp.gb2;
+    if (rows->n_rows == 0) return PG_OK;
+    return shuffle_prepare(sp, rows, ws, (hipStream_t)stream);
+}
+
+int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    ShufflePlan sp;
+    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp);
+    if (rc) return rc;
+    if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
+    if (rows->n_rows == 0) return PG_OK;
+    return shuffle_finish(sp, rows, vsize, abd_out, (char *)workspace, (hipStream_t)stream);
 }
 
 extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,

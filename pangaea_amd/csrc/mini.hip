@@ -495,6 +495,17 @@ __device__ __forceinline__ uint32_t mini_lookup_slow(const unsigned long long *t
 #ifndef PG_SHORT_MAX
 #define PG_SHORT_MAX 4
 #endif
+// where the SLOTS form scatters its (row, bin) words: straight into the row shuffle's group regions (pg_shuffle_ctx)
+struct ShufArgs {
+    const unsigned long long *goff;
+    unsigned long long *gcur1;
+    uint32_t *words_out;
+    int gb1, gb2, dshift;
+};
+// LDS of that scatter (bytes from the start of the dynamic area; the table has become 2-byte bins by then)
+constexpr uint32_t F_TILE = 16 * BIG_BLOCK;                  // words per tile: 16 per lane
+constexpr uint32_t F_BUF = 32 * 1024, F_CNT = F_BUF + 4 * F_TILE, F_START = F_CNT + 4 * 1024, F_GBASE = F_START + 4 * 1032,
+                   F_WAVE = F_GBASE + 8 * 1024, F_END = F_WAVE + 64;
 constexpr int SHORT_MAX = PG_SHORT_MAX;                                 // a record with at most this many k-mers is "short"
 
 template <int CAP, bool SLOTS>
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                                                                uint32_t window, uint32_t vsize, int vbits, uint32_t *__restrict__ words,
                                                                uint32_t *__restrict__ prov, unsigned long long *__restrict__ word_cursor,
                                                                unsigned long long *__restrict__ wbeg, unsigned long long *__restrict__ emit_end,
-                                                               uint32_t *status)
+                                                               ShufArgs sh, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ uint32_t emitted;
@@ -562,7 +573,6 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             for (int w = 0; w < COUNT_WAVES; ++w) { const unsigned long long v = wave_words[w]; wave_words[w] = run; run += v; }
             n_lookups = run;
             wbase = atomicAdd(word_cursor, run);
-            wbeg[blockIdx.x] = wbase;
         }
     }
     __syncthreads();
@@ -665,6 +675,85 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         if (lane == 0 && mine) atomicAdd(&n_lookups, mine);
     }
     __syncthreads();
+    if (emit_slots) {
+        // the packed slice (an empty table needs no clearing: every slot is written), and the table shrinks to 2-byte bins:
+        // 0 = slot never filled, 0xffff = bin out of range, else bin + 1.  (Every lane first reads all its slots -- the bins
+        // land on top of the first quarter of the table.)
+        uint16_t mybin[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t i = q * BIG_BLOCK + threadIdx.x;
+            mybin[q] = 0;
+            if (i < n_slots) {
+                const unsigned long long v = tab[i];
+                uint32_t c = (uint32_t)(v & HASH_CMASK);
+                if (c > HASH_SAT) c = HASH_SAT;
+                slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
+                const uint32_t bin = c / window;
+                mybin[q] = (uint16_t)(v ? (bin < vsize ? bin + 1u : 0xffffu) : 0u);
+            }
+        }
+        __syncthreads();
+        uint16_t *bins16 = reinterpret_cast<uint16_t *>(tab);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t i = q * BIG_BLOCK + threadIdx.x;
+            if (i < n_slots) bins16[i] = mybin[q];
+        }
+        PG_STAMP(2);
+        // ---- provisional (row, slot) words -> (row, bin) words, scattered at once by the first digit of their row group into
+        // the row shuffle's regions (an LDS multisplit per tile of 16 Ki words, one global cursor add per digit and tile): the
+        // final words never make a trip of their own through HBM
+        unsigned char *lds = reinterpret_cast<unsigned char *>(tab);
+        uint32_t *buf = reinterpret_cast<uint32_t *>(lds + F_BUF), *cnt = reinterpret_cast<uint32_t *>(lds + F_CNT);
+        uint32_t *start = reinterpret_cast<uint32_t *>(lds + F_START), *wave_tot = reinterpret_cast<uint32_t *>(lds + F_WAVE);
+        unsigned long long *gbase = reinterpret_cast<unsigned long long *>(lds + F_GBASE);
+        const uint32_t np = (uint32_t)n_lookups;
+        const uint32_t dmask = (1u << sh.gb1) - 1u;
+        for (uint32_t t0 = 0; t0 < np; t0 += F_TILE) {
+            cnt[threadIdx.x] = 0;
+            __syncthreads();
+            uint32_t w[16], dr[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t i = t0 + j * BIG_BLOCK + threadIdx.x;
+                w[j] = i < np ? prov_b[i] : 0xffffffffu;
+            }
+            uint32_t live = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t i = t0 + j * BIG_BLOCK + threadIdx.x;
+                const uint32_t b1 = bins16[w[j] & smask];
+                if (i < np && b1 != 0 && b1 != 0xffffu) {
+                    w[j] = ((w[j] >> lb) << vbits) | (b1 - 1u);
+                    const uint32_t d = (w[j] >> sh.dshift) & dmask;
+                    dr[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
+                    live |= 1u << j;
+                }
+            }
+            __syncthreads();
+            scan_digits<1024>(cnt, start, wave_tot);
+            unsigned long long gpos = 0;
+            {
+                const uint32_t d = threadIdx.x;
+                const uint32_t c = start[d + 1] - start[d];
+                if (c) gpos = sh.goff[(uint64_t)d << sh.gb2] + atomicAdd(&sh.gcur1[d], (unsigned long long)c) - start[d];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((live >> j) & 1u) buf[start[dr[j] >> 16] + (dr[j] & 0xffffu)] = w[j];
+            gbase[threadIdx.x] = gpos;
+            __syncthreads();
+            const uint32_t total = start[1024];
+            for (uint32_t i = threadIdx.x; i < total; i += BIG_BLOCK) {
+                const uint32_t r = buf[i];
+                sh.words_out[gbase[(r >> sh.dshift) & dmask] + i] = r;
+            }
+            __syncthreads();
+        }
+        PG_STAMP(3);
+        return;
+    }
     // the packed slice (an empty table needs no clearing: every slot is written); then counts -> bins, in place
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
         const unsigned long long v = tab[i];
@@ -678,39 +767,13 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
     }
     PG_STAMP(2);
     if (!window) return;
-    // (general form) this bucket's words go to a range of the word buffer claimed with one global add: an upper bound, every
-    // k-mer inside a row
-    if (!emit_slots && threadIdx.x == 0) {
+    // this bucket's words go to a range of the word buffer claimed with one global add: an upper bound, every k-mer inside a row
+    if (threadIdx.x == 0) {
         wbase = atomicAdd(word_cursor, n_lookups);
         wbeg[blockIdx.x] = wbase;
     }
     __syncthreads();
     wb = wbase;
-    if (emit_slots) {
-        // ---- provisional (row, slot) words -> (row, bin) words: a stream with one LDS read per word.  A word whose bin is out
-        // of range becomes a hole (all ones) that the row shuffle skips: positions stay, nothing is compacted.
-        const uint32_t np = (uint32_t)n_lookups;
-        uint32_t *const words_b = words + wb;
-        for (uint32_t i0 = 0; i0 < np; i0 += 8 * BIG_BLOCK) {
-            uint32_t w[8], b1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t i = i0 + u * BIG_BLOCK + threadIdx.x;
-                w[u] = i < np ? prov_b[i] : 0xffffffffu;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) b1[u] = (uint32_t)(tab[w[u] & smask] & HASH_CMASK);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t i = i0 + u * BIG_BLOCK + threadIdx.x;
-                // (a slot that was never filled -- a full bucket -- reads as count 0: a hole too)
-                if (i < np) words_b[i] = b1[u] != BIN_NONE && b1[u] != 0 ? ((w[u] >> lb) << vbits) | (b1[u] - 1u) : 0xffffffffu;
-            }
-        }
-        if (threadIdx.x == 0) emit_end[blockIdx.x] = wb + np;
-        PG_STAMP(3);
-        return;
-    }
     // ---- general form: the records are read and probed a second time
     // (row, bin) words of 64 lanes -> the bucket's word range: one LDS add per call, the stores are contiguous
     auto emit = [&](bool put, uint32_t row, uint32_t bin1) {
@@ -866,6 +929,12 @@ MiniView mini_view(const pg_table *t)
     return v;
 }
 
+// the SLOTS form of the lookups needs a row and a slot index in one 32-bit word (PG_MINI_PROBE_TWICE forces the general form)
+bool mini_slots_form(const pg_table *t, const pg_rows *rows)
+{
+    return rows && rows->n_rows > 0 && rows->n_rows < ((int64_t)1 << (32 - t->log2_bucket_slots)) - 1 && !getenv("PG_MINI_PROBE_TWICE");
+}
+
 int check_mini_rows(const pg_rows *rows, const char *who)
 {
     if (!rows) return PG_OK;
@@ -1017,27 +1086,36 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
                                (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l);
         }
     }
-    // the SLOTS form of the lookups needs a row and a slot index in one 32-bit word
-    const bool slots_form = window > 0 && rows->n_rows < ((int64_t)1 << (32 - t->log2_bucket_slots)) - 1 && !getenv("PG_MINI_PROBE_TWICE");
+    const bool slots_form = window > 0 && mini_slots_form(t, rows);
     // (the classes are sorted apart by the second scatter pass: without it -- at most 256 buckets -- every record counts as long)
     const unsigned long long *n_short = p.bits2 && mini_cap(t->k) > SHORT_MAX ? (const unsigned long long *)cur2 : (const unsigned long long *)nullptr;
     uint32_t *words_e = window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr;
     uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
+    ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0};
+    size_t count_lds = slice_lds;
+    if (slots_form) {
+        // the count kernel scatters its words into the row shuffle's group regions itself: offsets and cursors must be ready
+        pg_shuffle_ctx ctx;
+        if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx))) return rc;
+        sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift};
+        words_a = ctx.words_in;                          // the provisional words wait in the shuffle's input buffer
+        if (count_lds < F_END) count_lds = F_END;
+    }
     unsigned long long *emit_end = window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
 #define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \
     do {                                                                                                                    \
         if (slots_form) {                                                                                                   \
-            if ((rc = raise_lds_limit((const void *)mini_count_kernel<CAP_, true>, slice_lds, "pg_mini_count"))) return rc;   \
-            hipLaunchKernelGGL((mini_count_kernel<CAP_, true>), dim3(nb), dim3(BIG_BLOCK), slice_lds, s,                    \
+            if ((rc = raise_lds_limit((const void *)mini_count_kernel<CAP_, true>, count_lds, "pg_mini_count"))) return rc;   \
+            hipLaunchKernelGGL((mini_count_kernel<CAP_, true>), dim3(nb), dim3(BIG_BLOCK), count_lds, s,                    \
                                (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a), \
                                (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,    \
-                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, status);                             \
+                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                         \
         } else {                                                                                                            \
             if ((rc = raise_lds_limit((const void *)mini_count_kernel<CAP_, false>, slice_lds, "pg_mini_count"))) return rc;  \
             hipLaunchKernelGGL((mini_count_kernel<CAP_, false>), dim3(nb), dim3(BIG_BLOCK), slice_lds, s,                   \
                                (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a), \
                                (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,    \
-                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, status);                             \
+                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                         \
         }                                                                                                                   \
     } while (0)
     switch (mini_cap(t->k)) {                                          // k-mers per record at most (as the first pass cuts them)
@@ -1067,6 +1145,8 @@ extern "C" int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *
     plan_mini(t, n_words_counted, &p);
     if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: plan workspace does not match n_words_counted");
     if ((reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: workspace must be 256-byte aligned");
+    if (mini_slots_form(t, rows))        // the count kernel has scattered the words by row group already
+        return pg_internal_shuffle_finish(n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
     const auto *wbeg = (const unsigned long long *)((const char *)plan_ws + p.wbeg_off);
     return pg_internal_shuffle_rows(wbeg, 1 << p.bits, n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
 }

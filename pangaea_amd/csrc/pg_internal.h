@@ -14,6 +14,18 @@ struct pg_shuffle_layout {
     size_t emit_off, words_e_off, words_a_off, total;      // words_a: the shuffle's second word buffer, free until it runs
 };
 int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out);
+// a lookup pass that scatters its (row, bin) words by row group itself (mini.hip): prepare fills `ctx` and clears the cursors;
+// the pass puts a word whose first digit is d = (word >> dshift) & (2^gb1 - 1) at words_out[goff[d << gb2] + (atomicAdd on
+// gcur1[d])]; finish runs what is left (second pass for more than 2^10 row groups, row histograms)
+struct pg_shuffle_ctx {
+    const unsigned long long *goff;
+    unsigned long long *gcur1;
+    uint32_t *words_in, *words_out;
+    int vbits, gb1, gb2, dshift;
+};
+int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
+                                pg_shuffle_ctx *ctx);
+int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream);
 int pg_internal_shuffle_rows(const unsigned long long *in_begin, int nb, int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out,
                              void *workspace, int64_t workspace_bytes, void *stream);
 

@@ -24,3 +24,16 @@ def manifest():
     import json
     with open(os.path.join(GOLDEN, "manifest.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(autouse=True)
+def _give_gpu_memory_back():
+    """tests at the BASELINE sizes leave hundreds of GB in torch's caching allocator; the multi-process tests that follow
+    start child processes on the same GPU, which would find it full"""
+    yield
+    import gc
+    if "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_available():
+            gc.collect()
+            torch.cuda.empty_cache()
