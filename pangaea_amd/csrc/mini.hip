@@ -468,7 +468,7 @@ __device__ __forceinline__ uint32_t mini_insert_slow(unsigned long long *tab, ui
         const bool claimed = todo && cur == 0;
         const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
         // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
-        if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[s], 1ull);
+        if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[s]), 1u);   // (the count is in the low dword)
         if (claimed || match) { res = s; todo = false; }
         s = todo ? (s + 1) & smask : s;
     }
@@ -628,7 +628,8 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
 #pragma unroll
             for (int j = 0; j < CX; ++j) {
                 const bool hit = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j];
-                if (hit && (uint32_t)(cur[j] & HASH_CMASK) < HASH_SAT) atomicAdd(&tab[sl[j]], 1ull);
+                // (the count sits in the low 22 bits of the slot's low dword and stops far below 2^22: a 32-bit LDS add is enough)
+                if (hit && (uint32_t)(cur[j] & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[sl[j]]), 1u);
                 if (hit) hits |= 1u << j;
             }
             if (emit_slots) {
