@@ -352,6 +352,7 @@ def main():
                        "partition_plan": (("recomputed in every step" if args.plan_in_step else
                                            "computed once with the table sizing, outside the step (it depends on the reads, the rows and the geometry only)")
                                           if mini else "bucket histogram inside the step"),
+                       "records_per_pair": (table._mini_plan[2] / args.pairs if mini and table._mini_plan else 260.0),
                        "input": "packed reads resident in HBM", "table_load": table_load,
                        "table_buckets": table.n_buckets, "bucket_slots": 1 << table.log2_bucket if table.log2_bucket else None},
             "kernel_ms": kern_ms,

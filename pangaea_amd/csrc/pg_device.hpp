@@ -134,11 +134,14 @@ __device__ __forceinline__ uint64_t rev2_64(uint64_t x)
     const uint32_t lo = swap_pairs32(__brev((uint32_t)x)), hi = swap_pairs32(__brev((uint32_t)(x >> 32)));
     return ((uint64_t)lo << 32) | hi;
 }
+// (two 24-bit multiplies -- v_mul_u32_u24 issues at full rate, a 32-bit v_mul_lo_u32 at a quarter of it, and this runs once per
+// k-mer occurrence in kernels that are bound by VALU issue; the fold brings the well-mixed high product bits, which depend
+// on all 42 bits of the code, down to the slot index)
 __device__ __forceinline__ uint32_t mini_slot_hash(uint64_t code)
 {
-    uint32_t x = (uint32_t)code ^ ((uint32_t)(code >> 32) * 0x9E3779B1u);
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 16;
+    const uint32_t a = (uint32_t)code & 0xffffffu, b = (uint32_t)(code >> 21);
+    uint32_t x = __umul24(a, 0x9E3779u) ^ __umul24(b, 0xC2B2AFu);
+    x ^= x >> 15;
     return x;
 }
 // minimizer value of one k-mer given as a (forward or canonical) code, newest character in the low bits
