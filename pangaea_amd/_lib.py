@@ -15,7 +15,7 @@ _LIB = None
 
 PG_OK = 0
 PG_ETABLEFULL = -6
-TABLE_DENSE, TABLE_HASH, TABLE_WIDE, TABLE_MINI = 1, 2, 3, 4
+TABLE_DENSE, TABLE_HASH, TABLE_WIDE, TABLE_MINI, TABLE_MINI_WIDE = 1, 2, 3, 4, 5
 DENSE_MAX_K, HASH_MAX_K, WIDE_MAX_K = 16, 21, 31
 HASH_COUNT_BITS = 22
 HASH_COUNT_SAT = 1 << 21
@@ -23,7 +23,7 @@ TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
 ABI_VERSION = 3
-MINI_MIN_K, MINI_MAX_LOG2_BUCKETS, MINI_MAX_ROWS = 16, 15, (1 << 21) - 2
+MINI_MIN_K, MINI_MAX_LOG2_BUCKETS, MINI_MAX_ROWS, MINI_WIDE_MAX_LOG2_BUCKET_SLOTS = 16, 16, (1 << 21) - 2, 13
 SHUFFLE_MAX_VSIZE = 512
 DEFERRED_MAX_GROUP_LOG2 = 3
 KEY42_M1 = 0x3d7ed558ccd          # pg_key42 (include/pangaea_feat.h)

@@ -29,7 +29,7 @@
 #include "pg_device.hpp"
 
 namespace {
-enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2, TK_WIDE = 3, TK_MINI = 4 };
+enum { TK_NONE = 0, TK_DENSE = 1, TK_HASH = 2, TK_WIDE = 3, TK_MINI = 4, TK_MINIW = 5 };
 
 // Packed hash tables (k <= 21) do not store the canonical code but key42(code): a BIJECTION of the 42-bit codes onto
 // themselves with the avalanche of a hash (two xorshift-multiply rounds modulo 2^42; every step is invertible, the
@@ -60,7 +60,7 @@ struct HashView {
     __device__ __forceinline__ uint64_t home_mini(uint64_t code, int k) const
     {
         const uint32_t b = mini_bucket(mini_minimizer_of(code, k), log2_slots - log2_bucket);
-        return ((uint64_t)b << log2_bucket) | (mini_slot_hash(code) & ((1u << log2_bucket) - 1u));
+        return ((uint64_t)b << log2_bucket) | (mini_slot_hash<true>(code) & ((1u << log2_bucket) - 1u));
     }
     __device__ __forceinline__ uint64_t next(uint64_t s) const
     {
@@ -139,11 +139,12 @@ __device__ __forceinline__ uint32_t hash_probe(const HashView &t, uint64_t s, ui
 // and probing as the packed form; counts wrap modulo 2^32 like any uint32 counter.
 __device__ __forceinline__ uint32_t *wide_counts(const HashView &t) { return reinterpret_cast<uint32_t *>(t.slots + (1ull << t.log2_slots)); }
 
-__device__ __forceinline__ void wide_add(const HashView &t, uint64_t code, uint32_t add, uint32_t *status)
+// (mini_k != 0: a PG_TABLE_MINI_WIDE table -- home slot from the minimizer bucket, same keys/counts planes)
+__device__ __forceinline__ void wide_add(const HashView &t, uint64_t code, uint32_t add, uint32_t *status, int mini_k = 0)
 {
     const uint32_t limit = t.limit();
     const uint64_t key1 = code + 1;
-    uint64_t s = t.home_wide(code);
+    uint64_t s = mini_k ? t.home_mini(code, mini_k) : t.home_wide(code);
     for (uint32_t i = 0; i < limit; ++i) {
         uint64_t cur = t.slots[s];
         if (cur == 0) {
@@ -171,10 +172,10 @@ __device__ __forceinline__ uint32_t wide_probe(const HashView &t, uint64_t s, ui
 }
 
 __global__ __launch_bounds__(BLOCK) void wide_merge_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ counts, int64_t n,
-                                                           HashView t, uint32_t *status)
+                                                           HashView t, uint32_t *status, int mini_k)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
-        if (counts[i]) wide_add(t, codes[i], counts[i], status);
+        if (counts[i]) wide_add(t, codes[i], counts[i], status, mini_k);
 }
 
 // -------------------------------------------------------------------------------- K2 direct: global counts
@@ -1593,7 +1594,7 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                             cur[u] = dense[(uint32_t)canon[u]];
                         } else {
                             key8[u] = TK == TK_HASH ? key42((uint64_t)canon[u]) : (uint64_t)canon[u];
-                            hh[u] = TK == TK_WIDE ? t.home_wide(key8[u]) : TK == TK_MINI ? t.home_mini(key8[u], k) : t.home_key(key8[u]);
+                            hh[u] = TK == TK_WIDE ? t.home_wide(key8[u]) : (TK == TK_MINI || TK == TK_MINIW) ? t.home_mini(key8[u], k) : t.home_key(key8[u]);
                             // each table line is used once per launch: keep it out of the way of the stream (measured -2 %)
                             cur[u] = __builtin_nontemporal_load(&t.slots[hh[u]]);
                         }
@@ -1610,7 +1611,7 @@ __global__ __launch_bounds__(BLOCK) void features_kernel(const uint64_t *__restr
                         if (TK == TK_DENSE) {
                             cnt = (uint32_t)cur[u];
                             found = cnt != 0;       // absent from the table <=> never counted
-                        } else if (TK == TK_WIDE) {
+                        } else if (TK == TK_WIDE || TK == TK_MINIW) {
                             cnt = wide_probe(t, hh[u], cur[u], key8[u], &found);
                         } else {
                             cnt = hash_probe(t, hh[u], cur[u], key8[u], &found);
@@ -1659,6 +1660,11 @@ int check_table(const pg_table *t)
         if (t->log2_bucket_slots < 4 || t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS || t->log2_slots < t->log2_bucket_slots ||
             t->log2_slots - t->log2_bucket_slots > PG_MINI_MAX_LOG2_BUCKETS)
             return pg_fail(PG_EINVAL, "mini table geometry 2^%d slots in buckets of 2^%d", t->log2_slots, t->log2_bucket_slots);
+    } else if (t->kind == PG_TABLE_MINI_WIDE) {
+        if (t->k <= PG_HASH_MAX_K || t->k > PG_WIDE_MAX_K) return pg_fail(PG_EINVAL, "wide mini table needs %d < k <= %d (got %d)", PG_HASH_MAX_K, PG_WIDE_MAX_K, t->k);
+        if (t->log2_bucket_slots < 4 || t->log2_bucket_slots > PG_MINI_WIDE_MAX_LOG2_BUCKET_SLOTS || t->log2_slots < t->log2_bucket_slots ||
+            t->log2_slots - t->log2_bucket_slots > PG_MINI_MAX_LOG2_BUCKETS)
+            return pg_fail(PG_EINVAL, "wide mini table geometry 2^%d slots in buckets of 2^%d", t->log2_slots, t->log2_bucket_slots);
     } else if (t->kind == PG_TABLE_WIDE) {
         if (t->k < 1 || t->k > PG_WIDE_MAX_K) return pg_fail(PG_EINVAL, "wide table needs 1 <= k <= %d (got %d)", PG_WIDE_MAX_K, t->k);
         if (t->log2_slots < 10 || t->log2_slots > 40) return pg_fail(PG_EINVAL, "log2_slots %d out of range [10,40]", t->log2_slots);
@@ -1780,7 +1786,7 @@ extern "C" int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_kmer_count: bad word range [%lld,%lld)", (long long)word_begin, (long long)word_end);
     int rc = check_table(t);
     if (rc) return rc;
-    if (t->kind == PG_TABLE_MINI) return pg_fail(PG_EINVAL, "pg_kmer_count: mini tables are built by pg_mini_plan + pg_mini_count");
+    if (t->kind == PG_TABLE_MINI || t->kind == PG_TABLE_MINI_WIDE) return pg_fail(PG_EINVAL, "pg_kmer_count: mini tables are built by pg_mini_plan + pg_mini_count");
     if (t->kind != PG_TABLE_DENSE && !status) return pg_fail(PG_EINVAL, "pg_kmer_count: hash tables need a status word");
     if (word_end == word_begin) return PG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -2052,10 +2058,11 @@ extern "C" int pg_kmer_merge_wide(const uint64_t *codes, const uint32_t *counts,
 {
     int rc = check_table(t);
     if (rc) return rc;
-    if (t->kind != PG_TABLE_WIDE) return pg_fail(PG_EINVAL, "pg_kmer_merge_wide: wide tables only");
+    if (t->kind != PG_TABLE_WIDE && t->kind != PG_TABLE_MINI_WIDE) return pg_fail(PG_EINVAL, "pg_kmer_merge_wide: wide and wide mini tables only");
     if (n < 0 || (n > 0 && (!codes || !counts)) || !status) return pg_fail(PG_EINVAL, "pg_kmer_merge_wide: bad arguments");
     if (n == 0) return PG_OK;
-    hipLaunchKernelGGL(wide_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, codes, counts, n, view_of(t), status);
+    hipLaunchKernelGGL(wide_merge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, codes, counts, n, view_of(t), status,
+                       t->kind == PG_TABLE_MINI_WIDE ? t->k : 0);
     return check_launch("pg_kmer_merge_wide");
 }
 
@@ -2406,7 +2413,8 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
         if ((t->kind == PG_TABLE_HASH || t->kind == PG_TABLE_MINI) && (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
             return pg_fail(PG_EINVAL, "pg_features: window*vector_size %lld exceeds the exact range of the hash table (%u)",
                            (long long)window * vsize, PG_HASH_COUNT_SAT);
-        kind = t->kind == PG_TABLE_DENSE ? TK_DENSE : t->kind == PG_TABLE_WIDE ? TK_WIDE : t->kind == PG_TABLE_MINI ? TK_MINI : TK_HASH;
+        kind = t->kind == PG_TABLE_DENSE ? TK_DENSE : t->kind == PG_TABLE_WIDE ? TK_WIDE : t->kind == PG_TABLE_MINI ? TK_MINI
+             : t->kind == PG_TABLE_MINI_WIDE ? TK_MINIW : TK_HASH;
         k = t->k;
         if (kind == TK_DENSE) dense = (const uint32_t *)t->data;
         else view = view_of(t);
@@ -2423,6 +2431,7 @@ extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t
     else if (kind == TK_DENSE) PG_LAUNCH(uint32_t, TK_DENSE);
     else if (kind == TK_WIDE) PG_LAUNCH(uint64_t, TK_WIDE);
     else if (kind == TK_MINI) PG_LAUNCH(uint64_t, TK_MINI);
+    else if (kind == TK_MINIW) PG_LAUNCH(uint64_t, TK_MINIW);
     else PG_LAUNCH(uint64_t, TK_HASH);
 #undef PG_LAUNCH
     return check_launch("pg_features");

@@ -37,9 +37,10 @@ constexpr int STAGE_CAP = 8 * S1_BLOCK;                // records of a (sub-)rou
 constexpr int META_D2_BITS = 7, META_LEN_BITS = 4, META_ROW_SHIFT = META_D2_BITS + META_LEN_BITS;
 constexpr uint32_t MINI_ROW_NONE = (1u << (32 - META_ROW_SHIFT)) - 1u;
 constexpr int MINI_MAX_LEN = 1 << META_LEN_BITS;       // k-mers per record
-constexpr int MINI_BITS1 = 8;                          // first-pass digits (regions)
+constexpr int MINI_BITS1 = 8;                          // first-pass digits (regions): 8, or 9 for a table of 2^16 buckets
+constexpr int MINI_MAX_BITS1 = 9;
 static_assert(PG_MINI_MAX_ROWS == (int)MINI_ROW_NONE - 1, "row field of the record");
-static_assert(PG_MINI_MAX_LOG2_BUCKETS == MINI_BITS1 + META_D2_BITS, "bucket id = region digit + second-pass digit");
+static_assert(PG_MINI_MAX_LOG2_BUCKETS == MINI_MAX_BITS1 + META_D2_BITS, "bucket id = region digit + second-pass digit");
 
 struct MiniView {
     uint64_t *slots;
@@ -102,37 +103,29 @@ struct RowBits {
 
 // emit(e, n, bucket): one record of n k-mers ending at characters e - n + 1 .. e of the word.  `cuts`: positions where the row
 // changes; ok_row: k-mer ends that count for rows (a record never mixes the two kinds)
-template <int W, class Emit>
-__device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_t ok_row, uint32_t cuts, int k, int bits, int cap, Emit &&emit)
+// DELAY (k > 21): the minimizer of a k-mer is taken over its central W M-mers only (pg_device.hpp: mini_window), i.e. the
+// window that ends `off` characters before the k-mer does -- the window minimum passes through a delay line of `off` <= 5 steps.
+constexpr int MINI_MAX_OFF = 5;
+template <int W, bool DELAY, class Emit>
+__device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_t ok_row, uint32_t cuts, int k, int off, int bits, int cap, Emit &&emit)
 {
     uint32_t fwm = 0, rcm = 0;
     uint32_t win[W];                                            // win[0] = newest hashed canonical M-mer
+    uint32_t dl[DELAY ? MINI_MAX_OFF : 1];                      // dl[i] = window minimum i + 1 characters ago
 #pragma unroll
     for (int i = 0; i < W; ++i) win[i] = 0xffffffffu;
-    // pre-roll the k - 1 characters before the word; only the M-mers that end at the last W - 1 of them are complete (and wanted)
-    for (int c = 33 - k; c < 33 - W; ++c) {
+#pragma unroll
+    for (int i = 0; i < (DELAY ? MINI_MAX_OFF : 1); ++i) dl[i] = 0xffffffffu;
+    // pre-roll the characters before the word (DELAY: all 32 of the previous word -- more than the k - 1 that belong to the
+    // word's k-mers, which only completes M-mers earlier); only the M-mers that end at the last W - 1 (+ MINI_MAX_OFF) of them
+    // are wanted in the window
+    constexpr int PRE = W - 1 + (DELAY ? MINI_MAX_OFF : 0);
+    for (int c = DELAY ? 0 : 33 - k; c < 32 - PRE; ++c) {
         const uint32_t ch = (uint32_t)(x.pw >> (2 * c)) & 3u;
         fwm = ((fwm << 2) | ch) & MINI_MMASK;
         rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
     }
-#pragma unroll
-    for (int c = 33 - W; c < 32; ++c) {
-        const uint32_t ch = (uint32_t)(x.pw >> (2 * c)) & 3u;
-        fwm = ((fwm << 2) | ch) & MINI_MMASK;
-        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
-#pragma unroll
-        for (int i = W - 1; i > 0; --i) win[i] = win[i - 1];
-        win[0] = mhash(fwm < rcm ? fwm : rcm);
-    }
-    // a k-mer may continue the open record if it is valid, of the same kind (row-counting or not) as its predecessor and
-    // no row boundary lies at its last character -- and if it has the same minimizer (its bucket follows from that: the bucket
-    // is computed once per record, not per character)
-    const uint32_t same = ok & (ok << 1) & ~(ok_row ^ (ok_row << 1)) & ~cuts;
-    int n = 0;                                                  // k-mers of the open record (minimizer value cur_mv)
-    uint32_t cur_mv = 0;
-#pragma unroll
-    for (int p = 0; p < 32; ++p) {
-        const uint32_t ch = (uint32_t)(x.cw >> (2 * p)) & 3u;
+    auto step = [&](uint32_t ch) -> uint32_t {                  // one character in; the minimizer value of the k-mer that ends here
         fwm = ((fwm << 2) | ch) & MINI_MMASK;
         rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
 #pragma unroll
@@ -141,6 +134,26 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
         uint32_t mv = win[0];
 #pragma unroll
         for (int i = 1; i < W; ++i) mv = win[i] < mv ? win[i] : mv;
+        if (!DELAY) return mv;
+        uint32_t use = mv;                                      // (off is wave-uniform: scalar selects)
+#pragma unroll
+        for (int i = 0; i < MINI_MAX_OFF; ++i) use = off == i + 1 ? dl[i] : use;
+#pragma unroll
+        for (int i = MINI_MAX_OFF - 1; i > 0; --i) dl[i] = dl[i - 1];
+        dl[0] = mv;
+        return use;
+    };
+#pragma unroll
+    for (int c = 32 - PRE; c < 32; ++c) step((uint32_t)(x.pw >> (2 * c)) & 3u);
+    // a k-mer may continue the open record if it is valid, of the same kind (row-counting or not) as its predecessor and
+    // no row boundary lies at its last character -- and if it has the same minimizer (its bucket follows from that: the bucket
+    // is computed once per record, not per character)
+    const uint32_t same = ok & (ok << 1) & ~(ok_row ^ (ok_row << 1)) & ~cuts;
+    int n = 0;                                                  // k-mers of the open record (minimizer value cur_mv)
+    uint32_t cur_mv = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const uint32_t mv = step((uint32_t)(x.cw >> (2 * p)) & 3u);
         const bool v = (ok >> p) & 1u;
         // the open record ends at p - 1 unless this k-mer continues it (a record cannot end before the word starts)
         const bool cont = ((same >> p) & 1u) && n > 0 && mv == cur_mv && n < cap;
@@ -171,21 +184,22 @@ __device__ __forceinline__ LaneWord load_lane_word(const uint64_t *__restrict__ 
 }
 
 // ---- plan: records per bucket (hist) and, per chunk, records per first-pass region (chunk_hist[d * n_chunks + slot(chunk)])
-template <int W>
+template <int W, bool DELAY>
 __global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                              int64_t word_begin, int64_t word_end, int k, int bits, int bits2, int cap,
+                                                              int64_t word_begin, int64_t word_end, int k, int woff, int bits, int bits2, int cap,
                                                               const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
                                                               const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
                                                               unsigned long long *__restrict__ hist, unsigned long long *__restrict__ chunk_hist,
-                                                              int64_t n_chunks, int64_t chunk_stride)
+                                                              int64_t n_chunks, int64_t chunk_stride, uint32_t b_base, int nb)
 {
+    // this launch histograms the buckets [b_base, b_base + nb) in LDS (2^15 counters at most: a table of 2^16 buckets takes two
+    // launches); the per-chunk region counts are taken by the launch with b_base = 0
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int nb = 1 << bits;
-    uint32_t *coarse = lds + nb;                                    // [256]
+    uint32_t *coarse = lds + nb;                                    // [1 << MINI_MAX_BITS1]
     for (int i = threadIdx.x; i < nb; i += BIG_BLOCK) lds[i] = 0;
     const int n_dig = 1 << (bits - bits2);
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        if (threadIdx.x < 256) coarse[threadIdx.x] = 0;
+        if (threadIdx.x < (1 << MINI_MAX_BITS1)) coarse[threadIdx.x] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < MINI_CHUNK_WORDS; i += BIG_BLOCK) {
             const int64_t wi = chunk * MINI_CHUNK_WORDS + i;        // word index inside the range
@@ -195,18 +209,18 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__
             if (lw.ok == 0) continue;
             RowBits rb;
             rb.init(row_start, row_end, n_rows, row_start ? round_row[wi / ROUND_WORDS] : 0, w << 5);
-            mini_segment<W>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, bits, cap, [&](int, int, uint32_t b) {
-                atomicAdd(&lds[b], 1u);
-                atomicAdd(&coarse[b >> bits2], 1u);
+            mini_segment<W, DELAY>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int, int, uint32_t b) {
+                if (b - b_base < (uint32_t)nb) atomicAdd(&lds[b - b_base], 1u);
+                if (b_base == 0) atomicAdd(&coarse[b >> bits2], 1u);
             });
         }
         __syncthreads();
-        if ((int)threadIdx.x < n_dig)
+        if ((int)threadIdx.x < n_dig && b_base == 0)
             chunk_hist[(int64_t)threadIdx.x * n_chunks + (int64_t)(((__int128)chunk * chunk_stride) % n_chunks)] = coarse[threadIdx.x];
         __syncthreads();
     }
     for (int i = threadIdx.x; i < nb; i += BIG_BLOCK)
-        if (lds[i]) atomicAdd(&hist[i], (unsigned long long)lds[i]);
+        if (lds[i]) atomicAdd(&hist[b_base + i], (unsigned long long)lds[i]);
 }
 
 // total records = off[nb] -> header[0]
@@ -241,37 +255,38 @@ __device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start
 }
 
 // ---- A1': stream -> regions
-struct Scatter1Lds {
+template <int N1> struct Scatter1Lds {                              // N1 regions: 256, or 512 for a table of 2^16 buckets
     uint64_t bases[STAGE_CAP];
     uint32_t meta[STAGE_CAP];
-    uint8_t dig[STAGE_CAP];
-    uint32_t cnt[256];
-    uint32_t start[257];
-    unsigned long long gbase[256];
-    unsigned long long cur[256];                                    // running write offsets of this chunk, per region
-    uint32_t wave_tot[4];
+    typename std::conditional<(N1 > 256), uint16_t, uint8_t>::type dig[STAGE_CAP];
+    uint32_t cnt[N1];
+    uint32_t start[N1 + 1];
+    unsigned long long gbase[N1];
+    unsigned long long cur[N1];                                     // running write offsets of this chunk, per region
+    uint32_t wave_tot[N1 / 64];
 };
 
-template <int W>
+template <int W, bool DELAY, int N1>
 __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                                 int64_t word_begin, int64_t word_end, int k, int bits, int bits2, int cap,
+                                                                 int64_t word_begin, int64_t word_end, int k, int woff, int bits, int bits2, int cap,
                                                                  const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
                                                                  const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
                                                                  uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
                                                                  const unsigned long long *__restrict__ chunk_off, int64_t n_chunks, int64_t chunk_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    Scatter1Lds &L = *reinterpret_cast<Scatter1Lds *>(lds_raw);
+    static_assert(N1 <= S1_BLOCK, "one lane per region");
+    Scatter1Lds<N1> &L = *reinterpret_cast<Scatter1Lds<N1> *>(lds_raw);
     const int n_dig = 1 << (bits - bits2);
     const uint32_t d2mask = (1u << bits2) - 1u;
     const int64_t chunk = blockIdx.x;
     const int64_t slot = (int64_t)(((__int128)chunk * chunk_stride) % n_chunks);
-    if (threadIdx.x < 256) L.cur[threadIdx.x] = (int)threadIdx.x < n_dig ? chunk_off[(int64_t)threadIdx.x * n_chunks + slot] : 0ull;
+    if (threadIdx.x < N1) L.cur[threadIdx.x] = (int)threadIdx.x < n_dig ? chunk_off[(int64_t)threadIdx.x * n_chunks + slot] : 0ull;
     for (int rd = 0; rd < ROUNDS_PER_CHUNK; ++rd) {
         const int64_t round = chunk * ROUNDS_PER_CHUNK + rd;
         const int64_t w = word_begin + round * ROUND_WORDS + threadIdx.x;
         if (word_begin + round * ROUND_WORDS >= word_end) break;    // (uniform)
-        if (threadIdx.x < 256) L.cnt[threadIdx.x] = 0;
+        if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
         __syncthreads();
         uint32_t dr[32];                                            // bucket << 16 | rank inside the region
         uint32_t has = 0;
@@ -282,14 +297,14 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         rb.starts = rb.ends = rb.r0 = 0; rb.inside0 = false;
         if (lw.ok) {
             rb.init(row_start, row_end, n_rows, row_start ? round_row[round] : 0, w << 5);
-            mini_segment<W>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, bits, cap, [&](int e, int, uint32_t b) {
+            mini_segment<W, DELAY>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int e, int, uint32_t b) {
                 dr[e] = (b << 16) | atomicAdd(&L.cnt[b >> bits2], 1u);
                 has |= 1u << e;
             });
         }
         __syncthreads();
-        scan_digits<256>(L.cnt, L.start, L.wave_tot);
-        const uint32_t total = L.start[256];
+        scan_digits<N1>(L.cnt, L.start, L.wave_tot);
+        const uint32_t total = L.start[N1];
         // a round has at most 32 x 512 records; 8 positions x 512 lanes always fit the stage.  Nearly every round fits whole.
         const int n_win = total <= (uint32_t)STAGE_CAP ? 1 : 4;
         for (int win = 0; win < n_win; ++win) {
@@ -299,16 +314,16 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
             asm volatile("" : "+v"(lw.x.cw), "+v"(lw.x.pw), "+v"(has));
             if (n_win > 1) {                                        // rank again, this window's records only
                 __syncthreads();
-                if (threadIdx.x < 256) L.cnt[threadIdx.x] = 0;
+                if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < 32; ++e)
                     if ((has & wmask) >> e & 1u) dr[e] = (dr[e] & 0xffff0000u) | atomicAdd(&L.cnt[dr[e] >> (16 + bits2)], 1u);
                 __syncthreads();
-                scan_digits<256>(L.cnt, L.start, L.wave_tot);
+                scan_digits<N1>(L.cnt, L.start, L.wave_tot);
             }
             // gbase[d] = (where the region's run goes) - (where it starts in the stage): the copy-out adds the stage position
-            if (threadIdx.x < 256) {
+            if (threadIdx.x < N1) {
                 const uint32_t c = L.start[threadIdx.x + 1] - L.start[threadIdx.x];
                 L.gbase[threadIdx.x] = L.cur[threadIdx.x] - L.start[threadIdx.x];
                 L.cur[threadIdx.x] += c;
@@ -327,12 +342,12 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                         // the 32 characters ending at position e of the word
                         L.bases[at] = e == 31 ? lw.x.cw : (lw.x.cw << (2 * (31 - e))) | (lw.x.pw >> (2 * (e + 1)));
                         L.meta[at] = (row << META_ROW_SHIFT) | ((uint32_t)(n - 1) << META_D2_BITS) | (b & d2mask);
-                        L.dig[at] = (uint8_t)d;
+                        L.dig[at] = (decltype(L.dig[0] + 0))d;
                     }
                 }
             }
             __syncthreads();
-            const uint32_t tot = L.start[256];
+            const uint32_t tot = L.start[N1];
             for (uint32_t i = threadIdx.x; i < tot; i += S1_BLOCK) {
                 const unsigned long long g = L.gbase[L.dig[i]] + i;
                 out_bases[g] = L.bases[i];
@@ -455,37 +470,45 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 // Written as ONE wave-uniform loop with two short predicated regions per round (claim an empty slot / add to a match): the
 // structurizer's rendering of the obvious per-lane loop with early returns spends several times as many scalar
 // instructions on mask bookkeeping, and those -- not the LDS -- were the cost of this path.
-__device__ __forceinline__ uint32_t mini_insert_slow(unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code, bool act)
+// WIDE (k > 21): tab[] holds code + 1 (0 = empty) and the counts live in their own 32-bit plane cnts[].
+template <bool WIDE>
+__device__ __forceinline__ uint32_t mini_insert_slow(unsigned long long *tab, uint32_t *cnts, uint32_t smask, uint32_t limit, uint64_t code, bool act)
 {
-    uint32_t s = mini_slot_hash(code) & smask;
+    uint32_t s = mini_slot_hash<WIDE>(code) & smask;
     uint32_t res = act ? 0xffffffffu : 0u;
     bool todo = act;
-    const unsigned long long fresh = (unsigned long long)((code << HASH_CBITS) | 1ull);
+    const unsigned long long fresh = WIDE ? (unsigned long long)(code + 1ull) : (unsigned long long)((code << HASH_CBITS) | 1ull);
     for (uint32_t i = 0; i < limit; ++i) {
         if (!__any(todo)) break;
         unsigned long long cur = tab[s];                        // (settled lanes read their last slot again: harmless)
         if (todo && cur == 0) cur = atomicCAS(&tab[s], 0ull, fresh);
         const bool claimed = todo && cur == 0;
-        const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
-        // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
-        if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[s]), 1u);   // (the count is in the low dword)
-        if (claimed || match) { res = s; todo = false; }
+        if (WIDE) {
+            const bool match = todo && cur == fresh;
+            if (claimed || match) { atomicAdd(&cnts[s], 1u); res = s; todo = false; }
+        } else {
+            const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
+            // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
+            if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[s]), 1u);   // (the count is in the low dword)
+            if (claimed || match) { res = s; todo = false; }
+        }
         s = todo ? (s + 1) & smask : s;
     }
     return res;
 }
 
 // the general lookup: count field of `code` (BIN_NONE if absent)
-__device__ __forceinline__ uint32_t mini_lookup_slow(const unsigned long long *tab, uint32_t smask, uint32_t limit, uint64_t code, bool act)
+template <bool WIDE>
+__device__ __forceinline__ uint32_t mini_lookup_slow(const unsigned long long *tab, const uint32_t *cnts, uint32_t smask, uint32_t limit, uint64_t code, bool act)
 {
-    uint32_t s = mini_slot_hash(code) & smask;
+    uint32_t s = mini_slot_hash<WIDE>(code) & smask;
     uint32_t res = BIN_NONE;
     bool todo = act;
     for (uint32_t q = 0; q < limit; ++q) {
         if (!__any(todo)) break;
         const unsigned long long cur = tab[s];
-        const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
-        if (match) res = (uint32_t)(cur & HASH_CMASK);
+        const bool match = todo && (WIDE ? cur == code + 1ull : cur != 0 && (cur >> HASH_CBITS) == code);
+        if (match) res = WIDE ? cnts[s] : (uint32_t)(cur & HASH_CMASK);
         if (match || cur == 0) todo = false;
         s = todo ? (s + 1) & smask : s;
     }
@@ -508,7 +531,7 @@ constexpr uint32_t F_BUF = 32 * 1024, F_CNT = F_BUF + 4 * F_TILE, F_START = F_CN
                    F_WAVE = F_GBASE + 8 * 1024, F_END = F_WAVE + 64;
 constexpr int SHORT_MAX = PG_SHORT_MAX;                                 // a record with at most this many k-mers is "short"
 
-template <int CAP, bool SLOTS>
+template <int CAP, bool SLOTS, bool WIDE>
 __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
                                                                const unsigned long long *__restrict__ off,
                                                                const unsigned long long *__restrict__ n_short, MiniView t,
@@ -525,12 +548,15 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = n_slots < MAX_PROBE ? n_slots : MAX_PROBE;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    unsigned long long *ring = tab + n_slots + wave * RING;                          // [RING] codes of this wavefront
-    uint32_t *ring_row = reinterpret_cast<uint32_t *>(tab + n_slots + COUNT_WAVES * RING) + wave * RING;
+    uint32_t *const cnts = reinterpret_cast<uint32_t *>(tab + n_slots);             // WIDE: the count plane behind the key plane
+    const uint32_t tab_units = WIDE ? n_slots + n_slots / 2 : n_slots;              // 8-byte units of the table
+    unsigned long long *ring = tab + tab_units + wave * RING;                        // [RING] codes of this wavefront
+    uint32_t *ring_row = reinterpret_cast<uint32_t *>(tab + tab_units + COUNT_WAVES * RING) + wave * RING;
     const int k = t.k, lb = t.log2_bucket;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const int rc_sh0 = 2 * (32 - k);
     uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    uint32_t *slice_counts = reinterpret_cast<uint32_t *>(t.slots + (1ull << t.log2_slots)) + ((uint64_t)blockIdx.x << t.log2_bucket);   // WIDE
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
     // [r0, rs) short records (at most SHORT_MAX k-mers; the second scatter pass put them first), [rs, r1) the others
     const int64_t rs = n_short && CAP > SHORT_MAX ? r0 + (int64_t)n_short[blockIdx.x] : r0;
@@ -542,7 +568,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
 #else
 #define PG_STAMP(K) do { } while (0)
 #endif
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < tab_units; i += BIG_BLOCK) tab[i] = 0ull;
     if (threadIdx.x == 0) { emitted = 0; n_lookups = 0; }
     if (emit_slots) {
         // every occurrence that lies in a row leaves exactly one word, and a wavefront knows its records in advance (batches
@@ -588,7 +614,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         const uint32_t at = (head + lane) & (RING - 1);
         const uint64_t c = act ? ring[at] : 0ull;
         const uint32_t rw = act && emit_slots ? ring_row[at] : MINI_ROW_NONE;
-        const uint32_t sl = mini_insert_slow(tab, smask, limit, c, act);
+        const uint32_t sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act);
         full |= act && sl == 0xffffffffu;
         if (emit_slots) {
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
@@ -621,15 +647,21 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             for (int j = 0; j < CX; ++j) {                       // every first probe of the record in flight
                 const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
                 code[j] = fw < rc ? fw : rc;
-                sl[j] = mini_slot_hash(code[j]) & smask;
+                sl[j] = mini_slot_hash<WIDE>(code[j]) & smask;
                 cur[j] = j < n ? tab[sl[j]] : 0ull;
             }
             uint32_t hits = 0;                                   // bit j: settled by the first probe
 #pragma unroll
             for (int j = 0; j < CX; ++j) {
-                const bool hit = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j];
-                // (the count sits in the low 22 bits of the slot's low dword and stops far below 2^22: a 32-bit LDS add is enough)
-                if (hit && (uint32_t)(cur[j] & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[sl[j]]), 1u);
+                bool hit;
+                if (WIDE) {
+                    hit = j < n && cur[j] == code[j] + 1ull;
+                    if (hit) atomicAdd(&cnts[sl[j]], 1u);
+                } else {
+                    hit = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j];
+                    // (the count sits in the low 22 bits of the slot's low dword and stops far below 2^22: a 32-bit LDS add is enough)
+                    if (hit && (uint32_t)(cur[j] & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[sl[j]]), 1u);
+                }
                 if (hit) hits |= 1u << j;
             }
             if (emit_slots) {
@@ -687,9 +719,16 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             mybin[q] = 0;
             if (i < n_slots) {
                 const unsigned long long v = tab[i];
-                uint32_t c = (uint32_t)(v & HASH_CMASK);
-                if (c > HASH_SAT) c = HASH_SAT;
-                slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
+                uint32_t c;
+                if (WIDE) {
+                    c = cnts[i];
+                    slice[i] = v;
+                    slice_counts[i] = c;
+                } else {
+                    c = (uint32_t)(v & HASH_CMASK);
+                    if (c > HASH_SAT) c = HASH_SAT;
+                    slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
+                }
                 const uint32_t bin = c / window;
                 mybin[q] = (uint16_t)(v ? (bin < vsize ? bin + 1u : 0xffffu) : 0u);
             }
@@ -758,6 +797,16 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
     // the packed slice (an empty table needs no clearing: every slot is written); then counts -> bins, in place
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
         const unsigned long long v = tab[i];
+        if (WIDE) {
+            const uint32_t c = cnts[i];
+            slice[i] = v;
+            slice_counts[i] = c;
+            if (window && v) {
+                const uint32_t bin = c / window;
+                cnts[i] = bin < vsize ? bin + 1u : BIN_NONE;
+            }
+            continue;
+        }
         uint32_t c = (uint32_t)(v & HASH_CMASK);
         if (c > HASH_SAT) c = HASH_SAT;
         slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
@@ -801,11 +850,14 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             m = i < r1 ? meta[i] : 0xffffffffu;
             uint64_t code[CAP];
             unsigned long long cur[CAP];
+            uint32_t bin1[CAP];                                  // count field of a k-mer found at its home slot: bin + 1, or BIN_NONE
 #pragma unroll
             for (int j = 0; j < CAP; ++j) {
                 const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
                 code[j] = fw < rc ? fw : rc;
-                cur[j] = j < n ? tab[mini_slot_hash(code[j]) & smask] : 0ull;
+                const uint32_t sl = mini_slot_hash<WIDE>(code[j]) & smask;
+                cur[j] = j < n ? tab[sl] : 0ull;
+                bin1[j] = WIDE ? (j < n ? cnts[sl] : 0u) : 0u;
             }
             // settled by the first probe: a hit (emit, unless its bin is out of range) or an empty slot (cannot happen for a
             // counted k-mer; nothing to emit).  Slot by slot, ONE add on the bucket's counter per batch.
@@ -813,8 +865,9 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             uint32_t total = 0;
 #pragma unroll
             for (int j = 0; j < CAP; ++j) {
-                const bool hit = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j];
-                pm[j] = __ballot(hit && (uint32_t)(cur[j] & HASH_CMASK) != BIN_NONE);
+                const bool hit = j < n && (WIDE ? cur[j] == code[j] + 1ull : cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j]);
+                if (!WIDE) bin1[j] = (uint32_t)(cur[j] & HASH_CMASK);
+                pm[j] = __ballot(hit && bin1[j] != BIN_NONE);
                 total += (uint32_t)__popcll(pm[j]);
             }
             if (total) {                                         // (uniform)
@@ -823,13 +876,13 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                 at = __shfl(at, 0);
 #pragma unroll
                 for (int j = 0; j < CAP; ++j) {
-                    if ((pm[j] >> lane) & 1ull) words[wb + at + lanes_below(pm[j])] = (row << vbits) | ((uint32_t)(cur[j] & HASH_CMASK) - 1u);
+                    if ((pm[j] >> lane) & 1ull) words[wb + at + lanes_below(pm[j])] = (row << vbits) | (bin1[j] - 1u);
                     at += (uint32_t)__popcll(pm[j]);
                 }
             }
 #pragma unroll
             for (int j = 0; j < CAP; ++j) {                      // collisions: onto the ring
-                const bool pend = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) != code[j];
+                const bool pend = j < n && cur[j] != 0 && (WIDE ? cur[j] != code[j] + 1ull : (cur[j] >> HASH_CBITS) != code[j]);
                 const unsigned long long mask = __ballot(pend);
                 if (mask) {
                     if (pend) {
@@ -843,7 +896,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                         const uint64_t c = ring[at];
                         const uint32_t rw = ring_row[at];
                         head += 64;
-                        const uint32_t b1 = mini_lookup_slow(tab, smask, limit, c, true);
+                        const uint32_t b1 = mini_lookup_slow<WIDE>(tab, cnts, smask, limit, c, true);
                         emit(b1 != BIN_NONE, rw, b1);
                     }
                 }
@@ -854,7 +907,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             const uint32_t at = (head + lane) & (RING - 1);
             const uint64_t c = act ? ring[at] : 0ull;
             const uint32_t rw = act ? ring_row[at] : 0u;
-            const uint32_t b1 = mini_lookup_slow(tab, smask, limit, c, act);
+            const uint32_t b1 = mini_lookup_slow<WIDE>(tab, cnts, smask, limit, c, act);
             emit(b1 != BIN_NONE, rw, b1);
         }
     }
@@ -874,11 +927,13 @@ struct MiniPlan {
 // (homopolymers, short tandem repeats).  The bucket workgroups treat every record in `cap` unrolled, predicated steps: cutting
 // those rare runs at W costs a few records and saves a quarter of the steps (k = 21: 12 -> 9; mini_count 19.1 -> 18.5 ms).
 // PG_MINI_CAP overrides (tuning).
-static_assert(PG_HASH_MAX_K - MINI_M + 1 <= 9, "count kernels are instantiated for up to 9 k-mers per record");
+static_assert(MINI_MAX_WINDOW <= 9, "count kernels are instantiated for up to 9 k-mers per record");
 int mini_cap(int k)
 {
+    int wc, woff;
+    mini_window(k, &wc, &woff);
     int cap = 33 - k < MINI_MAX_LEN ? 33 - k : MINI_MAX_LEN;
-    if (k - MINI_M + 1 < cap) cap = k - MINI_M + 1;
+    if (wc < cap) cap = wc;
     static const int forced = getenv("PG_MINI_CAP") ? atoi(getenv("PG_MINI_CAP")) : 0;
     if (forced >= 1 && forced < cap) cap = forced;
     return cap;
@@ -887,10 +942,13 @@ int mini_cap(int k)
 int check_mini(const pg_table *t, const char *who)
 {
     if (!t || !t->data) return pg_fail(PG_EINVAL, "%s: table descriptor is null", who);
-    if (t->kind != PG_TABLE_MINI) return pg_fail(PG_EINVAL, "%s: needs a PG_TABLE_MINI table", who);
-    if (t->k < PG_MINI_MIN_K || t->k > PG_HASH_MAX_K) return pg_fail(PG_EINVAL, "%s: mini tables need %d <= k <= %d (got %d)", who, PG_MINI_MIN_K, PG_HASH_MAX_K, t->k);
-    if (t->log2_bucket_slots < 4 || t->log2_bucket_slots > PG_BUCKET_MAX_LOG2_SLOTS)
-        return pg_fail(PG_EINVAL, "%s: log2_bucket_slots %d out of range [4,%d]", who, t->log2_bucket_slots, PG_BUCKET_MAX_LOG2_SLOTS);
+    if (t->kind != PG_TABLE_MINI && t->kind != PG_TABLE_MINI_WIDE) return pg_fail(PG_EINVAL, "%s: needs a PG_TABLE_MINI or PG_TABLE_MINI_WIDE table", who);
+    const bool wide = t->kind == PG_TABLE_MINI_WIDE;
+    const int k_lo = wide ? PG_HASH_MAX_K + 1 : PG_MINI_MIN_K, k_hi = wide ? PG_WIDE_MAX_K : PG_HASH_MAX_K;
+    if (t->k < k_lo || t->k > k_hi) return pg_fail(PG_EINVAL, "%s: %s tables need %d <= k <= %d (got %d)", who, wide ? "wide mini" : "mini", k_lo, k_hi, t->k);
+    const int lb_hi = wide ? PG_MINI_WIDE_MAX_LOG2_BUCKET_SLOTS : PG_BUCKET_MAX_LOG2_SLOTS;
+    if (t->log2_bucket_slots < 4 || t->log2_bucket_slots > lb_hi)
+        return pg_fail(PG_EINVAL, "%s: log2_bucket_slots %d out of range [4,%d]", who, t->log2_bucket_slots, lb_hi);
     const int bits = t->log2_slots - t->log2_bucket_slots;
     if (bits < 0 || bits > PG_MINI_MAX_LOG2_BUCKETS) return pg_fail(PG_EINVAL, "%s: 2^%d buckets (at most 2^%d)", who, bits, PG_MINI_MAX_LOG2_BUCKETS);
     return PG_OK;
@@ -900,6 +958,7 @@ int plan_mini(const pg_table *t, int64_t n_words, MiniPlan *p)
 {
     p->bits = t->log2_slots - t->log2_bucket_slots;
     p->bits1 = p->bits < MINI_BITS1 ? p->bits : MINI_BITS1;
+    if (p->bits - p->bits1 > META_D2_BITS) p->bits1 = p->bits - META_D2_BITS;       // 2^16 buckets: 512 regions
     p->bits2 = p->bits - p->bits1;
     p->n_rounds = (n_words + ROUND_WORDS - 1) / ROUND_WORDS;
     p->n_chunks = (n_words + MINI_CHUNK_WORDS - 1) / MINI_CHUNK_WORDS;
@@ -976,14 +1035,26 @@ extern "C" int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vs
     return (int64_t)sl.total;
 }
 
-#define PG_MINI_DISPATCH_W(W_, CALL)                                                                                        \
-    switch (W_) {                                                                                                           \
-    case 4: { constexpr int W = 4; CALL; } break;                                                                           \
-    case 5: { constexpr int W = 5; CALL; } break;                                                                           \
-    case 6: { constexpr int W = 6; CALL; } break;                                                                           \
-    case 7: { constexpr int W = 7; CALL; } break;                                                                           \
-    case 8: { constexpr int W = 8; CALL; } break;                                                                           \
-    default: { constexpr int W = 9; CALL; } break;                                                                          \
+// the first-pass kernels are instantiated per window length (registers of the rolling minimum); k > 21 runs the delayed
+// central window of 8 or 9 M-mers (mini_window)
+#define PG_MINI_DISPATCH_W(K_, CALL)                                                                                        \
+    {                                                                                                                       \
+        int wc_, woff;                                                                                                      \
+        mini_window(K_, &wc_, &woff);                                                                                       \
+        if ((K_) > PG_HASH_MAX_K) {                                                                                         \
+            constexpr bool DELAY = true;                                                                                    \
+            if (wc_ == 8) { constexpr int W = 8; CALL; } else { constexpr int W = 9; CALL; }                                \
+        } else {                                                                                                            \
+            constexpr bool DELAY = false;                                                                                   \
+            switch (wc_) {                                                                                                  \
+            case 4: { constexpr int W = 4; CALL; } break;                                                                   \
+            case 5: { constexpr int W = 5; CALL; } break;                                                                   \
+            case 6: { constexpr int W = 6; CALL; } break;                                                                   \
+            case 7: { constexpr int W = 7; CALL; } break;                                                                   \
+            case 8: { constexpr int W = 8; CALL; } break;                                                                   \
+            default: { constexpr int W = 9; CALL; } break;                                                                  \
+            }                                                                                                               \
+        }                                                                                                                   \
     }
 
 extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
@@ -1013,14 +1084,17 @@ extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_
         if (with_rows)
             hipLaunchKernelGGL(round_rows_kernel, dim3((unsigned)((p.n_rounds + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_end, rows->n_rows,
                                word_begin, p.n_rounds, round_row);
-        const size_t lds = (size_t)nb * 4 + 1024;
+        const int nb_launch = nb < (1 << 15) ? nb : (1 << 15);
+        const size_t lds = (size_t)nb_launch * 4 + ((size_t)4 << MINI_MAX_BITS1);
         const int grid = (int)(p.n_chunks < 512 ? p.n_chunks : 512);
-        PG_MINI_DISPATCH_W(t->k - PG_MINI_M + 1,
-            if ((rc = raise_lds_limit((const void *)mini_plan_kernel<W>, lds, "pg_mini_plan"))) return rc;
-            hipLaunchKernelGGL(mini_plan_kernel<W>, dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, p.bits, p.bits2, mini_cap(t->k),
-                               with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
-                               with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
-                               (const int32_t *)round_row, hist, chunk_tab, p.n_chunks, p.chunk_stride))
+        for (int b_base = 0; b_base < nb; b_base += nb_launch) {
+            PG_MINI_DISPATCH_W(t->k,
+                if ((rc = raise_lds_limit((const void *)(mini_plan_kernel<W, DELAY>), lds, "pg_mini_plan"))) return rc;
+                hipLaunchKernelGGL((mini_plan_kernel<W, DELAY>), dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, p.bits2, mini_cap(t->k),
+                                   with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
+                                   with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
+                                   (const int32_t *)round_row, hist, chunk_tab, p.n_chunks, p.chunk_stride, (uint32_t)b_base, nb_launch))
+        }
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)hist, (int64_t)nb, off);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(1u << p.bits1), dim3(BIG_BLOCK), 0, s, chunk_tab, p.n_chunks, (const unsigned long long *)off,
@@ -1043,7 +1117,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     if (window > 0) {
         if (!with_rows) return pg_fail(PG_EINVAL, "pg_mini_count: the lookup pass needs rows");
         if (!shuffle_ws) return pg_fail(PG_EINVAL, "pg_mini_count: null shuffle workspace");
-        if (vsize > PG_SHUFFLE_MAX_VSIZE || (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT)
+        if (vsize > PG_SHUFFLE_MAX_VSIZE || (t->kind == PG_TABLE_MINI && (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT))
             return pg_fail(PG_EINVAL, "pg_mini_count: window %d x vector size %d outside the exact range of the table", window, vsize);
     }
     MiniPlan p;
@@ -1076,15 +1150,19 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         if ((int64_t)sl.total > shuffle_ws_bytes || (reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0)
             return pg_fail(PG_EINVAL, "pg_mini_count: shuffle workspace of %lld bytes (256-byte aligned), %lld needed", (long long)shuffle_ws_bytes, (long long)sl.total);
     }
-    const size_t slice_lds = ((size_t)8 << t->log2_bucket_slots) + (size_t)COUNT_WAVES * RING * 12;      // table + the wavefronts' rings
+    const bool wide = t->kind == PG_TABLE_MINI_WIDE;              // 8-byte keys + 4-byte counts per slot
+    const size_t slice_lds = ((size_t)(wide ? 12 : 8) << t->log2_bucket_slots) + (size_t)COUNT_WAVES * RING * 12;      // table + the wavefronts' rings
     if (word_end > word_begin) {
-        const size_t lds1 = sizeof(Scatter1Lds);
-        PG_MINI_DISPATCH_W(t->k - PG_MINI_M + 1,
-            if ((rc = raise_lds_limit((const void *)mini_scatter_kernel<W>, lds1, "pg_mini_count"))) return rc;
-            hipLaunchKernelGGL(mini_scatter_kernel<W>, dim3((unsigned)p.n_chunks), dim3(S1_BLOCK), lds1, s, codes, valid, word_begin, word_end, t->k, p.bits,
-                               p.bits2, mini_cap(t->k), with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
-                               with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
+#define PG_MINI_LAUNCH_SCATTER(N1_)                                                                                          \
+        PG_MINI_DISPATCH_W(t->k,                                                                                            \
+            const size_t lds1 = sizeof(Scatter1Lds<N1_>);                                                                   \
+            if ((rc = raise_lds_limit((const void *)(mini_scatter_kernel<W, DELAY, N1_>), lds1, "pg_mini_count"))) return rc; \
+            hipLaunchKernelGGL((mini_scatter_kernel<W, DELAY, N1_>), dim3((unsigned)p.n_chunks), dim3(S1_BLOCK), lds1, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, \
+                               p.bits2, mini_cap(t->k), with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr, \
+                               with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr, \
                                (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride))
+        if (p.bits1 > MINI_BITS1) { PG_MINI_LAUNCH_SCATTER(512) } else { PG_MINI_LAUNCH_SCATTER(256) }
+#undef PG_MINI_LAUNCH_SCATTER
         if (p.bits2) {
             const int tiles_x = 96;
             hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
@@ -1107,21 +1185,18 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         if (count_lds < F_END) count_lds = F_END;
     }
     unsigned long long *emit_end = window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
+#define PG_MINI_LAUNCH_COUNT_(CAP_, SLOTS_, WIDE_, LDS_)                                                                     \
+    do {                                                                                                                    \
+        if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_>), LDS_, "pg_mini_count"))) return rc; \
+        hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_>), dim3(nb), dim3(BIG_BLOCK), LDS_, s,                     \
+                           (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a),  \
+                           (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,        \
+                           sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                             \
+    } while (0)
 #define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \
     do {                                                                                                                    \
-        if (slots_form) {                                                                                                   \
-            if ((rc = raise_lds_limit((const void *)mini_count_kernel<CAP_, true>, count_lds, "pg_mini_count"))) return rc;   \
-            hipLaunchKernelGGL((mini_count_kernel<CAP_, true>), dim3(nb), dim3(BIG_BLOCK), count_lds, s,                    \
-                               (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a), \
-                               (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,    \
-                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                         \
-        } else {                                                                                                            \
-            if ((rc = raise_lds_limit((const void *)mini_count_kernel<CAP_, false>, slice_lds, "pg_mini_count"))) return rc;  \
-            hipLaunchKernelGGL((mini_count_kernel<CAP_, false>), dim3(nb), dim3(BIG_BLOCK), slice_lds, s,                   \
-                               (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a), \
-                               (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,    \
-                               sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                         \
-        }                                                                                                                   \
+        if (wide) { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, true, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, slice_lds); } \
+        else { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, slice_lds); }    \
     } while (0)
     switch (mini_cap(t->k)) {                                          // k-mers per record at most (as the first pass cuts them)
     case 1: case 2: case 3: case 4: PG_MINI_LAUNCH_COUNT(4); break;
@@ -1130,6 +1205,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     default: PG_MINI_LAUNCH_COUNT(9); break;        // (cap <= W <= 9: see mini_cap)
     }
 #undef PG_MINI_LAUNCH_COUNT
+#undef PG_MINI_LAUNCH_COUNT_
     return check_launch("pg_mini_count");
 }
 

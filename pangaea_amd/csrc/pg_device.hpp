@@ -134,21 +134,36 @@ __device__ __forceinline__ uint64_t rev2_64(uint64_t x)
     const uint32_t lo = swap_pairs32(__brev((uint32_t)x)), hi = swap_pairs32(__brev((uint32_t)(x >> 32)));
     return ((uint64_t)lo << 32) | hi;
 }
-// (two 24-bit multiplies -- v_mul_u32_u24 issues at full rate, a 32-bit v_mul_lo_u32 at a quarter of it, and this runs once per
+// (24-bit multiplies -- v_mul_u32_u24 issues at full rate, a 32-bit v_mul_lo_u32 at a quarter of it, and this runs once per
 // k-mer occurrence in kernels that are bound by VALU issue; the fold brings the well-mixed high product bits, which depend
-// on all 42 bits of the code, down to the slot index)
-__device__ __forceinline__ uint32_t mini_slot_hash(uint64_t code)
+// on all bits of the code, down to the slot index).  WIDE: codes of k > 21 (up to 62 bits) add a third term, which is 0 for
+// the 42-bit codes -- the two forms agree wherever both apply.
+template <bool WIDE = false> __device__ __forceinline__ uint32_t mini_slot_hash(uint64_t code)
 {
     const uint32_t a = (uint32_t)code & 0xffffffu, b = (uint32_t)(code >> 21);
     uint32_t x = __umul24(a, 0x9E3779u) ^ __umul24(b, 0xC2B2AFu);
+    if (WIDE) x ^= __umul24((uint32_t)(code >> 45), 0x85EBCBu);
     x ^= x >> 15;
     return x;
+}
+// The M-mers of a k-mer that compete for its minimizer: all k - M + 1 of them up to 9, beyond that (k > 21) the CENTRAL 8 or 9
+// (same parity as k - M + 1, so that `off` M-mers are left out on either side).  The reverse complement maps M-mer t to
+// k - M - t, i.e. the central window onto itself: both strands pick the same M-mer, as they must.  A window of at most 9
+// keeps the rolling minimum of the first scatter pass in 9 registers for every k.
+constexpr int MINI_MAX_WINDOW = 9;
+__host__ __device__ __forceinline__ void mini_window(int k, int *wc, int *off)
+{
+    const int w = k - MINI_M + 1;
+    *wc = w <= MINI_MAX_WINDOW ? w : MINI_MAX_WINDOW - 1 + (w & 1);
+    *off = (w - *wc) / 2;
 }
 // minimizer value of one k-mer given as a (forward or canonical) code, newest character in the low bits
 __device__ __forceinline__ uint32_t mini_minimizer_of(uint64_t code, int k)
 {
+    int wc, off;
+    mini_window(k, &wc, &off);
     uint32_t best = 0xffffffffu;
-    for (int t = 0; t + MINI_M <= k; ++t) {
+    for (int t = off; t < off + wc; ++t) {
         const uint32_t fw = (uint32_t)(code >> (2 * t)) & MINI_MMASK;
         const uint32_t rc = (swap_pairs32(__brev(fw)) >> (32 - 2 * MINI_M)) ^ MINI_MCOMP;
         const uint32_t h = mhash(fw < rc ? fw : rc);

@@ -48,7 +48,8 @@ class KmerTable:
     def __init__(self, k: int, kind: str, data: torch.Tensor, log2_slots: int = 0, log2_bucket: int = 0):
         self.k, self.kind, self.data, self.log2_slots, self.log2_bucket = int(k), kind, data, int(log2_slots), int(log2_bucket)
         self.status = torch.zeros(2, dtype=torch.int32, device=data.device)
-        code = {"dense": _lib.TABLE_DENSE, "hash": _lib.TABLE_HASH, "wide": _lib.TABLE_WIDE, "mini": _lib.TABLE_MINI}[kind]
+        code = {"dense": _lib.TABLE_DENSE, "hash": _lib.TABLE_HASH, "wide": _lib.TABLE_WIDE, "mini": _lib.TABLE_MINI,
+                "miniw": _lib.TABLE_MINI_WIDE}[kind]
         self._desc = _lib.pg_table(code, self.k, self.log2_slots, self.log2_bucket, data.data_ptr())
         self._empty = True               # nothing counted since allocation / reset()
         self._workspace = None
@@ -89,7 +90,7 @@ class KmerTable:
             if k > _lib.DENSE_MAX_K:
                 raise ValueError(f"dense tables need k <= {_lib.DENSE_MAX_K}")
             return cls(k, "dense", torch.zeros(4 ** k, dtype=torch.int32, device=device))
-        if kind == "mini":
+        if kind in ("mini", "miniw"):
             want = max(1024, int((distinct_hint or 1 << 20) / load))
             return cls.mini_with_slots(k, device, max(10, math.ceil(math.log2(want))), log2_bucket)
         if kind not in ("hash", "wide"):
@@ -103,19 +104,31 @@ class KmerTable:
         return cls.with_slots(k, device, log2, log2_bucket)
 
     @staticmethod
+    def mini_max_log2_bucket(k: int) -> int:
+        """slots of one LDS-resident bucket: 8-byte packed slots up to k = 21, 8-byte keys + 4-byte counts beyond"""
+        return _lib.BUCKET_MAX_LOG2_SLOTS if k <= _lib.HASH_MAX_K else _lib.MINI_WIDE_MAX_LOG2_BUCKET_SLOTS
+
+    @staticmethod
     def mini_applies(k: int, log2_slots: int, log2_bucket: int | None = None) -> bool:
         """can a MINI table (minimizer buckets, built from super-k-mers) hold 2^log2_slots slots for this k?"""
-        lb = min(_lib.BUCKET_MAX_LOG2_SLOTS, log2_slots) if log2_bucket is None else log2_bucket
-        return (_lib.MINI_MIN_K <= k <= _lib.HASH_MAX_K and 4 <= lb <= _lib.BUCKET_MAX_LOG2_SLOTS
-                and 0 <= log2_slots - lb <= _lib.MINI_MAX_LOG2_BUCKETS)
+        if not _lib.MINI_MIN_K <= k <= _lib.WIDE_MAX_K:
+            return False
+        top = KmerTable.mini_max_log2_bucket(k)
+        lb = min(top, log2_slots) if log2_bucket is None else log2_bucket
+        return 4 <= lb <= top and 0 <= log2_slots - lb <= _lib.MINI_MAX_LOG2_BUCKETS
 
     @classmethod
     def mini_with_slots(cls, k: int, device, log2_slots: int, log2_bucket: int | None = None) -> "KmerTable":
-        lb = min(_lib.BUCKET_MAX_LOG2_SLOTS, log2_slots) if log2_bucket is None else log2_bucket
+        """``mini`` (k <= 21: packed 8-byte slots) or ``miniw`` (22 <= k <= 31: keys + counts planes, as ``wide``)"""
+        top = cls.mini_max_log2_bucket(k)
+        lb = min(top, log2_slots) if log2_bucket is None else log2_bucket
         if not cls.mini_applies(k, log2_slots, lb):
-            raise ValueError(f"mini tables need {_lib.MINI_MIN_K} <= k <= {_lib.HASH_MAX_K} and at most 2^{_lib.MINI_MAX_LOG2_BUCKETS} buckets "
-                             f"of at most 2^{_lib.BUCKET_MAX_LOG2_SLOTS} slots (k {k}, 2^{log2_slots} slots, buckets of 2^{lb})")
-        return cls(k, "mini", torch.zeros(1 << log2_slots, dtype=torch.int64, device=device), log2_slots, lb)
+            raise ValueError(f"mini tables need {_lib.MINI_MIN_K} <= k <= {_lib.WIDE_MAX_K} and at most 2^{_lib.MINI_MAX_LOG2_BUCKETS} buckets "
+                             f"of at most 2^{top} slots (k {k}, 2^{log2_slots} slots, buckets of 2^{lb})")
+        n = 1 << log2_slots
+        if k > _lib.HASH_MAX_K:
+            return cls(k, "miniw", torch.zeros(n + n // 2, dtype=torch.int64, device=device), log2_slots, lb)
+        return cls(k, "mini", torch.zeros(n, dtype=torch.int64, device=device), log2_slots, lb)
 
     @classmethod
     def wide_with_slots(cls, k: int, device, log2_slots: int) -> "KmerTable":
@@ -138,7 +151,7 @@ class KmerTable:
         codes = torch.as_tensor(np.asarray(codes).astype(np.int64))
         counts = torch.as_tensor(np.asarray(counts).astype(np.int64))
         table = cls.alloc(k, device, kind, distinct_hint=max(1024, codes.numel()))
-        if table.kind == "wide":
+        if table.kind in ("wide", "miniw"):
             c = codes.to(table.device).contiguous()
             n = counts.to(table.device, torch.int32).contiguous()
             table._empty = False
@@ -172,7 +185,7 @@ class KmerTable:
 
     def reset(self) -> "KmerTable":
         """forget every count.  Bucketed tables are not even cleared: the next count overwrites every slice."""
-        if not (self.kind in ("hash", "mini") and self.log2_bucket):
+        if not (self.kind in ("hash", "mini", "miniw") and self.log2_bucket):
             self.data.zero_()
         self.status.zero_()
         self._empty = True
@@ -247,7 +260,7 @@ class KmerTable:
             self._rows_desc_keepalive = desc
             return C.byref(desc)
 
-        if self.kind == "mini":
+        if self.kind in ("mini", "miniw"):
             if deferred_group is not None:
                 raise ValueError("mini tables have no deferred form")
             return self._count_mini(stream, word_begin, word_end, valid_ptr, rows, rows_arg, emit, lenient, check)
@@ -320,7 +333,7 @@ class KmerTable:
         if rows is not None and keep is None:
             raise ValueError("mini tables need sorted, disjoint, non-empty rows (at most 2^21 - 2 of them)")
         fuse = (emit is not None and keep is not None and n_words > 0 and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1
-                and emit[0] * emit[1] <= _lib.HASH_COUNT_SAT)
+                and (self.kind == "miniw" or emit[0] * emit[1] <= _lib.HASH_COUNT_SAT))
         key = (stream.codes.data_ptr(), valid_ptr, word_begin, word_end, id(keep), bool(lenient), self.log2_slots, self.log2_bucket)
         with torch.cuda.device(self.device):
             if self._mini_plan is None or self._mini_plan[0] != key:
@@ -355,7 +368,7 @@ class KmerTable:
 
     def can_shuffle(self, plan: "Plan", window: int, vsize: int) -> bool:
         """can ``abundance_from_records`` build the rows of this plan (instead of table lookups)?"""
-        if self.kind == "mini":
+        if self.kind in ("mini", "miniw"):
             return self._records is not None and self._records[0] is plan and self._emitted == (int(window), int(vsize))
         return self.has_records_for(plan, vsize)
 
@@ -369,7 +382,7 @@ class KmerTable:
             raise RuntimeError("no partition records for these rows: count(stream, rows=plan) first")
         n_words = self._records[1]
         L = _lib.load()
-        if self.kind == "mini":
+        if self.kind in ("mini", "miniw"):
             plan_ws = self._mini_plan[1]
             with torch.cuda.device(self.device):
                 _lib.check(L.pg_mini_abundance_from_emitted(self.desc(), C.byref(plan.rows_desc), vsize, out.data_ptr(), plan_ws.data_ptr(),
@@ -410,7 +423,7 @@ class KmerTable:
 
     @property
     def n_buckets(self) -> int:
-        return 1 << (self.log2_slots - self.log2_bucket) if self.kind in ("hash", "mini") and self.log2_bucket else 1
+        return 1 << (self.log2_slots - self.log2_bucket) if self.kind in ("hash", "mini", "miniw") and self.log2_bucket else 1
 
     def bucket_counts(self) -> torch.Tensor:
         """occupied slots per bucket, int64 [n_buckets] -- the segment lengths of ``compact()`` (slot order = bucket order)"""
@@ -589,7 +602,7 @@ class KmerTable:
 
     def occupancy(self) -> float:
         self._require_counts()
-        if self.kind == "wide":
+        if self.kind in ("wide", "miniw"):
             return float(torch.count_nonzero(self._wide_parts()[0]).item()) / (1 << self.log2_slots)
         if self.kind not in ("hash", "mini"):
             return float("nan")
@@ -602,7 +615,7 @@ class KmerTable:
             t = self.data.cpu().numpy().view(np.uint32)
             codes = np.nonzero(t)[0].astype(np.uint64)
             return codes, t[codes.astype(np.int64)].astype(np.uint64)
-        if self.kind == "wide":
+        if self.kind in ("wide", "miniw"):
             keys, cnts = self._wide_parts()
             occ = keys != 0
             codes = (keys[occ] - 1).cpu().numpy().view(np.uint64)
@@ -680,9 +693,9 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
     """build the table of one stream; a full hash table is re-built with four times the slots.  ``emit`` = (window,
     vector_size) fuses the lookup pass of the abundance rows into the count where that applies (``KmerTable.count``)."""
     resolved = kind or KmerTable.default_kind(k)
-    auto_mini = (kind is None and resolved == "hash" and rows is not None and emit is not None and rows.shuffle_ok
+    auto_mini = (kind is None and resolved in ("hash", "wide") and rows is not None and emit is not None and rows.shuffle_ok
                  and rows.n_rows <= _lib.MINI_MAX_ROWS and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1
-                 and emit[0] * emit[1] <= _lib.HASH_COUNT_SAT and _lib.MINI_MIN_K <= k <= _lib.HASH_MAX_K
+                 and (resolved == "wide" or emit[0] * emit[1] <= _lib.HASH_COUNT_SAT) and _lib.MINI_MIN_K <= k <= _lib.WIDE_MAX_K
                  and os.environ.get("PANGAEA_NO_MINI", "0") in ("", "0"))
     if distinct_hint is None and resolved != "dense":
         # size from a HyperLogLog pass (as cheap as the bucket histogram) instead of guessing the coverage; +10 % covers
@@ -696,7 +709,7 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
         # (at most 2^15 buckets of 2^14 slots) holds the table
         want = max(1024, int(distinct_hint / load))
         if KmerTable.mini_applies(k, max(10, math.ceil(math.log2(want)))):
-            kind = "mini"
+            kind = "mini" if k <= _lib.HASH_MAX_K else "miniw"
     table = KmerTable.alloc(k, stream.device, kind, distinct_hint, load=load, log2_bucket=log2_bucket)
     while True:
         try:
@@ -705,11 +718,12 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
             if e.code != _lib.PG_ETABLEFULL or table.log2_slots >= max_log2_slots:
                 raise
             log2 = min(max_log2_slots, table.log2_slots + 2)
-            if table.kind == "mini":
-                lb = min(_lib.BUCKET_MAX_LOG2_SLOTS, table.log2_bucket + 2)
+            if table.kind in ("mini", "miniw"):
+                lb = min(KmerTable.mini_max_log2_bucket(k), table.log2_bucket + 2)
                 del table
                 table = (KmerTable.mini_with_slots(k, stream.device, log2, lb) if KmerTable.mini_applies(k, log2, lb)
-                         else KmerTable.with_slots(k, stream.device, log2))
+                         else KmerTable.with_slots(k, stream.device, log2) if k <= _lib.HASH_MAX_K
+                         else KmerTable.wide_with_slots(k, stream.device, log2))
                 continue
             if table.kind == "wide":
                 del table

@@ -37,6 +37,19 @@ def _same_items(a, b):
     (17, 20, 8, 7, 33, 600, 3000),
     (19, 21, 12, 25, 512, 2000, 3000),
     (20, 20, 11, 1, 512, 2000, 3000),
+    (21, 24, 8, 10, 400, 2000, 3000),       # 2^16 buckets: 512 regions in the first pass, the plan in two bucket ranges
+    (29, 24, 8, 10, 400, 2000, 1500),
+    # k > 21 (PG_TABLE_MINI_WIDE: keys + counts planes, the minimizer over the central 8 / 9 M-mers, delayed by 1..5 characters)
+    (22, 20, 13, 10, 400, 2000, 3000),
+    (23, 19, 10, 3, 64, 600, 1500),
+    (24, 20, 12, 2, 50, 2000, 1500),
+    (25, 18, 13, 1, 512, 2000, 1500),
+    (26, 19, 9, 10, 400, 2000, 1500),
+    (27, 20, 11, 10, 400, 2000, 3000),
+    (28, 18, 12, 5, 100, 302, 1500),
+    (29, 19, 13, 10, 400, 2000, 1500),
+    (30, 20, 8, 1, 6, 2000, 1500),
+    (31, 20, 13, 10, 400, 2000, 3000),
 ])
 def test_mini_table_and_rows_against_oracle(k, log2_slots, log2_bucket, window, vsize, min_len, n_pairs):
     cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=min(37, max(1, n_pairs // 20)), n_genomes=3, genome_len=30_000, fragment=8_000,
@@ -47,7 +60,7 @@ def test_mini_table_and_rows_against_oracle(k, log2_slots, log2_bucket, window, 
     t = kmer.KmerTable.mini_with_slots(k, DEV, log2_slots, log2_bucket)
     t.data.fill_(0x7FFF_FFFF_FFFF)                      # a fresh table is never cleared: every slot must be overwritten
     t.count(s, rows=plan, emit=(window, vsize))
-    assert t.kind == "mini" and t._emitted == (window, vsize)
+    assert t.kind == ("mini" if k <= 21 else "miniw") and t._emitted == (window, vsize)
     otab, otnf, oabd = _oracle(s, rows, k, window, vsize)
     assert _same_items(t.items(), otab.items())
     tnf, abd = kmer.features(s, plan, k_tnf=4, table=t, window=window, vsize=vsize)                 # from the emitted words
@@ -56,7 +69,7 @@ def test_mini_table_and_rows_against_oracle(k, log2_slots, log2_bucket, window, 
     _, abd_l = kmer.features(s, rows, k_tnf=None, table=t, window=window, vsize=vsize, seg_chars=64)  # by lookups in the mini table
     assert torch.equal(abd_l, abd)
     _, abd_o = kmer.features(s, plan, k_tnf=None, table=t, window=window + 1, vsize=vsize)          # other parameters: lookups too
-    h = kmer.count_kmers(s, k, kind="hash")
+    h = kmer.count_kmers(s, k, kind="hash" if k <= 21 else "wide")
     _, want = kmer.features(s, rows, k_tnf=None, table=h, window=window + 1, vsize=vsize)
     assert torch.equal(abd_o, want)
     # counting again (reset) reuses the partition plan and gives the same table and rows
@@ -67,7 +80,7 @@ def test_mini_table_and_rows_against_oracle(k, log2_slots, log2_bucket, window, 
     assert torch.equal(abd2, abd) and _same_items(t.items(), otab.items())
 
 
-@pytest.mark.parametrize("k,log2_slots,log2_bucket", [(21, 22, 10), (18, 19, 14)])
+@pytest.mark.parametrize("k,log2_slots,log2_bucket", [(21, 22, 10), (18, 19, 14), (27, 20, 11), (31, 19, 13)])
 def test_mini_general_lookup_form(k, log2_slots, log2_bucket, monkeypatch):
     """the lookups' general form (records read and probed a second time: what row sets too large for the (row, slot) words
     take) gives the same rows as the slot form"""
@@ -102,6 +115,18 @@ def test_mini_table_only_and_from_items():
         t.count(s)                                                  # one count per fresh table
     with pytest.raises(ValueError):
         kmer.KmerTable.mini_with_slots(15, DEV, 20)
+    # k = 27: entries of a dump into a wide mini table (pg_kmer_merge_wide places them by minimizer bucket), auto-selection
+    w = kmer.count_kmers(s, 27, rows=kmer.Plan(rows, DEV), emit=(2, 100))
+    otab = oracle.Table(27, threads=4).count(s.decode())
+    assert w.kind == "miniw" and _same_items(w.items(), otab.items())
+    codes, counts = otab.items()
+    v = kmer.KmerTable.from_items(27, codes, counts, DEV, "miniw")
+    assert _same_items(v.items(), otab.items())
+    _, a = kmer.features(s, rows, k_tnf=None, table=v, window=2, vsize=100)
+    _, b = kmer.features(s, rows, k_tnf=None, table=kmer.count_kmers(s, 27, kind="wide"), window=2, vsize=100)
+    assert torch.equal(a, b) and int(a.sum()) > 0
+    with pytest.raises(ValueError):
+        kmer.KmerTable.mini_with_slots(27, DEV, 20, 14)             # 12-byte slots: buckets of at most 2^13
 
 
 def test_mini_every_kmer_its_own_record():
