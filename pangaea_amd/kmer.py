@@ -708,8 +708,14 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
         # one GPU, rows and abundance parameters known: the super-k-mer pipeline (table by minimizer buckets) where its geometry
         # (at most 2^15 buckets of 2^14 slots) holds the table
         want = max(1024, int(distinct_hint / load))
-        if KmerTable.mini_applies(k, max(10, math.ceil(math.log2(want)))):
+        log2 = max(10, math.ceil(math.log2(want)))
+        if KmerTable.mini_applies(k, log2):
             kind = "mini" if k <= _lib.HASH_MAX_K else "miniw"
+        elif KmerTable.mini_applies(k, log2 - 1) and distinct_hint <= 0.7 * (1 << (log2 - 1)):
+            # the largest geometry (2^16 buckets) at a higher load still beats the other pipelines by far (k = 31, 10 M pairs:
+            # 2^29 slots at load 0.45 instead of a 2^30-slot direct table)
+            kind = "mini" if k <= _lib.HASH_MAX_K else "miniw"
+            load = distinct_hint / float(1 << (log2 - 1))
     table = KmerTable.alloc(k, stream.device, kind, distinct_hint, load=load, log2_bucket=log2_bucket)
     while True:
         try:
