@@ -230,9 +230,10 @@ __global__ void mini_total_kernel(const unsigned long long *__restrict__ off, in
 }
 
 // exclusive scan of cnt[0..N) -> start[0..N] by the first N / 64 wavefronts (N = 128 or 256); every lane of the workgroup calls
-template <int N>
+template <int N, bool LDS_ONLY = false>
 __device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start, uint32_t *wave_tot)
 {
+    auto sync = [] { if (LDS_ONLY) lds_sync(); else __syncthreads(); };
     uint32_t v = 0, incl = 0;
     if (threadIdx.x < N) {
         v = cnt[threadIdx.x];
@@ -244,14 +245,14 @@ __device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start
         }
         if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
     }
-    __syncthreads();
+    sync();
     if (threadIdx.x < N) {
         uint32_t before = 0;
         for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += wave_tot[wv];
         start[threadIdx.x] = before + incl - v;
         if (threadIdx.x == N - 1) start[N] = before + incl;
     }
-    __syncthreads();
+    sync();
 }
 
 // ---- A1': stream -> regions
@@ -376,8 +377,12 @@ struct Scatter2Lds {
 __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__restrict__ in_bases, const uint32_t *__restrict__ in_meta,
                                                               const unsigned long long *__restrict__ off, int bits2, int tiles_x, int short_max,
                                                               uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
-                                                              unsigned long long *__restrict__ cursor, unsigned long long *__restrict__ cursor_l)
+                                                              unsigned long long *__restrict__ cursor, unsigned long long *__restrict__ cursor_l,
+                                                              unsigned long long *__restrict__ kwords)
 {
+    // kwords[b] += the k-mers of bucket b that lie inside a row (= the words its workgroup will emit): they ride in the high
+    // half of the tile's rank counters -- a tile has 4096 records of at most 9 k-mers, both halves stay below 2^16
+    static_assert(S2_TILE * MINI_MAX_WINDOW < 65536, "two 16-bit halves per rank counter");
     __shared__ Scatter2Lds L;
     const int n_dig = 1 << bits2;
     const uint32_t dmask = (uint32_t)n_dig - 1u;
@@ -406,16 +411,20 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) {
                 const uint32_t d = digit_of(rm[j]);
-                dr[j] = (d << 16) | atomicAdd(&L.cnt[d], 1u);
+                const uint32_t kw = (rm[j] >> META_ROW_SHIFT) != MINI_ROW_NONE ? ((rm[j] >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1u : 0u;
+                dr[j] = (d << 16) | (atomicAdd(&L.cnt[d], 1u | (kw << 16)) & 0xffffu);
             }
         }
         __syncthreads();
+        const uint32_t kw_mine = L.cnt[threadIdx.x] >> 16;          // (this lane's digit; scan_digits reads the same entry next)
+        L.cnt[threadIdx.x] &= 0xffffu;
         scan_digits<256>(L.cnt, L.start, L.wave_tot);
         // the returning cursor adds (one per digit and tile) are issued first and consumed after the placement
         unsigned long long gpos = 0;
         {
             const uint32_t d = threadIdx.x;
             const uint32_t c = L.start[d + 1] - L.start[d];
+            if (kw_mine) atomicAdd(&kwords[b0 + (d & 127u)], (unsigned long long)kw_mine);
             if (c) {
                 const int64_t b = b0 + (d & 127u);
                 gpos = d < 128 ? off[b] + atomicAdd(&cursor[b], (unsigned long long)c) - L.start[d]
@@ -534,7 +543,8 @@ constexpr int SHORT_MAX = PG_SHORT_MAX;                                 // a rec
 template <int CAP, bool SLOTS, bool WIDE>
 __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
                                                                const unsigned long long *__restrict__ off,
-                                                               const unsigned long long *__restrict__ n_short, MiniView t,
+                                                               const unsigned long long *__restrict__ n_short,
+                                                               const unsigned long long *__restrict__ kwords, MiniView t,
                                                                uint32_t window, uint32_t vsize, int vbits, uint32_t *__restrict__ words,
                                                                uint32_t *__restrict__ prov, unsigned long long *__restrict__ word_cursor,
                                                                unsigned long long *__restrict__ wbeg, unsigned long long *__restrict__ emit_end,
@@ -571,40 +581,42 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
     for (uint32_t i = threadIdx.x; i < tab_units; i += BIG_BLOCK) tab[i] = 0ull;
     if (threadIdx.x == 0) { emitted = 0; n_lookups = 0; }
     if (emit_slots) {
-        // every occurrence that lies in a row leaves exactly one word, and a wavefront knows its records in advance (batches
-        // w, w + 16, ... of either class): the bucket's word range and every wavefront's part of it are fixed before the first
-        // word is written, so words are placed with a wave-local running position -- no counter in LDS, no returning atomic
-        unsigned long long mine = 0;
-        auto tally = [&](int64_t ra, int64_t rb) {
-            for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += 4 * BIG_BLOCK) {
-                uint32_t m[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t i = i0 + u * BIG_BLOCK + lane;
-                    m[u] = i < rb ? meta[i] : 0xffffffffu;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if ((m[u] >> META_ROW_SHIFT) != MINI_ROW_NONE) mine += ((m[u] >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1;
+        // every occurrence that lies in a row leaves exactly one word: the bucket's word range is claimed before the first word is
+        // written (one global add).  The total comes with the records (the second scatter pass tallies it per bucket); without that
+        // pass -- at most 256 buckets -- a pre-pass over the meta plane counts it.
+        if (kwords) {
+            if (threadIdx.x == 0) {
+                n_lookups = kwords[blockIdx.x];
+                wbase = atomicAdd(word_cursor, n_lookups);
             }
-        };
-        tally(r0, rs);
-        tally(rs, r1);
+        } else {
+            unsigned long long mine = 0;
+            for (int64_t i0 = r0 + threadIdx.x; i0 < r1; i0 += BIG_BLOCK) {
+                const uint32_t m = meta[i0];
+                if ((m >> META_ROW_SHIFT) != MINI_ROW_NONE) mine += ((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1;
+            }
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
-        if (lane == 0) wave_words[wave] = mine;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long run = 0;
-            for (int w = 0; w < COUNT_WAVES; ++w) { const unsigned long long v = wave_words[w]; wave_words[w] = run; run += v; }
-            n_lookups = run;
-            wbase = atomicAdd(word_cursor, run);
+            for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+            if (lane == 0) wave_words[wave] = mine;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long run = 0;
+                for (int w = 0; w < COUNT_WAVES; ++w) run += wave_words[w];
+                n_lookups = run;
+                wbase = atomicAdd(word_cursor, run);
+            }
         }
     }
     __syncthreads();
     unsigned long long wb = emit_slots ? wbase : 0ull;
     uint32_t *const prov_b = prov + wb;                          // the bucket's words (32-bit positions from here on)
-    uint32_t wpos = emit_slots ? (uint32_t)wave_words[wave] : 0u;  // this wavefront's next word (wave-uniform)
+    // words are placed by claiming positions on the bucket's LDS counter `emitted`: ONE returning add per batch of 64 records
+    // (all its first-probe hits) and one per general insert round, by lane 0
+    auto claim = [&](uint32_t n_words) -> uint32_t {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&emitted, n_words);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+    };
     PG_STAMP(0);
     bool full = false;
     unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
@@ -620,8 +632,10 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
             const bool put = rw != MINI_ROW_NONE;
             const unsigned long long qm = __ballot(put);
-            if (put) prov_b[wpos + lanes_below(qm)] = (rw << lb) | (sl & smask);
-            wpos += (uint32_t)__popcll(qm);
+            if (qm) {                                            // (uniform)
+                const uint32_t at = claim((uint32_t)__popcll(qm));
+                if (put) prov_b[at + lanes_below(qm)] = (rw << lb) | (sl & smask);
+            }
         }
     };
     // ---- count: wavefront w takes the batches [ra + 64 (w + 16 t), + 64) of a class; CX = k-mers per record at most there
@@ -664,16 +678,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                 }
                 if (hit) hits |= 1u << j;
             }
+            unsigned long long pm[CX];
+            uint32_t at = 0;
             if (emit_slots) {
-                // provisional words of the hits, slot by slot (neighbours in the buffer come from different records: the row
-                // histograms behind the shuffle do not like runs of equal words)
+                // positions for the provisional words of the hits: the claim is issued here and used behind the ring pushes
+                uint32_t total = 0;
 #pragma unroll
                 for (int j = 0; j < CX; ++j) {
-                    const bool put = in_row && ((hits >> j) & 1u);
-                    const unsigned long long pm = __ballot(put);
-                    if (put) prov_b[wpos + lanes_below(pm)] = (row << lb) | sl[j];
-                    wpos += (uint32_t)__popcll(pm);
+                    pm[j] = __ballot(in_row && ((hits >> j) & 1u));
+                    total += (uint32_t)__popcll(pm[j]);
                 }
+                if (total) at = claim(total);                    // (uniform)
             }
 #pragma unroll
             for (int j = 0; j < CX; ++j) {
@@ -690,6 +705,15 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                         slow_round(true);
                         head += 64;
                     }
+                }
+            }
+            if (emit_slots) {
+                // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
+                // shuffle do not like runs of equal words)
+#pragma unroll
+                for (int j = 0; j < CX; ++j) {
+                    if ((pm[j] >> lane) & 1ull) prov_b[at + lanes_below(pm[j])] = (row << lb) | sl[j];
+                    at += (uint32_t)__popcll(pm[j]);
                 }
             }
         }
@@ -750,15 +774,25 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         unsigned long long *gbase = reinterpret_cast<unsigned long long *>(lds + F_GBASE);
         const uint32_t np = (uint32_t)n_lookups;
         const uint32_t dmask = (1u << sh.gb1) - 1u;
+#ifdef PG_MINI_STAMPS
+        unsigned long long tl = __builtin_amdgcn_s_memtime();
+#define PG_LAP(K) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&dbg[K], now_ - tl); tl = now_; } } while (0)
+#else
+#define PG_LAP(K) do { } while (0)
+#endif
+        // Software pipeline: the next tile's words are fetched while this tile is placed and copied out, and every barrier in
+        // the loop is an LDS-only one (lds_sync) -- the stores of a copy-out, the prefetch and the cursor adds stay in flight
+        uint32_t w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t i = j * BIG_BLOCK + threadIdx.x;
+            w[j] = i < np ? prov_b[i] : 0xffffffffu;
+        }
         for (uint32_t t0 = 0; t0 < np; t0 += F_TILE) {
             cnt[threadIdx.x] = 0;
-            __syncthreads();
-            uint32_t w[16], dr[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t i = t0 + j * BIG_BLOCK + threadIdx.x;
-                w[j] = i < np ? prov_b[i] : 0xffffffffu;
-            }
+            lds_sync();                                          // (also: every wavefront is done with the previous tile's buffer)
+            PG_LAP(16);
+            uint32_t dr[16];
             uint32_t live = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -771,25 +805,36 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                     live |= 1u << j;
                 }
             }
-            __syncthreads();
-            scan_digits<1024>(cnt, start, wave_tot);
+            lds_sync();
+            PG_LAP(17);
+            scan_digits<1024, true>(cnt, start, wave_tot);
+            PG_LAP(18);
             unsigned long long gpos = 0;
             {
                 const uint32_t d = threadIdx.x;
                 const uint32_t c = start[d + 1] - start[d];
                 if (c) gpos = sh.goff[(uint64_t)d << sh.gb2] + atomicAdd(&sh.gcur1[d], (unsigned long long)c) - start[d];
             }
+            uint32_t wn[16];                                     // the next tile's words: in flight until the loop comes round
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t i = t0 + F_TILE + j * BIG_BLOCK + threadIdx.x;
+                wn[j] = i < np ? prov_b[i] : 0xffffffffu;
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 if ((live >> j) & 1u) buf[start[dr[j] >> 16] + (dr[j] & 0xffffu)] = w[j];
             gbase[threadIdx.x] = gpos;
-            __syncthreads();
+            lds_sync();
+            PG_LAP(19);
             const uint32_t total = start[1024];
             for (uint32_t i = threadIdx.x; i < total; i += BIG_BLOCK) {
                 const uint32_t r = buf[i];
                 sh.words_out[gbase[(r >> sh.dshift) & dmask] + i] = r;
             }
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = wn[j];
+            PG_LAP(20);
         }
         PG_STAMP(3);
         return;
@@ -919,7 +964,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
 struct MiniPlan {
     int bits, bits1, bits2;
     int64_t n_rounds, n_chunks, chunk_stride;
-    size_t header_off, hist_off, off_off, cur2_off, cur2l_off, wbeg_off, round_off, chunk_off, total;
+    size_t header_off, hist_off, off_off, cur2_off, cur2l_off, kw_off, wbeg_off, round_off, chunk_off, total;
 };
 
 // k-mers per record at most: what fits the 32 characters of a record and the 4-bit length field -- and the window: a
@@ -976,6 +1021,7 @@ int plan_mini(const pg_table *t, int64_t n_words, MiniPlan *p)
     p->off_off = take((nb + 1) * 8);
     p->cur2_off = take(nb * 8);
     p->cur2l_off = take(nb * 8);
+    p->kw_off = take(nb * 8);
     p->wbeg_off = take(nb * 8);
     p->round_off = take((size_t)(p->n_rounds + 1) * 4);
     p->chunk_off = take(((size_t)p->n_chunks << p->bits1) * 8);
@@ -1132,6 +1178,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     auto *off = (unsigned long long *)(ws + p.off_off);
     auto *cur2 = (unsigned long long *)(ws + p.cur2_off);
     auto *cur2l = (unsigned long long *)(ws + p.cur2l_off);
+    auto *kwords = (unsigned long long *)(ws + p.kw_off);            // (cur2 | cur2l | kwords are cleared together below)
     auto *wbeg = (unsigned long long *)(ws + p.wbeg_off);
     auto *round_row = (int32_t *)(ws + p.round_off);
     auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
@@ -1166,7 +1213,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         if (p.bits2) {
             const int tiles_x = 96;
             hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
-                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l);
+                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l, kwords);
         }
     }
     const bool slots_form = window > 0 && mini_slots_form(t, rows);
@@ -1190,7 +1237,8 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_>), LDS_, "pg_mini_count"))) return rc; \
         hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_>), dim3(nb), dim3(BIG_BLOCK), LDS_, s,                     \
                            (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a),  \
-                           (const unsigned long long *)off, n_short, mini_view(t), (uint32_t)window, (uint32_t)vsize,        \
+                           (const unsigned long long *)off, n_short, p.bits2 ? (const unsigned long long *)kwords : (const unsigned long long *)nullptr, \
+                           mini_view(t), (uint32_t)window, (uint32_t)vsize,                                                 \
                            sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                             \
     } while (0)
 #define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \

@@ -55,6 +55,13 @@ __device__ __forceinline__ Word load_word(const uint64_t *__restrict__ codes, co
     return x;
 }
 
+// Workgroup barrier for phases that communicate through LDS only.  __syncthreads() is a workgroup-scope fence + barrier and
+// the fence waits for every outstanding GLOBAL load, store and atomic of the wavefront (s_waitcnt vmcnt(0)): in the LDS-staged
+// scatter loops that exposes the full store latency of every copy-out at the next barrier (measured in mini_count's scatter
+// phase: 8.6 of 26 k cycles per tile).  This one waits for the wavefront's LDS operations only; global stores, prefetch loads
+// and cursor atomics stay in flight across it.  Not for data that another wavefront reads from GLOBAL memory.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // per-digit exclusive scan of table[d][0..n) in place, plus base[d << base_shift]; totals[d] (may be NULL) = row sum.
 // One workgroup per digit.
 __global__ __launch_bounds__(BIG_BLOCK) void digit_scan_kernel(unsigned long long *__restrict__ table, int64_t n,
