@@ -288,7 +288,7 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         const int64_t w = word_begin + round * ROUND_WORDS + threadIdx.x;
         if (word_begin + round * ROUND_WORDS >= word_end) break;    // (uniform)
         if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
-        __syncthreads();
+        lds_sync();
         uint32_t dr[32];                                            // bucket << 16 | rank inside the region
         uint32_t has = 0;
         LaneWord lw;
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 has |= 1u << e;
             });
         }
-        __syncthreads();
-        scan_digits<N1>(L.cnt, L.start, L.wave_tot);
+        lds_sync();
+        scan_digits<N1, true>(L.cnt, L.start, L.wave_tot);
         const uint32_t total = L.start[N1];
         // a round has at most 32 x 512 records; 8 positions x 512 lanes always fit the stage.  Nearly every round fits whole.
         const int n_win = total <= (uint32_t)STAGE_CAP ? 1 : 4;
@@ -314,14 +314,14 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
             // hoisted out of this loop and spilled)
             asm volatile("" : "+v"(lw.x.cw), "+v"(lw.x.pw), "+v"(has));
             if (n_win > 1) {                                        // rank again, this window's records only
-                __syncthreads();
+                lds_sync();
                 if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
-                __syncthreads();
+                lds_sync();
 #pragma unroll
                 for (int e = 0; e < 32; ++e)
                     if ((has & wmask) >> e & 1u) dr[e] = (dr[e] & 0xffff0000u) | atomicAdd(&L.cnt[dr[e] >> (16 + bits2)], 1u);
-                __syncthreads();
-                scan_digits<N1>(L.cnt, L.start, L.wave_tot);
+                lds_sync();
+                scan_digits<N1, true>(L.cnt, L.start, L.wave_tot);
             }
             // gbase[d] = (where the region's run goes) - (where it starts in the stage): the copy-out adds the stage position
             if (threadIdx.x < N1) {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                     }
                 }
             }
-            __syncthreads();
+            lds_sync();
             const uint32_t tot = L.start[N1];
             for (uint32_t i = threadIdx.x; i < tot; i += S1_BLOCK) {
                 const unsigned long long g = L.gbase[L.dig[i]] + i;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 out_meta[g] = L.meta[i];
             }
         }
-        __syncthreads();
+        lds_sync();
     }
 }
 
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
     };
     for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
         L.cnt[threadIdx.x] = 0;
-        __syncthreads();
+        lds_sync();
         const int64_t t0 = r0 + tile * S2_TILE;
         uint64_t rb[S2_RPL];
         uint32_t rm[S2_RPL], dr[S2_RPL];
@@ -415,10 +415,10 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
                 dr[j] = (d << 16) | (atomicAdd(&L.cnt[d], 1u | (kw << 16)) & 0xffffu);
             }
         }
-        __syncthreads();
+        lds_sync();
         const uint32_t kw_mine = L.cnt[threadIdx.x] >> 16;          // (this lane's digit; scan_digits reads the same entry next)
         L.cnt[threadIdx.x] &= 0xffffu;
-        scan_digits<256>(L.cnt, L.start, L.wave_tot);
+        scan_digits<256, true>(L.cnt, L.start, L.wave_tot);
         // the returning cursor adds (one per digit and tile) are issued first and consumed after the placement
         unsigned long long gpos = 0;
         {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
             }
         }
         L.gbase[threadIdx.x] = gpos;
-        __syncthreads();
+        lds_sync();
         const uint32_t total = L.start[256];
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {     // flat sweep: the digit is in the record
             const uint32_t m = L.meta[i];
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
             out_bases[g] = L.bases[i];
             out_meta[g] = m;
         }
-        __syncthreads();
+        lds_sync();
     }
 }
 
