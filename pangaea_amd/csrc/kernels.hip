@@ -390,7 +390,7 @@ template <int FAN_BITS> __device__ __forceinline__ void scatter_scan(ScatterLds<
         if ((int)(threadIdx.x & 63) >= d) incl += o;
     }
     if ((threadIdx.x & 63) == 63) L.wave_tot[threadIdx.x >> 6] = incl;
-    __syncthreads();
+    lds_sync();
     uint32_t before = 0;
     for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += L.wave_tot[wv];
     uint32_t run = before + incl - v;
@@ -401,7 +401,7 @@ template <int FAN_BITS> __device__ __forceinline__ void scatter_scan(ScatterLds<
         run += e[j];
     }
     if (threadIdx.x == BLOCK - 1) L.start[n_dig] = before + incl;
-    __syncthreads();
+    lds_sync();
 }
 
 // A1: stream -> 2^bits1 regions (bits1 <= 8).  A lane owns HALF a word (16 characters) and keeps its <= 16 records in
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
     if ((int)threadIdx.x < n_dig) L.cur[threadIdx.x] = chunk_off[(int64_t)threadIdx.x * n_chunks + slot];
     for (int64_t tile = chunk * TILES_PER_CHUNK; tile < (chunk + 1) * TILES_PER_CHUNK && tile < n_tiles; ++tile) {
         L.cnt[threadIdx.x] = 0;
-        __syncthreads();
+        lds_sync();
         uint64_t rec[A1_CHARS];
         uint32_t dr[A1_CHARS];                                      // digit << 16 | rank inside the digit
         uint32_t ok = 0;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
                 }
             }
         }
-        __syncthreads();
+        lds_sync();
         {   // exclusive scan of cnt[256] -> start[257]: one entry per lane
             const uint32_t v = L.cnt[threadIdx.x];
             uint32_t incl = v;
@@ -504,19 +504,19 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
                 if ((int)(threadIdx.x & 63) >= d) incl += o;
             }
             if ((threadIdx.x & 63) == 63) L.wave_tot[threadIdx.x >> 6] = incl;
-            __syncthreads();
+            lds_sync();
             uint32_t before = 0;
             for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += L.wave_tot[wv];
             L.start[threadIdx.x] = before + incl - v;
             if (threadIdx.x == BLOCK - 1) L.start[BLOCK] = before + incl;
             // gbase[d] = (where the digit's run goes) - (where it starts in the tile): the copy-out adds the tile position
             if ((int)threadIdx.x < n_dig) { L.gbase[threadIdx.x] = L.cur[threadIdx.x] - (before + incl - v); L.cur[threadIdx.x] += v; }
-            __syncthreads();
+            lds_sync();
         }
 #pragma unroll
         for (int j = 0; j < A1_CHARS; ++j)
             if ((ok >> j) & 1) buf[L.start[dr[j] >> 16] + (dr[j] & 0xffffu)] = rec[j];
-        __syncthreads();
+        lds_sync();
         // copy out: LDS position i holds a record of digit d at rank i - start[d]; the digit is recomputed from the record
         // (pure ALU), so the loop is a flat, pipelinable sweep and consecutive lanes write consecutive addresses per run
         const uint32_t total = L.start[BLOCK];
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_stream_kernel(const uint64_t *_
             const uint32_t d = (uint32_t)((r & REC_KEY_MASK) >> dsh);
             rec_out[L.gbase[d] + i] = r;
         }
-        __syncthreads();
+        lds_sync();
     }
 }
 
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
     };
     for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
         for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt()[i] = 0;
-        __syncthreads();
+        lds_sync();
         const int64_t t0 = r0 + tile * TILE1;
         REC rec[REC_PER_LANE];
         uint32_t dr[REC_PER_LANE];
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
                 dr[j] = (d << 16) | atomicAdd(&L.cnt()[d], 1u);
             }
         }
-        __syncthreads();
+        lds_sync();
         scatter_scan(L, n_dig);
         // the returning cursor adds (one per digit and tile) are issued first and consumed after the placement: their round
         // trip to L2 overlaps the LDS stores instead of standing in front of them
@@ -602,14 +602,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
             const int d = (int)threadIdx.x + q * BLOCK;
             if (d < n_dig) L.gbase[d] = gpos[q];
         }
-        __syncthreads();
+        lds_sync();
         const uint32_t total = L.start[n_dig];
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {    // flat sweep: digit recomputed from the record
             const REC r = buf[i];
             const uint32_t d = digit_of(r);
             rec_out[L.gbase[d] + i] = r;                            // gbase[d] = destination of the run - its start in the tile
         }
-        __syncthreads();
+        lds_sync();
     }
 }
 
