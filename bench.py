@@ -57,7 +57,11 @@ def parse_args():
     ap.add_argument("--load", type=float, default=0.6, help="highest load of the hash table (its size is the next power of two)")
     ap.add_argument("--no-fuse", action="store_true", help="N = 1: separate count and lookup kernels (as N > 1 must run them)")
     ap.add_argument("--no-mini", action="store_true", help="N = 1: the key-partitioned pipeline (8-byte record per k-mer occurrence) instead of super-k-mers")
-    ap.add_argument("--plan-in-step", action="store_true", help="super-k-mer pipeline: recompute the partition plan inside every step")
+    ap.add_argument("--plan", choices=("ahead", "in-step", "once"), default="ahead",
+                    help="super-k-mer pipeline, the partition plan of a batch (it depends on the reads, the rows and the table geometry): "
+                         "'ahead' = computed in every step for the NEXT batch, on a side stream under the row histograms and the encode "
+                         "of this one (default); 'in-step' = computed in front of the count of its own batch; 'once' = computed once, "
+                         "before the timed steps (valid only because the bench repeats one batch: a comparison figure, never the default)")
     ap.add_argument("--no-defer", action="store_true", help="N > 1: write every rank's own table and compact it (instead of the deferred count)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     return ap.parse_args()
@@ -266,17 +270,21 @@ def main():
     alg = ALG_BYTES_FUSED if fused else ALG_BYTES
     ev = {k: [] for k in ((k2, "exchange", "features") if multi else (k2, "features"))}
 
+    side = torch.cuda.Stream(device=dev)
+
     def step(timed: bool):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         table.reset()                   # bucketed tables are overwritten slice by slice: no 4 GB clear
-        if mini and args.plan_in_step:
-            table._mini_plan = None
+        if mini and args.plan != "once":
+            table._mini_plan = None         # every step plans its batch: in front of the count, or ahead (prefetched by the step before)
 
         # one GPU: the lookup pass of the abundance rows rides inside the counting kernel (same table, same matrices)
         table.count(stream, check=False, rows=plan, deferred_group=defer if defer is not None and table.can_defer(stream.n_words) else None,
                     emit=(WINDOW, VSIZE) if fused else None)
         e[1].record()
+        if mini and args.plan == "ahead":
+            table.prefetch_plan(stream, plan, side)     # the next batch's plan: starts when this count is done, under the rest of the step
         if world > 1:
             pdist.exchange_table(table, check=False)
         elif multi:
@@ -349,8 +357,9 @@ def main():
                                        else f"REHEARSAL of the {args.rehearse_dist}-rank path on one GPU (one-rank RCCL group)" if multi else "single GPU"),
                        "pipeline": ("super-k-mers by minimizer bucket (12-byte records, LDS counting + lookups per bucket)" if mini
                                     else "k-mer occurrences by key (8-byte records, LDS counting" + (" + lookups" if fused else "") + " per bucket)"),
-                       "partition_plan": (("recomputed in every step" if args.plan_in_step else
-                                           "computed once with the table sizing, outside the step (it depends on the reads, the rows and the geometry only)")
+                       "partition_plan": ({"ahead": "computed in every step for the next batch, on a side stream under the row histograms and the encode",
+                                            "in-step": "computed in every step, in front of the count",
+                                            "once": "computed ONCE before the timed steps (comparison figure: only valid because the bench repeats one batch)"}[args.plan]
                                           if mini else "bucket histogram inside the step"),
                        "records_per_pair": (table._mini_plan[2] / args.pairs if mini and table._mini_plan else 260.0),
                        "input": "packed reads resident in HBM", "table_load": table_load,

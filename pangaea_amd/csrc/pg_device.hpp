@@ -118,16 +118,14 @@ constexpr int MINI_M = PG_MINI_M;
 constexpr uint32_t MINI_MMASK = (1u << (2 * MINI_M)) - 1u;
 constexpr uint32_t MINI_MCOMP = 0xAAAAAAAAu & MINI_MMASK;
 
-// a bijection of 32-bit words (xor with a constant, three xorshifts: every step is invertible): distinct canonical M-mers have
-// distinct values, so "the smallest value" picks the same M-mer on both strands.  No multiplies: this runs once per character
-// of the stream, and 32-bit integer multiplies issue at a quarter of the rate of shifts and xors.
+// The order in which M-mers compete for "minimizer": a multiplicative hash of the low 24 bits of the canonical M-mer (its
+// oldest character does not take part: M-mers that differ only there tie, and a tie is harmless -- the bucket is a function of
+// the minimum VALUE, which both strands compute from the same multiset).  The xor keeps poly-A (code 0) from being the
+// smallest value of all.  Two full-rate instructions (v_xor, v_mul_u32_u24): this runs once per character of the stream in
+// kernels that are bound by VALU issue; the three-xorshift mixer it replaces took seven.
 __device__ __forceinline__ uint32_t mhash(uint32_t x)
 {
-    x ^= 0x9E3779B9u;               // (poly-A must not be the smallest value of all)
-    x ^= x << 13;
-    x ^= x >> 17;
-    x ^= x << 5;
-    return x;
+    return __umul24(x ^ 0x5E3779u, 0xC2B2AFu);
 }
 // bucket of a minimizer value (the value itself is biased towards small numbers: mix once more, take the top bits)
 __device__ __forceinline__ uint32_t mini_bucket(uint32_t minv, int bits)

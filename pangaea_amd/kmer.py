@@ -58,6 +58,8 @@ class KmerTable:
         self._deferred = None            # (fill, n_words) after a deferred count: entries wait in the workspace, slots unwritten
         self._emitted = None             # (window, vsize) while the shuffle workspace holds the words of a fused count + lookup
         self._mini_plan = None           # (key, plan workspace, n_records) of the last pg_mini_plan: reused while the key matches
+        self._mini_next = None           # (key, plan workspace, event, rows) of a plan computed ahead on a side stream
+        self._mini_spare = None          # the plan workspace that is neither in use nor being filled
         self._mini_rec_ws = None
 
     # ------------------------------------------------------------------ construction
@@ -336,12 +338,26 @@ class KmerTable:
                 and (self.kind == "miniw" or emit[0] * emit[1] <= _lib.HASH_COUNT_SAT))
         key = (stream.codes.data_ptr(), valid_ptr, word_begin, word_end, id(keep), bool(lenient), self.log2_slots, self.log2_bucket)
         with torch.cuda.device(self.device):
+            if (self._mini_plan is None or self._mini_plan[0] != key) and self._mini_next is not None and self._mini_next[0] == key:
+                # a plan computed ahead (``prefetch_plan``): the count waits for it on the device; its record count is read here
+                _, ws, event, _ = self._mini_next
+                torch.cuda.current_stream(self.device).wait_event(event)
+                event.synchronize()
+                if self._mini_plan is not None:
+                    self._mini_spare = self._mini_plan[1]
+                self._mini_plan = (key, ws, int(ws[:8].view(torch.int64).item()), keep)
+                self._mini_next = None
             if self._mini_plan is None or self._mini_plan[0] != key:
                 need = _lib.check(L.pg_mini_plan_bytes(n_words, self.desc()))
-                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                ws = self._mini_spare if self._mini_spare is not None and self._mini_spare.numel() == need else None
+                self._mini_spare = None
+                if ws is None:
+                    ws = torch.empty(need, dtype=torch.uint8, device=self.device)
                 _lib.check(L.pg_mini_plan(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
                                           ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
                 n_records = int(ws[:8].view(torch.int64).item())          # (host sync; once per plan)
+                if self._mini_plan is not None:
+                    self._mini_spare = self._mini_plan[1]
                 self._mini_plan = (key, ws, n_records, keep)
             _, plan_ws, n_records, _ = self._mini_plan
             need = _lib.check(L.pg_mini_records_bytes(n_records))
@@ -365,6 +381,33 @@ class KmerTable:
         if check:
             self.check_status()
         return self
+
+    def prefetch_plan(self, stream: ReadStream, rows: "Plan | None", side: "torch.cuda.Stream") -> None:
+        """compute the partition plan of the NEXT count of ``stream`` (whole range, strict validity) on the stream ``side``, into a
+        workspace of its own: ``side`` waits for what the current stream has enqueued so far -- call this right after ``count`` and
+        the plan of batch i + 1 runs under the row histograms and the encode of batch i instead of in front of its own count.
+        The next ``count`` of the same stream and rows picks it up (and waits for it); any other count ignores it."""
+        if self.kind not in ("mini", "miniw"):
+            raise ValueError("prefetch_plan() is for mini tables")
+        if stream.table_valid(False) is not stream.valid or not stream.rows_inside_table:
+            return                                               # (soft-masked / quality-masked input: plan inside the count)
+        L = _lib.load()
+        keep = rows if (rows is not None and rows.shuffle_ok and rows.n_rows <= _lib.MINI_MAX_ROWS) else None
+        n_words = stream.n_words
+        key = (stream.codes.data_ptr(), stream.valid.data_ptr(), 0, n_words, id(keep), False, self.log2_slots, self.log2_bucket)
+        need = _lib.check(L.pg_mini_plan_bytes(n_words, self.desc()))
+        ws = self._mini_spare if self._mini_spare is not None and self._mini_spare.numel() == need else None
+        self._mini_spare = None
+        if ws is None:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.device(self.device), torch.cuda.stream(side):
+            _lib.check(L.pg_mini_plan(stream.codes.data_ptr(), stream.valid.data_ptr(), 0, n_words, self.desc(),
+                                      C.byref(keep.rows_desc) if keep is not None else None, ws.data_ptr(), ws.numel(), side.cuda_stream))
+            event = torch.cuda.Event()
+            event.record(side)
+        ws.record_stream(side)
+        self._mini_next = (key, ws, event, keep)
 
     def can_shuffle(self, plan: "Plan", window: int, vsize: int) -> bool:
         """can ``abundance_from_records`` build the rows of this plan (instead of table lookups)?"""
