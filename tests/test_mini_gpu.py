@@ -205,3 +205,33 @@ def test_mini_mid_scale_against_oracle():
         seq = text[int(rows.start[i]):int(rows.end[i])]
         assert np.array_equal(tnf[i].cpu().numpy(), oracle.tnf_row(seq, 4))
         assert np.array_equal(abd[i].cpu().numpy(), oracle.abd_row(seq, 21, otab, 10, 400))
+
+
+@pytest.mark.parametrize("k", [21, 25])
+def test_mini_low_complexity_runs_and_saturating_counts(k):
+    """homopolymers and short tandem repeats: one minimizer value recurs along the whole run (records cut at the cap, one hot
+    bucket whose workgroup gets almost every record), 3.1 M copies of one k-mer (the packed count stops at 2^21 and every bin
+    below vsize * window stays exact; the wide layout counts on), rows through the emitted words and by lookups"""
+    rng = np.random.RandomState(11)
+    rnd = bytes(rng.choice(list(b"ACGT"), size=30_000).astype(np.uint8))
+    s = ReadStream.from_runs([("a", b"A" * 1_600_000 + b"N" + b"T" * 1_500_040 + b"N"),
+                              ("b", b"AC" * 40_000 + b"N" + b"ACG" * 30_000 + b"N" + b"AACCGGTT" * 9_000 + b"N"),
+                              ("c", rnd + b"N" + rnd[:20_000] + b"N")], device=DEV)
+    rows = s.rows(0)
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.count_kmers(s, k, rows=plan, emit=(10, 400))
+    assert t.kind == ("mini" if k <= 21 else "miniw")
+    codes, counts = t.items()
+    otab = oracle.Table(k, threads=4).count(s.decode())
+    ocodes, ocounts = otab.items()
+    assert np.array_equal(codes, ocodes)
+    if k <= 21:
+        assert counts.max() >= _lib.HASH_COUNT_SAT and np.array_equal(np.minimum(counts, _lib.HASH_COUNT_SAT), np.minimum(ocounts, _lib.HASH_COUNT_SAT))
+        assert np.array_equal(counts[ocounts < _lib.HASH_COUNT_SAT], ocounts[ocounts < _lib.HASH_COUNT_SAT])
+    else:
+        assert np.array_equal(counts, ocounts) and counts.max() > 3_000_000
+    _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
+    _, _, oabd = _oracle(s, rows, k, 10, 400)
+    assert np.array_equal(abd.cpu().numpy(), oabd)
+    _, abd_l = kmer.features(s, rows, k_tnf=None, table=t, window=10, vsize=400)
+    assert torch.equal(abd_l, abd)

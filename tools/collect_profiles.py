@@ -27,8 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = [
     # the super-k-mer pipeline (one GPU).  Factors by the same calibration: mini_scatter2 reads n_records x 12 B (8-B and 4-B
     # coalesced loads: the 8-B plane is the bulk) and mini_count streams the same planes plus the 4-B provisional words
-    ("mini_plan_kernel", "plan (outside the step)", 2.0), ("round_rows_kernel", "plan (outside the step)", 1.0),
-    ("mini_total_kernel", "plan (outside the step)", 1.0), ("distinct_sketch_kernel", "plan (outside the step)", 2.0),
+    ("mini_plan_kernel", "plan (every step, for the next batch, side stream)", 2.0), ("round_rows_kernel", "plan (every step, for the next batch, side stream)", 1.0),
+    ("mini_total_kernel", "plan (every step, for the next batch, side stream)", 1.0), ("distinct_sketch_kernel", "plan (every step, for the next batch, side stream)", 2.0),
     ("mini_scatter_kernel", "kmer_count+lookup", 2.0), ("mini_scatter2_kernel", "kmer_count+lookup", 2.0),
     ("mini_count_kernel", "kmer_count+lookup", 2.0),
     ("bucket_hist_kernel", "kmer_count", 2.0), ("scan_kernel", "kmer_count", 1.0), ("digit_scan_kernel", "kmer_count", 1.0),
