@@ -154,14 +154,14 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
         return time.perf_counter() - t0, lap, tuple(mu.shape)
 
     run(warm)                                           # first-call costs (code objects, allocator) stay out of the figure
-    total, lap, shape = run(fq)
+    total, lap, shape = min((run(fq) for _ in range(2)), key=lambda r: r[0])        # (the faster of two passes: the leg is ~35 ms)
     for f in (fq, warm):
         os.remove(f)
     os.rmdir(tmp)
     threads = min(32, len(os.sched_getaffinity(0)))
     return {"value": n / total, "unit": "pairs/s", "pairs": n, "fastq_bytes": size, "host_threads": threads,
             "seconds": {k: round(v, 4) for k, v in lap.items()}, "mu_shape": list(shape),
-            "what": "plain interleaved FASTQ file -> ingest -> H2D -> table sizing + plan + count/lookups -> rows -> normalise -> encode, one GPU"}
+            "what": "plain interleaved FASTQ file -> ingest -> H2D -> table sizing + plan + count/lookups -> rows -> normalise -> encode, one GPU; faster of two passes"}
 
 
 def spawn_ranks(n: int) -> int:
