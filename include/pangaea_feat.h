@@ -151,7 +151,7 @@ int pg_tnf_colmap(int k, uint16_t *colmap /* [4^k] host */, uint32_t *col_code /
 enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3, PG_TABLE_MINI = 4, PG_TABLE_MINI_WIDE = 5 };
 /*   PG_TABLE_MINI   PG_MINI_MIN_K <= k <= 21: uint64_t slots[2^log2_slots], slot = (canonical code << 22) | count, in
  *                   buckets of 2^log2_bucket_slots slots (<= PG_BUCKET_MAX_LOG2_SLOTS, at most 2^16 buckets); a k-mer's
- *                   bucket is a hash of its MINIMIZER (the smallest hashed canonical 13-mer inside it), its home slot
+ *                   bucket is a hash of its MINIMIZER (the smallest hashed canonical 13-mer inside it; 11-mer for k < 16), its home slot
  *                   inside the bucket a hash of its code; linear probing wraps inside the bucket.  Consecutive k-mers
  *                   of a read share their minimizer, so the partition passes move super-k-mers (12 bytes for a run of
  *                   k-mers) instead of 8 bytes per occurrence: built by pg_mini_plan + pg_mini_count, read by
@@ -162,8 +162,9 @@ enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3, PG_TABLE_MINI =
  *                   LDS).  The minimizer is taken over the CENTRAL 8 or 9 13-mers of the k-mer (a window that the
  *                   reverse complement maps onto itself), so the first pass keeps at most 9 values per lane for every k.
  *                   Entries of a dump are merged with pg_kmer_merge_wide. */
-#define PG_MINI_M 13
-#define PG_MINI_MIN_K 16
+#define PG_MINI_M 13          /* minimizer length for k >= 16 */
+#define PG_MINI_M_SMALL 11    /* ... and for PG_MINI_MIN_K <= k <= 15 */
+#define PG_MINI_MIN_K 13
 #define PG_MINI_MAX_LOG2_BUCKETS 16
 #define PG_MINI_MAX_ROWS ((1 << 21) - 2)
 #define PG_MINI_WIDE_MAX_LOG2_BUCKET_SLOTS 13

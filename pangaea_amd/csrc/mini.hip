@@ -106,9 +106,10 @@ struct RowBits {
 // DELAY (k > 21): the minimizer of a k-mer is taken over its central W M-mers only (pg_device.hpp: mini_window), i.e. the
 // window that ends `off` characters before the k-mer does -- the window minimum passes through a delay line of `off` <= 5 steps.
 constexpr int MINI_MAX_OFF = 5;
-template <int W, bool DELAY, class Emit>
+template <int W, bool DELAY, int M, class Emit>
 __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_t ok_row, uint32_t cuts, int k, int off, int bits, int cap, Emit &&emit)
 {
+    constexpr uint32_t MMASK = (1u << (2 * M)) - 1u;
     uint32_t fwm = 0, rcm = 0;
     uint32_t win[W];                                            // win[0] = newest hashed canonical M-mer
     uint32_t dl[DELAY ? MINI_MAX_OFF : 1];                      // dl[i] = window minimum i + 1 characters ago
@@ -122,12 +123,12 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
     constexpr int PRE = W - 1 + (DELAY ? MINI_MAX_OFF : 0);
     for (int c = DELAY ? 0 : 33 - k; c < 32 - PRE; ++c) {
         const uint32_t ch = (uint32_t)(x.pw >> (2 * c)) & 3u;
-        fwm = ((fwm << 2) | ch) & MINI_MMASK;
-        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
+        fwm = ((fwm << 2) | ch) & MMASK;
+        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (M - 1)));
     }
     auto step = [&](uint32_t ch) -> uint32_t {                  // one character in; the minimizer value of the k-mer that ends here
-        fwm = ((fwm << 2) | ch) & MINI_MMASK;
-        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (MINI_M - 1)));
+        fwm = ((fwm << 2) | ch) & MMASK;
+        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (M - 1)));
 #pragma unroll
         for (int i = W - 1; i > 0; --i) win[i] = win[i - 1];
         win[0] = mhash(fwm < rcm ? fwm : rcm);
@@ -184,7 +185,7 @@ __device__ __forceinline__ LaneWord load_lane_word(const uint64_t *__restrict__ 
 }
 
 // ---- plan: records per bucket (hist) and, per chunk, records per first-pass region (chunk_hist[d * n_chunks + slot(chunk)])
-template <int W, bool DELAY>
+template <int W, bool DELAY, int M>
 __global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                               int64_t word_begin, int64_t word_end, int k, int woff, int bits, int bits2, int cap,
                                                               const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__
             if (lw.ok == 0) continue;
             RowBits rb;
             rb.init(row_start, row_end, n_rows, row_start ? round_row[wi / ROUND_WORDS] : 0, w << 5);
-            mini_segment<W, DELAY>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int, int, uint32_t b) {
+            mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int, int, uint32_t b) {
                 if (b - b_base < (uint32_t)nb) atomicAdd(&lds[b - b_base], 1u);
                 if (b_base == 0) atomicAdd(&coarse[b >> bits2], 1u);
             });
@@ -267,7 +268,7 @@ template <int N1> struct Scatter1Lds {                              // N1 region
     uint32_t wave_tot[N1 / 64];
 };
 
-template <int W, bool DELAY, int N1>
+template <int W, bool DELAY, int M, int N1>
 __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                                  int64_t word_begin, int64_t word_end, int k, int woff, int bits, int bits2, int cap,
                                                                  const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         rb.starts = rb.ends = rb.r0 = 0; rb.inside0 = false;
         if (lw.ok) {
             rb.init(row_start, row_end, n_rows, row_start ? round_row[round] : 0, w << 5);
-            mini_segment<W, DELAY>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int e, int, uint32_t b) {
+            mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int e, int, uint32_t b) {
                 dr[e] = (b << 16) | atomicAdd(&L.cnt[b >> bits2], 1u);
                 has |= 1u << e;
             });
@@ -1089,9 +1090,19 @@ extern "C" int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vs
         mini_window(K_, &wc_, &woff);                                                                                       \
         if ((K_) > PG_HASH_MAX_K) {                                                                                         \
             constexpr bool DELAY = true;                                                                                    \
+            constexpr int M = MINI_M;                                                                                       \
             if (wc_ == 8) { constexpr int W = 8; CALL; } else { constexpr int W = 9; CALL; }                                \
+        } else if (mini_m(K_) == MINI_M_SMALL) {                                                                            \
+            constexpr bool DELAY = false;                                                                                   \
+            constexpr int M = MINI_M_SMALL;                                                                                 \
+            switch (wc_) {                                                                                                  \
+            case 3: { constexpr int W = 3; CALL; } break;                                                                   \
+            case 4: { constexpr int W = 4; CALL; } break;                                                                   \
+            default: { constexpr int W = 5; CALL; } break;                                                                  \
+            }                                                                                                               \
         } else {                                                                                                            \
             constexpr bool DELAY = false;                                                                                   \
+            constexpr int M = MINI_M;                                                                                       \
             switch (wc_) {                                                                                                  \
             case 4: { constexpr int W = 4; CALL; } break;                                                                   \
             case 5: { constexpr int W = 5; CALL; } break;                                                                   \
@@ -1135,8 +1146,8 @@ extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_
         const int grid = (int)(p.n_chunks < 512 ? p.n_chunks : 512);
         for (int b_base = 0; b_base < nb; b_base += nb_launch) {
             PG_MINI_DISPATCH_W(t->k,
-                if ((rc = raise_lds_limit((const void *)(mini_plan_kernel<W, DELAY>), lds, "pg_mini_plan"))) return rc;
-                hipLaunchKernelGGL((mini_plan_kernel<W, DELAY>), dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, p.bits2, mini_cap(t->k),
+                if ((rc = raise_lds_limit((const void *)(mini_plan_kernel<W, DELAY, M>), lds, "pg_mini_plan"))) return rc;
+                hipLaunchKernelGGL((mini_plan_kernel<W, DELAY, M>), dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, p.bits2, mini_cap(t->k),
                                    with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
                                    with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
                                    (const int32_t *)round_row, hist, chunk_tab, p.n_chunks, p.chunk_stride, (uint32_t)b_base, nb_launch))
@@ -1203,8 +1214,8 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
 #define PG_MINI_LAUNCH_SCATTER(N1_)                                                                                          \
         PG_MINI_DISPATCH_W(t->k,                                                                                            \
             const size_t lds1 = sizeof(Scatter1Lds<N1_>);                                                                   \
-            if ((rc = raise_lds_limit((const void *)(mini_scatter_kernel<W, DELAY, N1_>), lds1, "pg_mini_count"))) return rc; \
-            hipLaunchKernelGGL((mini_scatter_kernel<W, DELAY, N1_>), dim3((unsigned)p.n_chunks), dim3(S1_BLOCK), lds1, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, \
+            if ((rc = raise_lds_limit((const void *)(mini_scatter_kernel<W, DELAY, M, N1_>), lds1, "pg_mini_count"))) return rc; \
+            hipLaunchKernelGGL((mini_scatter_kernel<W, DELAY, M, N1_>), dim3((unsigned)p.n_chunks), dim3(S1_BLOCK), lds1, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, \
                                p.bits2, mini_cap(t->k), with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr, \
                                with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr, \
                                (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride))

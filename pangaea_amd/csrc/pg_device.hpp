@@ -114,9 +114,11 @@ __global__ __launch_bounds__(BIG_BLOCK) void scan_kernel(const unsigned long lon
 // k-mers of a read mostly share their minimizer, so the occurrences that go to one bucket travel as SUPER-k-mers: one
 // 12-byte record (32 bases + row + length) for a run of up to 16 k-mers instead of 8 bytes per occurrence.  Inside the
 // bucket the home slot is slot_hash(code); slots hold (canonical code << 22) | count, 0 = empty.
-constexpr int MINI_M = PG_MINI_M;
-constexpr uint32_t MINI_MMASK = (1u << (2 * MINI_M)) - 1u;
-constexpr uint32_t MINI_MCOMP = 0xAAAAAAAAu & MINI_MMASK;
+// M depends on k alone: 13 from k = 16 on, 11 for 13 <= k <= 15 (Pangaea's default k = 15 then has windows of five 11-mers;
+// with 13-mers it would have three and hardly any k-mer would share its minimizer with a neighbour)
+constexpr int MINI_M = PG_MINI_M, MINI_M_SMALL = PG_MINI_M_SMALL;
+__host__ __device__ __forceinline__ int mini_m(int k) { return k >= MINI_M + 3 ? MINI_M : MINI_M_SMALL; }
+static_assert(PG_MINI_MIN_K == MINI_M_SMALL + 2, "windows of at least three M-mers");
 
 // The order in which M-mers compete for "minimizer": a multiplicative hash of the low 24 bits of the canonical M-mer (its
 // oldest character does not take part: M-mers that differ only there tie, and a tie is harmless -- the bucket is a function of
@@ -158,7 +160,7 @@ template <bool WIDE = false> __device__ __forceinline__ uint32_t mini_slot_hash(
 constexpr int MINI_MAX_WINDOW = 9;
 __host__ __device__ __forceinline__ void mini_window(int k, int *wc, int *off)
 {
-    const int w = k - MINI_M + 1;
+    const int w = k - mini_m(k) + 1;
     *wc = w <= MINI_MAX_WINDOW ? w : MINI_MAX_WINDOW - 1 + (w & 1);
     *off = (w - *wc) / 2;
 }
@@ -167,10 +169,12 @@ __device__ __forceinline__ uint32_t mini_minimizer_of(uint64_t code, int k)
 {
     int wc, off;
     mini_window(k, &wc, &off);
+    const int m = mini_m(k);
+    const uint32_t mmask = (1u << (2 * m)) - 1u;
     uint32_t best = 0xffffffffu;
     for (int t = off; t < off + wc; ++t) {
-        const uint32_t fw = (uint32_t)(code >> (2 * t)) & MINI_MMASK;
-        const uint32_t rc = (swap_pairs32(__brev(fw)) >> (32 - 2 * MINI_M)) ^ MINI_MCOMP;
+        const uint32_t fw = (uint32_t)(code >> (2 * t)) & mmask;
+        const uint32_t rc = (swap_pairs32(__brev(fw)) >> (32 - 2 * m)) ^ (0xAAAAAAAAu & mmask);
         const uint32_t h = mhash(fw < rc ? fw : rc);
         best = h < best ? h : best;
     }

@@ -33,7 +33,10 @@ def _same_items(a, b):
     (21, 22, 10, 10, 400, 2000, 3000),      # 4096 buckets: both passes
     (21, 18, 14, 1, 6, 302, 800),           # 16 buckets
     (21, 14, 14, 3, 64, 0, 40),             # one bucket, every run a row
-    (16, 20, 9, 2, 50, 2000, 3000),         # the smallest k, windows of 4 M-mers, 16 k-mers per record
+    (16, 20, 9, 2, 50, 2000, 3000),         # the smallest k with 13-mer minimizers: windows of 4
+    (15, 20, 10, 10, 400, 2000, 3000),      # Pangaea's default k: 11-mer minimizers, windows of 5
+    (14, 19, 9, 3, 64, 600, 3000),
+    (13, 18, 12, 1, 512, 2000, 3000),       # the smallest k: windows of 3
     (17, 20, 8, 7, 33, 600, 3000),
     (19, 21, 12, 25, 512, 2000, 3000),
     (20, 20, 11, 1, 512, 2000, 3000),
@@ -114,7 +117,7 @@ def test_mini_table_only_and_from_items():
     with pytest.raises(ValueError):
         t.count(s)                                                  # one count per fresh table
     with pytest.raises(ValueError):
-        kmer.KmerTable.mini_with_slots(15, DEV, 20)
+        kmer.KmerTable.mini_with_slots(12, DEV, 20)
     # k = 27: entries of a dump into a wide mini table (pg_kmer_merge_wide places them by minimizer bucket), auto-selection
     w = kmer.count_kmers(s, 27, rows=kmer.Plan(rows, DEV), emit=(2, 100))
     otab = oracle.Table(27, threads=4).count(s.decode())
