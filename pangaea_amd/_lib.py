@@ -60,6 +60,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (make -C pangaea_amd/csrc). "
             "There is no CPU fallback for the feature path.")
+    # torch first: its wheel carries its own libamdhip64, and the library's kernels run on torch's device memory and streams --
+    # both must sit on ONE HIP runtime.  Loaded before torch, this library binds /opt/rocm's copy, torch then brings a second
+    # runtime into the process and the library's launches fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, cp = C.c_void_p, C.c_int64, C.c_int, C.c_char_p
     tp = C.POINTER(pg_table)
