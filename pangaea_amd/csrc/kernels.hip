@@ -1485,7 +1485,9 @@ __global__ __launch_bounds__(BLOCK) void group_caps_kernel(const int64_t *__rest
 
 // S3: one workgroup per row group: LDS histogram [64 rows][vsize] of the group's (row, bin) words, written out as the
 // rows of the abundance matrix (plain stores: every row belongs to exactly one group)
-__global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const uint32_t *__restrict__ words, const unsigned long long *__restrict__ goff,
+// WORD = uint16_t: the narrow words of a one-pass shuffle (row inside the group << vbits | bin; 0xffff = none)
+template <typename WORD>
+__global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restrict__ words, const unsigned long long *__restrict__ goff,
                                                              const unsigned long long *__restrict__ gcnt, int vbits, uint32_t vsize,
                                                              int64_t n_rows, int32_t *__restrict__ abd_out)
 {
@@ -1498,12 +1500,20 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const uint32_t *__r
     __syncthreads();
     const int64_t a = (int64_t)goff[g], b = a + (int64_t)gcnt[g];
     const uint32_t bmask = (1u << vbits) - 1u;
+    constexpr uint32_t NONE = (uint32_t)(WORD)~(WORD)0;
     for (int64_t base = a; base < b; base += (int64_t)BIG_BLOCK * 8) {
         uint32_t e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {                                // 8 loads per lane in flight
             const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
-            e[j] = i < b ? words[i] : 0xffffffffu;
+            if (sizeof(WORD) == 2) {
+                // (through the dword that holds it: two lanes share a load, and the compiler does not serialise dword loads the
+                // way it does 2-byte ones -- it put s_waitcnt vmcnt(0) behind every global_load_ushort)
+                const uint32_t pair = i < b ? reinterpret_cast<const uint32_t *>(words)[i >> 1] : 0xffffffffu;
+                e[j] = (i & 1) ? pair >> 16 : pair & 0xffffu;
+            } else {
+                e[j] = i < b ? (uint32_t)words[i] : NONE;
+            }
         }
         // equal words in neighbouring lanes are added once: consecutive k-mers of a read share their row and, mostly, their bin,
         // and a lookup pass that works on super-k-mers leaves them next to each other -- as single adds they would queue up on
@@ -1516,7 +1526,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const uint32_t *__r
             const unsigned long long hm = __ballot(head);
             const unsigned long long above = lane == 63 ? 0ull : hm >> (lane + 1);
             const uint32_t run = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
-            if (head && e[j] != 0xffffffffu) atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e[j] & bmask)], run);
+            if (head && e[j] != NONE) atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e[j] & bmask)], run);
         }
     }
     __syncthreads();
@@ -2296,7 +2306,7 @@ static int shuffle_prepare(const ShufflePlan &sp, const pg_rows *rows, char *ws,
     return check_launch("pg_abundance_from_records");
 }
 
-static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize, int32_t *abd_out, char *ws, hipStream_t s)
+static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize, int32_t *abd_out, char *ws, hipStream_t s, bool narrow = false)
 {
     int rc;
     auto *goff = (unsigned long long *)(ws + sp.goff_off);
@@ -2305,7 +2315,9 @@ static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize,
     auto *words_a = (uint32_t *)(ws + sp.words_a_off);
     auto *words_b = (uint32_t *)(ws + sp.words_b_off);
     const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
-    if ((rc = raise_lds_limit((const void *)row_hist_kernel, hist_lds, "pg_abundance_from_records"))) return rc;
+    if ((rc = raise_lds_limit((const void *)row_hist_kernel<uint32_t>, hist_lds, "pg_abundance_from_records"))) return rc;
+    if ((rc = raise_lds_limit((const void *)row_hist_kernel<uint16_t>, hist_lds, "pg_abundance_from_records"))) return rc;
+    if (narrow && sp.gb2) return pg_fail(PG_EINVAL, "row shuffle: narrow words need a one-pass shuffle");
     const int gshift = sp.vbits + GROUP_ROWS_LOG2;
     const unsigned long long *gcnt = gcur1;
     const uint32_t *final_words = words_a;
@@ -2318,8 +2330,12 @@ static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize,
         final_words = words_b;
     }
     // S3: LDS row histograms -> rows of the matrix
-    hipLaunchKernelGGL(row_hist_kernel, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, final_words, (const unsigned long long *)goff, gcnt,
-                       sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
+    if (narrow)
+        hipLaunchKernelGGL(row_hist_kernel<uint16_t>, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, (const uint16_t *)final_words,
+                           (const unsigned long long *)goff, gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
+    else
+        hipLaunchKernelGGL(row_hist_kernel<uint32_t>, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, final_words,
+                           (const unsigned long long *)goff, gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
     return check_launch("pg_abundance_from_records");
 }
 
@@ -2354,6 +2370,13 @@ static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begi
 }
 
 // the two outer parts for a lookup pass that does the first scatter itself: `ctx` tells it where the group regions are
+int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize)
+{
+    ShufflePlan sp;
+    if (plan_shuffle(cap, n_rows, vsize, 0, &sp)) return 0;
+    return sp.gb2 == 0 && sp.vbits + GROUP_ROWS_LOG2 <= 15 && !getenv("PG_WIDE_WORDS");
+}
+
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
                                 pg_shuffle_ctx *ctx)
 {
@@ -2370,18 +2393,20 @@ int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, voi
     ctx->gb1 = sp.gb1;
     ctx->gb2 = sp.gb2;
     ctx->dshift = sp.vbits + GROUP_ROWS_LOG2 + sp.gb2;
+    ctx->narrow = pg_internal_shuffle_is_narrow(cap, rows->n_rows, vsize);
     if (rows->n_rows == 0) return PG_OK;
     return shuffle_prepare(sp, rows, ws, (hipStream_t)stream);
 }
 
-int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream)
+int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
+                               int narrow)
 {
     ShufflePlan sp;
     int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp);
     if (rc) return rc;
     if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
     if (rows->n_rows == 0) return PG_OK;
-    return shuffle_finish(sp, rows, vsize, abd_out, (char *)workspace, (hipStream_t)stream);
+    return shuffle_finish(sp, rows, vsize, abd_out, (char *)workspace, (hipStream_t)stream, narrow != 0);
 }
 
 extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,

@@ -534,6 +534,7 @@ struct ShufArgs {
     unsigned long long *gcur1;
     uint32_t *words_out;
     int gb1, gb2, dshift;
+    int narrow;                                                  // one-pass shuffle: 2-byte words (row inside its group, bin)
 };
 // LDS of that scatter (bytes from the start of the dynamic area; the table has become 2-byte bins by then)
 constexpr uint32_t F_TILE = 16 * BIG_BLOCK;                  // words per tile: 16 per lane
@@ -829,9 +830,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             lds_sync();
             PG_LAP(19);
             const uint32_t total = start[1024];
-            for (uint32_t i = threadIdx.x; i < total; i += BIG_BLOCK) {
-                const uint32_t r = buf[i];
-                sh.words_out[gbase[(r >> sh.dshift) & dmask] + i] = r;
+            if (sh.narrow) {                                     // (the group region implies the rows' upper bits)
+                uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
+                for (uint32_t i = threadIdx.x; i < total; i += BIG_BLOCK) {
+                    const uint32_t r = buf[i];
+                    out16[gbase[(r >> sh.dshift) & dmask] + i] = (uint16_t)(r & 0x7fffu);
+                }
+            } else {
+                for (uint32_t i = threadIdx.x; i < total; i += BIG_BLOCK) {
+                    const uint32_t r = buf[i];
+                    sh.words_out[gbase[(r >> sh.dshift) & dmask] + i] = r;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) w[j] = wn[j];
@@ -1232,13 +1241,13 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     const unsigned long long *n_short = p.bits2 && mini_cap(t->k) > SHORT_MAX ? (const unsigned long long *)cur2 : (const unsigned long long *)nullptr;
     uint32_t *words_e = window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr;
     uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
-    ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0};
+    ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0, 0};
     size_t count_lds = slice_lds;
     if (slots_form) {
         // the count kernel scatters its words into the row shuffle's group regions itself: offsets and cursors must be ready
         pg_shuffle_ctx ctx;
         if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx))) return rc;
-        sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift};
+        sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, ctx.narrow};
         words_a = ctx.words_in;                          // the provisional words wait in the shuffle's input buffer
         if (count_lds < F_END) count_lds = F_END;
     }
@@ -1281,7 +1290,8 @@ extern "C" int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *
     if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: plan workspace does not match n_words_counted");
     if ((reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: workspace must be 256-byte aligned");
     if (mini_slots_form(t, rows))        // the count kernel has scattered the words by row group already
-        return pg_internal_shuffle_finish(n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
+        return pg_internal_shuffle_finish(n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream,
+                                          pg_internal_shuffle_is_narrow(n_words_counted * 32, rows->n_rows, vsize));
     const auto *wbeg = (const unsigned long long *)((const char *)plan_ws + p.wbeg_off);
     return pg_internal_shuffle_rows(wbeg, 1 << p.bits, n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
 }
