@@ -1495,16 +1495,20 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restr
     const int64_t g = blockIdx.x;
     const int64_t row0 = g << GROUP_ROWS_LOG2;
     const int64_t rows_here = n_rows - row0 < (1 << GROUP_ROWS_LOG2) ? n_rows - row0 : (1 << GROUP_ROWS_LOG2);
-    const uint32_t n_bins = (uint32_t)rows_here * vsize;
+    // rows lie `stride` words apart in LDS, an ODD number: with the matrix's own stride (V = 400 = 16 mod 32) the same bin of all
+    // 64 rows falls on two of the 32 banks, and most k-mers of a sample share a handful of bins -- the adds were bank-conflict bound
+    const uint32_t stride = vsize | 1u;
+    const uint32_t n_bins = (uint32_t)rows_here * stride;
     for (uint32_t i = threadIdx.x; i < n_bins; i += BIG_BLOCK) hist[i] = 0;
     __syncthreads();
     const int64_t a = (int64_t)goff[g], b = a + (int64_t)gcnt[g];
     const uint32_t bmask = (1u << vbits) - 1u;
     constexpr uint32_t NONE = (uint32_t)(WORD)~(WORD)0;
-    for (int64_t base = a; base < b; base += (int64_t)BIG_BLOCK * 8) {
-        uint32_t e[8];
+    // (one workgroup per CU -- the histogram fills LDS -- so nothing else hides the load latency: the next batch's 8 loads per
+    // lane are issued before this batch's adds)
+    auto fetch = [&](int64_t base, uint32_t (&e)[8]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                                // 8 loads per lane in flight
+        for (int j = 0; j < 8; ++j) {
             const int64_t i = base + (int64_t)j * BIG_BLOCK + threadIdx.x;
             if (sizeof(WORD) == 2) {
                 // (through the dword that holds it: two lanes share a load, and the compiler does not serialise dword loads the
@@ -1515,6 +1519,11 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restr
                 e[j] = i < b ? (uint32_t)words[i] : NONE;
             }
         }
+    };
+    uint32_t e[8], en[8];
+    fetch(a, e);
+    for (int64_t base = a; base < b; base += (int64_t)BIG_BLOCK * 8) {
+        fetch(base + (int64_t)BIG_BLOCK * 8, en);
         // equal words in neighbouring lanes are added once: consecutive k-mers of a read share their row and, mostly, their bin,
         // and a lookup pass that works on super-k-mers leaves them next to each other -- as single adds they would queue up on
         // one LDS address
@@ -1526,12 +1535,15 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restr
             const unsigned long long hm = __ballot(head);
             const unsigned long long above = lane == 63 ? 0ull : hm >> (lane + 1);
             const uint32_t run = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
-            if (head && e[j] != NONE) atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * vsize + (e[j] & bmask)], run);
+            if (head && e[j] != NONE) atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * stride + (e[j] & bmask)], run);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = en[j];
     }
     __syncthreads();
     int32_t *dst = abd_out + row0 * (int64_t)vsize;
-    for (uint32_t i = threadIdx.x; i < n_bins; i += BIG_BLOCK) dst[i] = (int32_t)hist[i];
+    const uint32_t n_out = (uint32_t)rows_here * vsize;
+    for (uint32_t i = threadIdx.x; i < n_out; i += BIG_BLOCK) dst[i] = (int32_t)hist[(i / vsize) * stride + i % vsize];
 }
 
 // -------------------------------------------------------------------------------- K1 + K3 by lookups: per-run rows
@@ -2314,7 +2326,7 @@ static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize,
     auto *gcur2 = (unsigned long long *)(ws + sp.gcur2_off);
     auto *words_a = (uint32_t *)(ws + sp.words_a_off);
     auto *words_b = (uint32_t *)(ws + sp.words_b_off);
-    const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)vsize;
+    const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)(vsize | 1);
     if ((rc = raise_lds_limit((const void *)row_hist_kernel<uint32_t>, hist_lds, "pg_abundance_from_records"))) return rc;
     if ((rc = raise_lds_limit((const void *)row_hist_kernel<uint16_t>, hist_lds, "pg_abundance_from_records"))) return rc;
     if (narrow && sp.gb2) return pg_fail(PG_EINVAL, "row shuffle: narrow words need a one-pass shuffle");
