@@ -654,6 +654,14 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             if (in_row) mine += (unsigned long long)n;
             const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
             i = i0 + BIG_BLOCK + lane;                           // the next batch's loads fly during this one
+            {
+                // ... provided they are issued BEHIND the wait for this batch's record: the compiler hoists them to the top of the
+                // loop, in front of that wait, and -- the loads being conditional -- the wait is an s_waitcnt vmcnt(0) that then
+                // covers them too: every batch stood still for a full memory round trip (one workgroup per CU: nothing else to
+                // run).  Making their address depend on this batch's record pins them behind the wait.
+                const uint32_t arrived = (uint32_t)FW;
+                asm volatile("" : "+v"(i) : "v"(arrived));
+            }
             R = i < rb ? bases[i] : 0ull;
             m = i < rb ? meta[i] : 0xffffffffu;
             uint64_t code[CX];
@@ -711,7 +719,8 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             }
             if (emit_slots) {
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
-                // shuffle do not like runs of equal words)
+                // shuffle do not like runs of equal words).  (Deferring these stores to the next iteration's top, behind its
+                // vmcnt wait, changed nothing: 17.33 ms either way.)
 #pragma unroll
                 for (int j = 0; j < CX; ++j) {
                     if ((pm[j] >> lane) & 1ull) prov_b[at + lanes_below(pm[j])] = (row << lb) | sl[j];
