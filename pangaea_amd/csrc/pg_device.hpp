@@ -60,7 +60,16 @@ __device__ __forceinline__ Word load_word(const uint64_t *__restrict__ codes, co
 // scatter loops that exposes the full store latency of every copy-out at the next barrier (measured in mini_count's scatter
 // phase: 8.6 of 26 k cycles per tile).  This one waits for the wavefront's LDS operations only; global stores, prefetch loads
 // and cursor atomics stay in flight across it.  Not for data that another wavefront reads from GLOBAL memory.
-__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (builtins, not inline asm: the barrier intrinsic is convergent, so the compiler will not duplicate or sink it into divergent code;
+// 0xc07f = lgkmcnt(0) with the vmcnt and expcnt fields at their maxima, i.e. not waited for; the signal fences keep the compiler
+// from moving memory operations across)
+__device__ __forceinline__ void lds_sync()
+{
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
 
 // per-digit exclusive scan of table[d][0..n) in place, plus base[d << base_shift]; totals[d] (may be NULL) = row sum.
 // One workgroup per digit.
