@@ -238,3 +238,33 @@ def test_mini_low_complexity_runs_and_saturating_counts(k):
     assert np.array_equal(abd.cpu().numpy(), oabd)
     _, abd_l = kmer.features(s, rows, k_tnf=None, table=t, window=10, vsize=400)
     assert torch.equal(abd_l, abd)
+
+
+def test_mini_plan_computed_ahead_on_a_side_stream():
+    """``prefetch_plan``: the partition plan of the next count, computed on a side stream (what ``bench.py --plan ahead`` does for
+    every batch), is picked up by that count and gives the same table and rows as a plan computed in front of the count"""
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=37, n_genomes=3, genome_len=30_000, fragment=8_000, sub_rate=0.01, n_rate=0.2, seed=808)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.KmerTable.mini_with_slots(21, DEV, 22, 10).count(s, rows=plan, emit=(10, 400))
+    want_items = t.items()
+    _, want = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
+    first_ws = t._mini_plan[1]
+    side = torch.cuda.Stream(device=DEV)
+    for _ in range(3):                                               # two workspaces take turns
+        t.prefetch_plan(s, plan, side)
+        assert t._mini_next is not None and t._mini_next[1] is not t._mini_plan[1]
+        t.reset()
+        t._mini_plan = None                                          # a new batch: the kept plan does not apply
+        t.count(s, rows=plan, emit=(10, 400))
+        assert t._mini_next is None
+        _, got = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
+        assert torch.equal(got, want) and _same_items(t.items(), want_items)
+    assert t._mini_plan[1] is not None and first_ws is not None
+    # a prefetched plan for other rows is ignored by a count that does not match it
+    other = kmer.Plan(s.rows(0), DEV)
+    t.prefetch_plan(s, other, side)
+    t.reset().count(s, rows=plan, emit=(10, 400))
+    _, got = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
+    assert torch.equal(got, want)
