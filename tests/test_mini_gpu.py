@@ -268,3 +268,22 @@ def test_mini_plan_computed_ahead_on_a_side_stream():
     t.reset().count(s, rows=plan, emit=(10, 400))
     _, got = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
     assert torch.equal(got, want)
+
+
+def test_mini_more_rows_than_a_slot_word_holds():
+    """300 k rows and buckets of 2^14 slots: row and slot index no longer fit one 32-bit word, so the lookups take the general form
+    by themselves (records probed a second time, two-pass row shuffle); rows against the lookup kernel on a key-partitioned table"""
+    rng = np.random.RandomState(6)
+    n = 300_000
+    text = bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8))
+    s = ReadStream.from_runs([("x", text)], device=DEV)
+    start = np.arange(50, n - 50, dtype=np.int64)
+    rows = Rows(np.zeros(len(start), dtype=np.int64), [""] * len(start), start, start + 1)
+    plan = kmer.Plan(rows, DEV)
+    assert plan.shuffle_ok and len(start) >= (1 << 18)
+    t = kmer.KmerTable.mini_with_slots(21, DEV, 20, 14).count(s, rows=plan, emit=(1, 8))
+    _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=1, vsize=8)
+    h = kmer.count_kmers(s, 21, kind="hash")
+    _, want = kmer.features(s, rows, k_tnf=None, table=h, window=1, vsize=8, seg_chars=32)
+    assert torch.equal(abd, want) and int(abd.sum()) > 250_000
+    assert _same_items(t.items(), h.items())
