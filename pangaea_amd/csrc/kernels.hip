@@ -655,6 +655,15 @@ struct PairRange {
             v[j] = q < q1 ? rec2[q] : make_ulonglong2(pad, pad);
         }
     }
+    // the NEXT batch's loads, issued behind the point where `dep` (something computed from the current batch) is known: without
+    // the dependency the compiler hoists these conditional loads in front of the s_waitcnt vmcnt(0) for the current batch, which
+    // then waits for them too -- the prefetch is gone, and a kernel that runs one workgroup per CU has nothing else to do meanwhile
+    __device__ __forceinline__ void load_next(int64_t base, ulonglong2 (&v)[CNT_BATCH / 2], unsigned long long pad, uint32_t dep) const
+    {
+        int64_t b = base + stride;
+        asm volatile("" : "+v"(b) : "v"(dep));
+        load(b, v, pad);
+    }
     // which of the batch's records belong to the bucket (the first / last pair may straddle its ends)
     __device__ __forceinline__ void live(int64_t base, bool (&l)[CNT_BATCH]) const
     {
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count32_kernel(const uint64_
         bool live[CNT_BATCH];
         pr.live(base, live);
         split32(nxt, tag_mask, hsh, smask, tg, ss, row);
-        pr.load(base + PairRange::stride, nxt, 0ull);               // software pipeline: the next batch's loads fly during the inserts
+        pr.load_next(base, nxt, 0ull, tg[0]);                       // software pipeline: the next batch's loads fly during the inserts
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
 #define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
@@ -887,13 +896,14 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_compact32_kernel(const
     __syncthreads();
     bool full = false;
     const PairRange pr(rec, r0, r1);
+    ulonglong2 v[CNT_BATCH / 2];
+    pr.load(pr.q0, v, 0ull);
     for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
-        ulonglong2 v[CNT_BATCH / 2];
         uint32_t tg[CNT_BATCH], ss[CNT_BATCH], row[CNT_BATCH], first[CNT_BATCH];
         bool live[CNT_BATCH];
-        pr.load(base, v, 0ull);
         pr.live(base, live);
         split32(v, tag_mask, hsh, smask, tg, ss, row);
+        pr.load_next(base, v, 0ull, tg[0]);                         // the next batch's loads fly during the inserts
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
 #define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
@@ -1351,13 +1361,14 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_lookup32_kernel(const uint64
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const PairRange pr(rec, r0, r1);
+    ulonglong2 w[CNT_BATCH / 2];
+    pr.load(pr.q0, w, ~0ull);                                       // a padding lane carries ROW_NONE
     for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {
-        ulonglong2 v[CNT_BATCH / 2];
         uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH], row[CNT_BATCH];
         bool live[CNT_BATCH];
-        pr.load(base, v, ~0ull);                                    // a padding lane carries ROW_NONE
         pr.live(base, live);
-        split32(v, tag_mask, hsh, smask, tg, ss, row);
+        split32(w, tag_mask, hsh, smask, tg, ss, row);
+        pr.load_next(base, w, ~0ull, tg[0]);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
             live[j] = live[j] && row[j] != ROW_NONE;
@@ -1415,13 +1426,14 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_emit32_kernel(const ui
     __syncthreads();
     bool full = false;
     const PairRange pr(rec, r0, r1);
+    ulonglong2 v[CNT_BATCH / 2];
+    pr.load(pr.q0, v, 0ull);
     for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {       // ---- count
-        ulonglong2 v[CNT_BATCH / 2];
         uint32_t tg[CNT_BATCH], ss[CNT_BATCH], row[CNT_BATCH], first[CNT_BATCH];
         bool live[CNT_BATCH];
-        pr.load(base, v, 0ull);
         pr.live(base, live);
         split32(v, tag_mask, hsh, smask, tg, ss, row);
+        pr.load_next(base, v, 0ull, tg[0]);                         // the next batch's loads fly during the inserts
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) first[j] = live[j] ? tags[ss[j]] : 0u;
 #define PG_RESOLVE(J) full |= !lds_insert32(tags, cnts, smask, limit, tg[J], live[J], ss[J], first[J]);
@@ -1432,13 +1444,13 @@ __global__ __launch_bounds__(BIG_BLOCK) void bucket_count_emit32_kernel(const ui
     __syncthreads();
     slice_from_planes(tags, cnts, n_slots, tag_mask, (uint64_t)blockIdx.x << tag_bits, slice);      // ---- the slice image (stores overlap the lookups)
     const uint32_t lane = threadIdx.x & 63;
+    pr.load(pr.q0, v, ~0ull);                                       // a padding lane carries ROW_NONE
     for (int64_t base = pr.q0; base < pr.q1; base += PairRange::stride) {       // ---- lookups of the same records
-        ulonglong2 v[CNT_BATCH / 2];
         uint32_t tg[CNT_BATCH], ss[CNT_BATCH], first[CNT_BATCH], row[CNT_BATCH];
         bool live[CNT_BATCH];
-        pr.load(base, v, ~0ull);                                    // a padding lane carries ROW_NONE
         pr.live(base, live);
         split32(v, tag_mask, hsh, smask, tg, ss, row);
+        pr.load_next(base, v, ~0ull, tg[0]);
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
             live[j] = live[j] && row[j] != ROW_NONE;
