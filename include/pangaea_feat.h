@@ -357,6 +357,15 @@ int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int v
                                    void *shuffle_ws, int64_t shuffle_ws_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Row normalisation of a count matrix (a9: Data.__init__, src/data.py:16-21 -- sklearn normalize(norm="l1") in float64, the
+ * sampling weight = (row maximum of the normalised abundance)^2, matrices narrowed to float32).  One pass over device int32
+ * [n_rows, n_cols]: out[r, c] = (float)((double)m[r, c] / (double)sum_c |m[r, c]|), an all-zero row stays zero (sklearn puts 1
+ * for a zero norm); weight[r] (may be NULL) = ((double)max_c m[r, c] / sum)^2 -- division by a positive number is monotone, so
+ * this is the square of the row maximum of the quotients.  Integer sums and IEEE double division: bit-identical to the CPU.
+ * ---------------------------------------------------------------------------------------------- */
+int pg_normalize_rows(const int32_t *m, int64_t n_rows, int n_cols, float *out, double *weight, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Cache files.  Rows as the reference binaries print them: "<name>,v1,...,vD\n", numbers through
  * ostream<<double (%g, six significant digits; count_tnf.cpp:293-303), gzip container.
  * names: n_rows NUL-terminated strings back to back.  mat: host int32 [n_rows, n_cols].

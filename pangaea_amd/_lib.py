@@ -124,6 +124,7 @@ def load() -> C.CDLL:
         "pg_mini_count": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, vp, i64, i32, i32, vp, i64, vp, vp]),
         "pg_mini_abundance_from_emitted": (i32, [tp, rp, i32, vp, vp, i64, i64, vp, i64, vp]),
         "pg_features": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp, vp, tp, i32, i32, vp, vp]),
+        "pg_normalize_rows": (i32, [vp, i64, i32, vp, vp, vp]),
         "pg_write_csv_gz": (i32, [cp, cp, vp, i64, i64]),
         "pg_extract_reads": (i32, [cp, cp, cp, cp, C.POINTER(i64)]),
     }
@@ -144,7 +145,7 @@ EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fast
            "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed", "pg_kmer_rebuild_bucketed", "pg_kmer_rebuild_bucketed_range", "pg_table_bucket_fill", "pg_kmer_count_deferred", "pg_deferred_gather", "pg_deferred_gather_planes", "pg_kmer_rebuild_planes_range", "pg_table_bucket_fill_range", "pg_table_compact_planes_range", "pg_table_compact", "pg_kmer_merge_wide", "pg_abundance_workspace_bytes",
            "pg_abundance_from_records", "pg_abundance_from_emitted", "pg_kmer_count_bucketed_emit",
            "pg_mini_plan_bytes", "pg_mini_plan", "pg_mini_records_bytes", "pg_mini_shuffle_bytes", "pg_mini_count", "pg_mini_abundance_from_emitted",
-           "pg_features", "pg_write_csv_gz", "pg_extract_reads"]
+           "pg_features", "pg_normalize_rows", "pg_write_csv_gz", "pg_extract_reads"]
 
 
 def check(rc: int) -> int:

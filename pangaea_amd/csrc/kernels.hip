@@ -2433,6 +2433,50 @@ int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int3
     return shuffle_finish(sp, rows, vsize, abd_out, (char *)workspace, (hipStream_t)stream, narrow != 0);
 }
 
+// a9: L1 row normalisation in float64, narrowed to float32, + the sampling weight; one wavefront per row (src/data.py:16-21)
+namespace {
+__global__ __launch_bounds__(BLOCK) void normalize_rows_kernel(const int32_t *__restrict__ m, int64_t n_rows, int n_cols,
+                                                               float *__restrict__ out, double *__restrict__ weight)
+{
+    const int64_t r = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const int32_t *row = m + r * n_cols;
+    long long sum = 0;
+    int32_t top = INT32_MIN;
+    for (int c = lane; c < n_cols; c += 64) {
+        const int32_t x = row[c];
+        sum += x < 0 ? -(long long)x : (long long)x;
+        top = x > top ? x : top;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sum += __shfl_xor(sum, d);
+        const int32_t o = __shfl_xor(top, d);
+        top = o > top ? o : top;
+    }
+    const double norm = sum == 0 ? 1.0 : (double)sum;                // (sklearn: a zero norm counts as 1)
+    float *dst = out + r * n_cols;
+    for (int c = lane; c < n_cols; c += 64) dst[c] = (float)((double)row[c] / norm);
+    if (weight && lane == 0) {
+        const double q = n_cols > 0 ? (double)top / norm : 0.0;
+        weight[r] = q * q;
+    }
+}
+}  // namespace
+
+extern "C" int pg_normalize_rows(const int32_t *m, int64_t n_rows, int n_cols, float *out, double *weight, void *stream)
+{
+    if (n_rows < 0 || n_cols < 0) return pg_fail(PG_EINVAL, "pg_normalize_rows: negative size");
+    if (n_rows == 0 || n_cols == 0) return PG_OK;
+    if (!m || !out) return pg_fail(PG_EINVAL, "pg_normalize_rows: null argument");
+    const int64_t per = BLOCK / 64;
+    const int64_t grid = (n_rows + per - 1) / per;
+    if (grid > 0x7fffffffLL) return pg_fail(PG_EINVAL, "pg_normalize_rows: too many rows for one launch");
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, m, n_rows, n_cols, out, weight);
+    return check_launch("pg_normalize_rows");
+}
+
 extern "C" int pg_features(const uint64_t *codes, const uint32_t *valid, int64_t n_words,
                            const int32_t *seg_row, const int64_t *seg_start, const int64_t *seg_end, int64_t n_segs,
                            int k_tnf, const uint16_t *colmap, int32_t *tnf_out,

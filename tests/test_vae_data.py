@@ -36,6 +36,29 @@ def test_data_is_bit_identical_to_reference(device):
     assert np.array_equal(d2.abd, g["abd"]) and np.array_equal(d2.weights, g["weights"])
 
 
+@pytest.mark.gpu
+def test_fused_row_normalisation_is_bit_identical():
+    """int32 device matrices (what the feature kernels leave) take ONE kernel (pg_normalize_rows) instead of the float64 torch
+    passes: same bits as the reference's vectors, as the oracle and as the torch path -- zero rows, negative entries, ragged widths"""
+    g = np.load(os.path.join(GOLDEN, "data_g4.npz"))
+    a32, t32 = torch.from_numpy(g["abd_in"].astype(np.int32)).cuda(), torch.from_numpy(g["tnf_in"].astype(np.int32)).cuda()
+    assert np.array_equal(a32.cpu().numpy(), g["abd_in"]) and np.array_equal(t32.cpu().numpy(), g["tnf_in"])     # (the golden inputs are counts)
+    d = Data(np.arange(37), a32, t32)
+    assert d.abd_dev.dtype == torch.float32 and d.weights.dtype == np.float64
+    assert np.array_equal(d.abd, g["abd"]) and np.array_equal(d.tnf, g["tnf"]) and np.array_equal(d.weights, g["weights"])
+    rs = np.random.RandomState(4)
+    for n, va, vt in ((1, 1, 1), (5, 400, 136), (1000, 63, 65), (257, 512, 32)):
+        abd = rs.randint(0, 2000, size=(n, va)).astype(np.int32)
+        tnf = rs.randint(-50, 3000, size=(n, vt)).astype(np.int32)
+        abd[rs.rand(n) < 0.2] = 0                                    # rows without any k-mer
+        abd[rs.rand(n) < 0.1, 0] = 2_000_000_000                     # sums beyond 32 bits
+        fused = Data(np.arange(n), torch.from_numpy(abd).cuda(), torch.from_numpy(tnf).cuda())
+        plain = Data(np.arange(n), torch.from_numpy(abd.astype(np.int64)).cuda(), torch.from_numpy(tnf.astype(np.int64)).cuda())
+        oa, ot, ow = oracle.data_normalize(abd, tnf)
+        for x, y, z in ((fused.abd, plain.abd, oa), (fused.tnf, plain.tnf, ot), (fused.weights, plain.weights, ow)):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
 @pytest.mark.parametrize("device", DEVICES)
 def test_network_matches_reference_vectors(device):
     g, state = _g5()
