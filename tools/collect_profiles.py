@@ -40,6 +40,7 @@ KERNELS = [
     ("bucket_lookup_kernel", "features", 2.0), ("bucket_lookup32_kernel", "features", 2.0), ("scatter_records_kernel<unsigned int", "features", 2.0),
     ("row_hist_kernel", "features", 2.0), ("group_caps_kernel", "features", 1.0),
     ("features_kernel<unsigned int, 0", "features", 2.0), ("features_kernel", "features", 1.0),
+    ("normalize_rows_kernel", "normalise", 2.0),
 ]
 
 
