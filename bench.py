@@ -284,7 +284,9 @@ def main():
                     emit=(WINDOW, VSIZE) if fused else None)
         e[1].record()
         if mini and args.plan == "ahead":
-            table.prefetch_plan(stream, plan, side)     # the next batch's plan: starts when this count is done, under the rest of the step
+            # the next batch's plan, on a side stream behind this batch's count: it runs under the row histograms and the encode
+            # (PG_PLAN_BESIDE=1 starts it beside the count instead -- measured: the count slows down by what the plan takes)
+            table.prefetch_plan(stream, plan, side, after=e[0] if os.environ.get("PG_PLAN_BESIDE") else None)
         if world > 1:
             pdist.exchange_table(table, check=False)
         elif multi:

@@ -184,25 +184,24 @@ __device__ __forceinline__ LaneWord load_lane_word(const uint64_t *__restrict__ 
     return lw;
 }
 
-// ---- plan: records per bucket (hist) and, per chunk, records per first-pass region (chunk_hist[d * n_chunks + slot(chunk)])
+// ---- plan: per chunk, records per first-pass region (chunk_hist[d * n_chunks + slot(chunk)]).  Nothing else: the per-bucket
+// counts are taken from the records themselves once the first pass has written them (mini_bucket_hist_kernel).  With 2 KB of
+// LDS, 256 threads and ~48 registers this kernel fits beside the workgroups of the other kernels on a CU -- beside the count
+// kernel, which fills LDS but leaves half of the VALU issue slots and a third of the registers idle: KmerTable.prefetch_plan
+// runs the next batch's plan on a side stream UNDER this batch's second scatter pass and count instead of in front of them
 template <int W, bool DELAY, int M>
-__global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                                                              int64_t word_begin, int64_t word_end, int k, int woff, int bits, int bits2, int cap,
-                                                              const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
-                                                              const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
-                                                              unsigned long long *__restrict__ hist, unsigned long long *__restrict__ chunk_hist,
-                                                              int64_t n_chunks, int64_t chunk_stride, uint32_t b_base, int nb)
+__global__ __launch_bounds__(BLOCK) void mini_plan_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                          int64_t word_begin, int64_t word_end, int k, int woff, int bits, int bits2, int cap,
+                                                          const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
+                                                          const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
+                                                          unsigned long long *__restrict__ chunk_hist, int64_t n_chunks, int64_t chunk_stride)
 {
-    // this launch histograms the buckets [b_base, b_base + nb) in LDS (2^15 counters at most: a table of 2^16 buckets takes two
-    // launches); the per-chunk region counts are taken by the launch with b_base = 0
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *coarse = lds + nb;                                    // [1 << MINI_MAX_BITS1]
-    for (int i = threadIdx.x; i < nb; i += BIG_BLOCK) lds[i] = 0;
+    __shared__ uint32_t coarse[1 << MINI_MAX_BITS1];
     const int n_dig = 1 << (bits - bits2);
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        if (threadIdx.x < (1 << MINI_MAX_BITS1)) coarse[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < (1 << MINI_MAX_BITS1); i += BLOCK) coarse[i] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < MINI_CHUNK_WORDS; i += BIG_BLOCK) {
+        for (int i = threadIdx.x; i < MINI_CHUNK_WORDS; i += BLOCK) {
             const int64_t wi = chunk * MINI_CHUNK_WORDS + i;        // word index inside the range
             const int64_t w = word_begin + wi;
             if (w >= word_end) continue;
@@ -211,17 +210,60 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_plan_kernel(const uint64_t *__
             RowBits rb;
             rb.init(row_start, row_end, n_rows, row_start ? round_row[wi / ROUND_WORDS] : 0, w << 5);
             mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int, int, uint32_t b) {
-                if (b - b_base < (uint32_t)nb) atomicAdd(&lds[b - b_base], 1u);
-                if (b_base == 0) atomicAdd(&coarse[b >> bits2], 1u);
+                atomicAdd(&coarse[b >> bits2], 1u);
             });
         }
         __syncthreads();
-        if ((int)threadIdx.x < n_dig && b_base == 0)
-            chunk_hist[(int64_t)threadIdx.x * n_chunks + (int64_t)(((__int128)chunk * chunk_stride) % n_chunks)] = coarse[threadIdx.x];
+        for (int d = threadIdx.x; d < n_dig; d += BLOCK)
+            chunk_hist[(int64_t)d * n_chunks + (int64_t)(((__int128)chunk * chunk_stride) % n_chunks)] = coarse[d];
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < nb; i += BIG_BLOCK)
-        if (lds[i]) atomicAdd(&hist[b_base + i], (unsigned long long)lds[i]);
+}
+
+// row sums of table[d][0..n): one workgroup per digit
+__global__ __launch_bounds__(BIG_BLOCK) void digit_totals_kernel(const unsigned long long *__restrict__ table, int64_t n,
+                                                                 unsigned long long *__restrict__ totals)
+{
+    __shared__ unsigned long long part[BIG_BLOCK / 64];
+    const unsigned long long *row = table + (int64_t)blockIdx.x * n;
+    unsigned long long s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += BIG_BLOCK) s += row[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < BIG_BLOCK / 64; ++i) run += part[i];
+        totals[blockIdx.x] = run;
+    }
+}
+
+// records per bucket, from the records the first pass has written: region = blockIdx.x / tiles_x holds [region_off[region],
+// region_off[region + 1]); its workgroups count the second-pass digits of their share of the meta plane and add them to hist
+__global__ __launch_bounds__(BLOCK) void mini_bucket_hist_kernel(const uint32_t *__restrict__ meta, const unsigned long long *__restrict__ region_off,
+                                                                 int bits2, int tiles_x, unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t cnt[1 << META_D2_BITS];
+    const int n_dig = 1 << bits2;
+    const uint32_t dmask = (uint32_t)n_dig - 1u;
+    const int64_t region = blockIdx.x / tiles_x;
+    const int64_t r0 = (int64_t)region_off[region], r1 = (int64_t)region_off[region + 1];
+    if ((int)threadIdx.x < n_dig) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i0 = r0 + (int64_t)(blockIdx.x % tiles_x) * (8 * BLOCK); i0 < r1; i0 += (int64_t)tiles_x * (8 * BLOCK)) {
+        uint32_t m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t i = i0 + j * BLOCK + threadIdx.x;
+            m[j] = i < r1 ? meta[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j * BLOCK + (int64_t)threadIdx.x < r1) atomicAdd(&cnt[m[j] & dmask], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_dig && cnt[threadIdx.x]) atomicAdd(&hist[(region << bits2) + threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
 }
 
 // total records = off[nb] -> header[0]
@@ -979,11 +1021,11 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
     if (threadIdx.x == 0) emit_end[blockIdx.x] = wb + emitted;
 }
 
-// ---- workspace of the plan: header | hist | off | cur2 | wbeg | round_row | chunk table
+// ---- workspace of the plan: header | region_tot | region_off | off | hist | cur2 | cur2l | kwords | wbeg | round_row | chunk table
 struct MiniPlan {
     int bits, bits1, bits2;
     int64_t n_rounds, n_chunks, chunk_stride;
-    size_t header_off, hist_off, off_off, cur2_off, cur2l_off, kw_off, wbeg_off, round_off, chunk_off, total;
+    size_t header_off, rtot_off, roff_off, hist_off, off_off, cur2_off, cur2l_off, kw_off, wbeg_off, round_off, chunk_off, total;
 };
 
 // k-mers per record at most: what fits the 32 characters of a record and the 4-bit length field -- and the window: a
@@ -1036,8 +1078,10 @@ int plan_mini(const pg_table *t, int64_t n_words, MiniPlan *p)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
     p->header_off = take(256);
-    p->hist_off = take(nb * 8);
-    p->off_off = take((nb + 1) * 8);
+    p->rtot_off = take(((size_t)1 << MINI_MAX_BITS1) * 8);          // plan: records per region
+    p->roff_off = take((((size_t)1 << MINI_MAX_BITS1) + 1) * 8);    // plan: where every region starts
+    p->off_off = take((nb + 1) * 8);                                // count: where every bucket starts
+    p->hist_off = take(nb * 8);                                     // count: records per bucket (cleared with the cursors behind it)
     p->cur2_off = take(nb * 8);
     p->cur2l_off = take(nb * 8);
     p->kw_off = take(nb * 8);
@@ -1147,11 +1191,11 @@ extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)plan_ws;
     auto *header = (unsigned long long *)(ws + p.header_off);
-    auto *hist = (unsigned long long *)(ws + p.hist_off);
-    auto *off = (unsigned long long *)(ws + p.off_off);
+    auto *region_tot = (unsigned long long *)(ws + p.rtot_off);
+    auto *region_off = (unsigned long long *)(ws + p.roff_off);
     auto *round_row = (int32_t *)(ws + p.round_off);
     auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
-    const int nb = 1 << p.bits;
+    const int n_regions = 1 << p.bits1;
     if (hipMemsetAsync(ws, 0, p.round_off, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_mini_plan: memset failed");
     if (hipMemsetAsync(chunk_tab, 0, ((size_t)p.n_chunks << p.bits1) * 8, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_mini_plan: memset failed");
     const bool with_rows = rows && rows->n_rows > 0;
@@ -1159,22 +1203,19 @@ extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_
         if (with_rows)
             hipLaunchKernelGGL(round_rows_kernel, dim3((unsigned)((p.n_rounds + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rows->row_end, rows->n_rows,
                                word_begin, p.n_rounds, round_row);
-        const int nb_launch = nb < (1 << 15) ? nb : (1 << 15);
-        const size_t lds = (size_t)nb_launch * 4 + ((size_t)4 << MINI_MAX_BITS1);
-        const int grid = (int)(p.n_chunks < 512 ? p.n_chunks : 512);
-        for (int b_base = 0; b_base < nb; b_base += nb_launch) {
-            PG_MINI_DISPATCH_W(t->k,
-                if ((rc = raise_lds_limit((const void *)(mini_plan_kernel<W, DELAY, M>), lds, "pg_mini_plan"))) return rc;
-                hipLaunchKernelGGL((mini_plan_kernel<W, DELAY, M>), dim3(grid), dim3(BIG_BLOCK), lds, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, p.bits2, mini_cap(t->k),
-                                   with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
-                                   with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
-                                   (const int32_t *)round_row, hist, chunk_tab, p.n_chunks, p.chunk_stride, (uint32_t)b_base, nb_launch))
-        }
+        const int grid = (int)(p.n_chunks < 4096 ? p.n_chunks : 4096);
+        PG_MINI_DISPATCH_W(t->k,
+            hipLaunchKernelGGL((mini_plan_kernel<W, DELAY, M>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, p.bits2, mini_cap(t->k),
+                               with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
+                               with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
+                               (const int32_t *)round_row, chunk_tab, p.n_chunks, p.chunk_stride))
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)hist, (int64_t)nb, off);
-    hipLaunchKernelGGL(digit_scan_kernel, dim3(1u << p.bits1), dim3(BIG_BLOCK), 0, s, chunk_tab, p.n_chunks, (const unsigned long long *)off,
-                       p.bits2, (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(mini_total_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long *)off, nb, header);
+    // records per region -> where the regions start -> exact offset of every (chunk, region) run; total -> header[0]
+    hipLaunchKernelGGL(digit_totals_kernel, dim3((unsigned)n_regions), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)chunk_tab, p.n_chunks, region_tot);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)region_tot, (int64_t)n_regions, region_off);
+    hipLaunchKernelGGL(digit_scan_kernel, dim3((unsigned)n_regions), dim3(BIG_BLOCK), 0, s, chunk_tab, p.n_chunks, (const unsigned long long *)region_off,
+                       0, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(mini_total_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long *)region_off, n_regions, header);
     return check_launch("pg_mini_plan");
 }
 
@@ -1207,7 +1248,9 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     auto *off = (unsigned long long *)(ws + p.off_off);
     auto *cur2 = (unsigned long long *)(ws + p.cur2_off);
     auto *cur2l = (unsigned long long *)(ws + p.cur2l_off);
-    auto *kwords = (unsigned long long *)(ws + p.kw_off);            // (cur2 | cur2l | kwords are cleared together below)
+    auto *kwords = (unsigned long long *)(ws + p.kw_off);            // (hist | cur2 | cur2l | kwords are cleared together below)
+    auto *hist = (unsigned long long *)(ws + p.hist_off);
+    auto *region_off = (unsigned long long *)(ws + p.roff_off);
     auto *wbeg = (unsigned long long *)(ws + p.wbeg_off);
     auto *round_row = (int32_t *)(ws + p.round_off);
     auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
@@ -1218,7 +1261,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     auto *bases_b = bases_a + cap;
     auto *meta_a = (uint32_t *)(bases_b + cap);
     auto *meta_b = meta_a + cap;
-    if (hipMemsetAsync(cur2, 0, p.wbeg_off - p.cur2_off, s) != hipSuccess || hipMemsetAsync(header + 1, 0, 8, s) != hipSuccess)
+    if (hipMemsetAsync(hist, 0, p.wbeg_off - p.hist_off, s) != hipSuccess || hipMemsetAsync(header + 1, 0, 8, s) != hipSuccess)
         return pg_fail(PG_EHIP, "pg_mini_count: memset failed");
     pg_shuffle_layout sl{0, 0, 0, 0, 0};
     if (window > 0) {
@@ -1239,6 +1282,18 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
                                (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride))
         if (p.bits1 > MINI_BITS1) { PG_MINI_LAUNCH_SCATTER(512) } else { PG_MINI_LAUNCH_SCATTER(256) }
 #undef PG_MINI_LAUNCH_SCATTER
+    }
+    if (p.bits2) {
+        // records per bucket from the regions' meta plane -> where every bucket starts (an empty range: all zero)
+        const int tiles_h = 32;
+        if (word_end > word_begin)
+            hipLaunchKernelGGL(mini_bucket_hist_kernel, dim3((unsigned)(tiles_h << p.bits1)), dim3(BLOCK), 0, s, (const uint32_t *)meta_a,
+                               (const unsigned long long *)region_off, p.bits2, tiles_h, hist);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)hist, (int64_t)nb, off);
+    } else {
+        off = region_off;                                   // buckets = regions
+    }
+    if (word_end > word_begin) {
         if (p.bits2) {
             const int tiles_x = 96;
             hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,

@@ -382,7 +382,8 @@ class KmerTable:
             self.check_status()
         return self
 
-    def prefetch_plan(self, stream: ReadStream, rows: "Plan | None", side: "torch.cuda.Stream") -> None:
+    def prefetch_plan(self, stream: ReadStream, rows: "Plan | None", side: "torch.cuda.Stream",
+                      after: "torch.cuda.Event | None" = None) -> None:
         """compute the partition plan of the NEXT count of ``stream`` (whole range, strict validity) on the stream ``side``, into a
         workspace of its own: ``side`` waits for what the current stream has enqueued so far -- call this right after ``count`` and
         the plan of batch i + 1 runs under the row histograms and the encode of batch i instead of in front of its own count.
@@ -400,7 +401,12 @@ class KmerTable:
         self._mini_spare = None
         if ws is None:
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
+        # ``after`` = an event recorded before this batch's count was enqueued: the plan then runs BESIDE the count (its kernel
+        # is small enough to share the CUs with it) instead of behind it
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device), torch.cuda.stream(side):
             _lib.check(L.pg_mini_plan(stream.codes.data_ptr(), stream.valid.data_ptr(), 0, n_words, self.desc(),
                                       C.byref(keep.rows_desc) if keep is not None else None, ws.data_ptr(), ws.numel(), side.cuda_stream))
