@@ -284,9 +284,12 @@ def main():
                     emit=(WINDOW, VSIZE) if fused else None)
         e[1].record()
         if mini and args.plan == "ahead":
-            # the next batch's plan, on a side stream behind this batch's count: it runs under the row histograms and the encode
-            # (PG_PLAN_BESIDE=1 starts it beside the count instead -- measured: the count slows down by what the plan takes)
-            table.prefetch_plan(stream, plan, side, after=e[0] if os.environ.get("PG_PLAN_BESIDE") else None)
+            # the next batch's plan, on a side stream behind this batch's count: it runs beside the row histograms and the encode
+            # (2.3 of its 2.7 ms stay visible).  PG_PLAN_WHERE=second-pass starts it behind the FIRST scatter pass instead, beside
+            # the memory-bound second pass (1.6 ms visible: the step is 0.7 ms shorter, but the roofline stage below then carries
+            # another batch's plan in its time -- not the default for that reason); =first-pass: beside everything (all visible)
+            where = os.environ.get("PG_PLAN_WHERE", "")
+            table.prefetch_plan(stream, plan, side, after="first-pass" if where == "second-pass" else e[0] if where == "first-pass" else None)
         if world > 1:
             pdist.exchange_table(table, check=False)
         elif multi:

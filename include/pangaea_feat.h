@@ -352,6 +352,9 @@ int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize);
 int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                   const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
                   int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream);
+/* `stream` waits for the first scatter pass of the calling thread's latest pg_mini_count (an event recorded there): the next
+ * batch's pg_mini_plan, enqueued on that stream afterwards, runs beside the memory-bound second pass. */
+int pg_mini_wait_first_pass(void *stream);
 int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int vsize, int32_t *abd_out,
                                    const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
                                    void *shuffle_ws, int64_t shuffle_ws_bytes, void *stream);

@@ -1219,6 +1219,17 @@ extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_
     return check_launch("pg_mini_plan");
 }
 
+static thread_local hipEvent_t first_pass_event = nullptr;         // recorded by every pg_mini_count behind its first scatter pass
+
+// makes `stream` wait for the first scatter pass of this thread's latest pg_mini_count: work enqueued on it afterwards (the next
+// batch's plan) overlaps the memory-bound second pass instead of the VALU-bound first one
+extern "C" int pg_mini_wait_first_pass(void *stream)
+{
+    if (!first_pass_event) return pg_fail(PG_EINVAL, "pg_mini_wait_first_pass: no count yet");
+    if (hipStreamWaitEvent((hipStream_t)stream, first_pass_event, 0) != hipSuccess) return pg_fail(PG_EHIP, "pg_mini_wait_first_pass: wait failed");
+    return PG_OK;
+}
+
 extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                              const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
                              int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream)
@@ -1283,6 +1294,10 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         if (p.bits1 > MINI_BITS1) { PG_MINI_LAUNCH_SCATTER(512) } else { PG_MINI_LAUNCH_SCATTER(256) }
 #undef PG_MINI_LAUNCH_SCATTER
     }
+    // (for pg_mini_wait_first_pass: what is enqueued on another stream behind this event runs beside the second pass and the count)
+    if (!first_pass_event && hipEventCreateWithFlags(&first_pass_event, hipEventDisableTiming) != hipSuccess)
+        return pg_fail(PG_EHIP, "pg_mini_count: event creation failed");
+    if (hipEventRecord(first_pass_event, s) != hipSuccess) return pg_fail(PG_EHIP, "pg_mini_count: event record failed");
     if (p.bits2) {
         // records per bucket from the regions' meta plane -> where every bucket starts (an empty range: all zero)
         const int tiles_h = 32;

@@ -403,7 +403,9 @@ class KmerTable:
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         # ``after`` = an event recorded before this batch's count was enqueued: the plan then runs BESIDE the count (its kernel
         # is small enough to share the CUs with it) instead of behind it
-        if after is not None:
+        if after == "first-pass":
+            _lib.check(L.pg_mini_wait_first_pass(side.cuda_stream))   # behind the first scatter pass of the count just enqueued
+        elif after is not None:
             side.wait_event(after)
         else:
             side.wait_stream(torch.cuda.current_stream(self.device))
