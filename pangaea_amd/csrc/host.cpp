@@ -274,7 +274,8 @@ struct pg_reads {
     uint32_t *valid_w = nullptr;
     uint32_t *lower_w = nullptr;                 // NULL unless the input has lower-case bases
     uint32_t *lowq_w = nullptr;                  // NULL unless paired input has bases of quality below '?'
-    std::vector<uint32_t> lower_plane;           // (the threaded path keeps the rare plane here)
+    std::vector<uint32_t> lower_plane;           // (the threaded paths keep the rare plane here)
+    std::vector<uint32_t> lowq_plane;            // (... and the threaded paired path its low-quality plane)
     int64_t n_words = 0, n_chars = 0;
     std::vector<int64_t> run_off;      // [n_runs + 1]
     std::vector<std::string> run_name;
@@ -404,20 +405,23 @@ public:
             if (eof_ || !more()) return c;
         }
     }
-    bool next(UnitLines &u)
+    // the next `want` (<= 8) lines as one unit: an interleaved pair (8) or a record of one file (4)
+    bool next(UnitLines &u, int want = 8)
     {
         for (;;) {
             size_t q = cur_;
             int k = 0;
-            while (k < 8 && q < have_) {
+            while (k < want && q < have_) {
                 const char *b = buf_.data() + q;
                 const char *nl = (const char *)memchr(b, '\n', have_ - q);
                 if (!nl) break;
                 u.p[k] = b; u.n[k] = (size_t)(nl - b); ++k;
                 q = (size_t)(nl - buf_.data()) + 1;
             }
-            if (k < 8) {
-                if (!eof_) { if (more()) continue; if (io_error_) return false; }
+            if (k < want) {
+                // (more() moves the unread tail to the front of the buffer even when it finds nothing further to read: the
+                // positions collected so far are stale either way, so the unit is scanned again)
+                if (!eof_) { more(); if (io_error_) return false; continue; }
                 if (q < have_) { u.p[k] = buf_.data() + q; u.n[k] = have_ - q; ++k; q = have_; }   // unterminated last line
                 if (k == 0) return false;
             }
@@ -528,26 +532,69 @@ inline uint32_t lower_bases(const char *s, int count, uint64_t &cb)
     return lb;
 }
 
+// 32 quality characters -> bit j set iff (unsigned char)q[j] < '?'
+__attribute__((target("avx2"))) inline uint32_t lowq32_avx2(const char *q)
+{
+    const __m256i x = _mm256_loadu_si256((const __m256i *)q);
+    const uint32_t below = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi8(_mm256_set1_epi8('?'), x));      // signed compare ...
+    return below & ~(uint32_t)_mm256_movemask_epi8(x);                                                        // ... bytes >= 128 are not below
+}
+
 struct LowerMask { int64_t pos; uint32_t mask; };     // lower-case bases at characters pos .. pos + 31 of the thread's stream
 
 struct LocalStream {          // one thread's characters, packed from bit 0
     std::vector<uint64_t> codes;
     std::vector<uint32_t> valid;
     std::vector<LowerMask> lower;         // sparse: sequencer reads are upper case
+    std::vector<uint32_t> lowq;           // paired files only (with_q): bases of quality below '?' -- dense, those are common
+    bool with_q = false, any_q = false;
     int64_t n = 0;
-    uint64_t cw = 0; uint32_t vw = 0;
+    uint64_t cw = 0; uint32_t vw = 0, qw = 0;
     const bool simd = simd_ok();
     // `count` (1..32) characters; bits above them are zero
-    inline void put_bits(uint64_t cb, uint32_t vb, int count)
+    inline void put_bits(uint64_t cb, uint32_t vb, int count, uint32_t qb = 0)
     {
         const int sh = (int)(n & 31);
         cw |= cb << (2 * sh);
         vw |= vb << sh;
+        qw |= qb << sh;
         n += count;
         if (sh + count >= 32) {
             codes.push_back(cw); valid.push_back(vw);
-            if (sh) { cw = cb >> (2 * (32 - sh)); vw = vb >> (32 - sh); } else { cw = 0; vw = 0; }
+            if (with_q) lowq.push_back(qw);
+            if (sh) { cw = cb >> (2 * (32 - sh)); vw = vb >> (32 - sh); qw = qb >> (32 - sh); } else { cw = 0; vw = 0; qw = 0; }
         }
+    }
+    // positions j < count of a block that starts at character i of its line whose quality character is below '?'
+    inline uint32_t lowq_bits(const char *q, size_t qlen, size_t i, int count) const
+    {
+        if (count == 32 && simd && i + 32 <= qlen) return lowq32_avx2(q + i);
+        uint32_t b = 0;
+        for (int j = 0; j < count && i + (size_t)j < qlen; ++j) b |= (uint32_t)((unsigned char)q[i + (size_t)j] < (unsigned char)'?') << j;
+        return b;
+    }
+    // a sequence line with its quality line (StreamWriter::put_span_q + the separator): a BASE (either case) of quality below
+    // '?' is marked in the lowq plane; a missing quality character marks nothing
+    void put_line_q(const char *s, size_t len, const char *q, size_t qlen)
+    {
+        size_t i = 0;
+        uint64_t cb; uint32_t vb;
+        auto block = [&](int count, int chars) {       // `chars` characters of the line (+ the separator when count > chars)
+            uint32_t lb = 0;
+            if (vb != (chars == 32 ? 0xffffffffu : (1u << chars) - 1u) && chars) {
+                lb = lower_bases(s + i, chars, cb);
+                if (lb) lower.push_back(LowerMask{n, lb});
+            }
+            const uint32_t qb = lowq_bits(q, qlen, i, chars) & (vb | lb);
+            any_q |= qb != 0;
+            put_bits(cb, vb, count, qb);
+        };
+        if (simd) for (; i + 32 <= len; i += 32) { pack32_avx2(s + i, cb, vb); block(32, 32); }
+        for (; i + 8 <= len; i += 8) { uint64_t x; memcpy(&x, s + i, 8); pack8(x, cb, vb); block(8, 8); }
+        uint64_t x = 0;
+        memcpy(&x, s + i, len - i);                  // < 8 characters, zero padded (zero bytes are invalid), then the separator
+        pack8(x, cb, vb);
+        block((int)(len - i) + 1, (int)(len - i));
     }
     // one sequence line followed by the separator the reference appends ('N': invalid)
     void put_line(const char *s, size_t len)
@@ -575,7 +622,7 @@ struct LocalStream {          // one thread's characters, packed from bit 0
         const uint32_t lb = lower_bases(s, count, cb);
         if (lb) lower.push_back(LowerMask{n, lb});
     }
-    void finish() { if (n & 31) { codes.push_back(cw); valid.push_back(vw); cw = 0; vw = 0; } }
+    void finish() { if (n & 31) { codes.push_back(cw); valid.push_back(vw); if (with_q) lowq.push_back(qw); cw = 0; vw = 0; qw = 0; } }
 };
 
 struct Change { int64_t end_pos; std::string prev; };       // a run ends at end_pos (thread-local); it carries `prev`
@@ -726,6 +773,298 @@ int open_plain(const char *path, int &fd, size_t &size, bool &plain)
     return PG_OK;
 }
 
+// ------------------------------------------------------------------------------------ parallel paired ingest (-1 / -2)
+//
+// Same result as the serial paired loop of pg_ingest_fastq (count_tnf.cpp:174-231: lines of the two files in lockstep, a pair
+// whose names or barcodes differ is skipped but its reads still feed the global table, jellyfish's --min-qual-char=? marks).
+// Records are cut by R1 byte ranges: newline counts of both files give every thread the record index of its first R1 record,
+// and the finer counts of R2 where the same record starts there.  Threads cover the records that are complete in BOTH files;
+// whatever lies behind them (a record cut short, an R2 that is shorter or longer) is a tail the serial rules are applied to.
+struct PairSink {                 // what a run of (R1 record, R2 record) pairs leaves behind
+    LocalStream main, orph;       // kept pairs; reads of skipped pairs (they follow the last run)
+    std::vector<Change> changes;
+    bool any = false;
+    std::string first, last;
+    int64_t first_end = 0, pairs = 0, unpaired = 0;
+    PairSink() { main.with_q = true; orph.with_q = true; }
+    void keep(const char *s1, size_t l1, const char *q1, size_t q1n, const char *s2, size_t l2, const char *q2, size_t q2n,
+              const char *bc, size_t bcn)
+    {
+        main.put_line_q(s1, l1, q1, q1n);
+        main.put_line_q(s2, l2, q2, q2n);
+        ++pairs;
+        if (!any) { any = true; first.assign(bc, bcn); first_end = main.n; last = first; }
+        else if (bcn != last.size() || (bcn && memcmp(bc, last.data(), bcn) != 0)) {
+            changes.push_back(Change{main.n, last});
+            last.assign(bc, bcn);
+        }
+    }
+    void skip(const char *s1, size_t l1, const char *q1, size_t q1n, const char *s2, size_t l2, const char *q2, size_t q2n)
+    {
+        orph.put_line_q(s1, l1, q1, q1n);
+        orph.put_line_q(s2, l2, q2, q2n);
+    }
+};
+
+struct PairLatch { uint64_t header; int mode; };     // first header (2 * record + file) that fixes the grammar (UINT64_MAX: none)
+inline int mode_of(const PairLatch &L, uint64_t header) { return header < L.header ? (int)MODE_UNSET : L.mode; }
+
+inline bool same_span(const char *a, const Span &x, const char *b, const Span &y)
+{
+    return x.n == y.n && (x.n == 0 || memcmp(a + x.b, b + y.b, x.n) == 0);
+}
+
+// lines of a file = newlines + an unterminated last line
+int count_lines_blocks(int fd, size_t size, int n_blocks, int T, std::vector<uint64_t> &nl_before, uint64_t &n_lines, const char *path)
+{
+    std::vector<uint64_t> nl(n_blocks, 0);
+    std::vector<char> bad(T, 0);
+    const size_t block = reader_block((size_t)1 << 20);
+    run_threads(T, [&](int t) {
+        for (int j = t; j < n_blocks; j += T) {
+            const size_t a = (size_t)((unsigned __int128)size * (unsigned)j / (unsigned)n_blocks);
+            const size_t b = (size_t)((unsigned __int128)size * (unsigned)(j + 1) / (unsigned)n_blocks);
+            UnitReader rd(fd, a, b, block);
+            nl[j] = rd.count_newlines();
+            if (rd.io_error()) bad[t] = 1;
+        }
+    });
+    for (char x : bad) if (x) return pg_fail(PG_EIO, "read error in %s", path);
+    nl_before.assign(n_blocks + 1, 0);
+    for (int j = 0; j < n_blocks; ++j) nl_before[j + 1] = nl_before[j] + nl[j];
+    char c = '\n';
+    if (size > 0 && pread(fd, &c, 1, (off_t)(size - 1)) != 1) return pg_fail(PG_EIO, "read error in %s", path);
+    n_lines = nl_before[n_blocks] + (size > 0 && c != '\n' ? 1 : 0);
+    return PG_OK;
+}
+
+// byte offset of line `line` (0-based) of a file whose newlines before every block start are known; size if there is no such line
+int offset_of_line(int fd, size_t size, int n_blocks, const std::vector<uint64_t> &nl_before, uint64_t line, size_t &off, const char *path)
+{
+    if (line == 0) { off = 0; return PG_OK; }
+    if (line > nl_before[n_blocks]) { off = size; return PG_OK; }
+    int j = 0;
+    while (nl_before[j + 1] < line) ++j;                    // the block that holds the line-th newline
+    const size_t a = (size_t)((unsigned __int128)size * (unsigned)j / (unsigned)n_blocks);
+    UnitReader rd(fd, a, size, reader_block((size_t)1 << 16));
+    for (uint64_t k = nl_before[j]; k < line; ++k)
+        if (!rd.skip_line()) { if (rd.io_error()) return pg_fail(PG_EIO, "read error in %s", path); break; }
+    off = rd.offset();
+    return PG_OK;
+}
+
+// the serial rules on what the threads leave: R1 from a1, R2 from a2 (both at the start of record `rec0`)
+int paired_tail(int fd1, size_t a1, size_t n1, int fd2, size_t a2, size_t n2, uint64_t rec0, const PairLatch &L, int &mode, PairSink &o,
+                const char *r1)
+{
+    std::vector<char> t1(n1 - a1), t2(n2 - a2);
+    if ((!t1.empty() && pread(fd1, t1.data(), t1.size(), (off_t)a1) != (ssize_t)t1.size()) ||
+        (!t2.empty() && pread(fd2, t2.data(), t2.size(), (off_t)a2) != (ssize_t)t2.size()))
+        return pg_fail(PG_EIO, "read error in %s", r1);
+    Lines L1(t1.data(), t1.size()), L2(t2.data(), t2.size());
+    if (L.header != UINT64_MAX && 2 * rec0 >= L.header) mode = L.mode;     // (else the tail latches by itself, as the serial loop does)
+    uint64_t line_no = 0;
+    const char *b, *c; size_t len, clen;
+    Span n1s, b1s, n2s, b2s;
+    const char *h1 = "", *h2 = "";
+    const char *s1 = "", *s2 = ""; size_t l1 = 0, l2 = 0;
+    bool have_pair = false, keep_pair = false;
+    auto flush_pair = [&](const char *q1, size_t q1n, const char *q2, size_t q2n) {
+        if (!have_pair) return;
+        have_pair = false;
+        if (keep_pair) o.keep(s1, l1, q1, q1n, s2, l2, q2, q2n, h1 + b1s.b, b1s.n);
+        else o.skip(s1, l1, q1, q1n, s2, l2, q2, q2n);
+    };
+    while (L1.next(b, len)) {
+        if (!L2.next(c, clen)) { c = ""; clen = 0; }
+        switch (++line_no % 4) {
+        case 1:
+            if (!header_fields(b, len, mode, n1s, b1s) || !header_fields(c, clen, mode, n2s, b2s))
+                return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag (the reference aborts here)", r1,
+                               (unsigned long long)(4 * rec0 + line_no));
+            h1 = b; h2 = c;
+            break;
+        case 2:
+            flush_pair("", 0, "", 0);
+            keep_pair = same_span(h1, n1s, h2, n2s) && same_span(h1, b1s, h2, b2s);
+            if (!keep_pair) o.unpaired++;
+            s1 = b; l1 = len; s2 = c; l2 = clen;
+            have_pair = true;
+            break;
+        case 0:
+            flush_pair(b, len, c, clen);
+            break;
+        default: break;
+        }
+    }
+    flush_pair("", 0, "", 0);
+    uint64_t ln2 = line_no;
+    const char *os = nullptr; size_t on = 0;
+    while (L2.next(c, clen)) {                                  // R2 records beyond the end of R1: input of the global counter only
+        ++ln2;
+        if (ln2 % 4 == 2) { if (os) o.orph.put_line_q(os, on, "", 0); os = c; on = clen; }
+        else if (ln2 % 4 == 0 && os) { o.orph.put_line_q(os, on, c, clen); os = nullptr; }
+    }
+    if (os) o.orph.put_line_q(os, on, "", 0);
+    return PG_OK;
+}
+
+int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r1, const char *r2, pg_reads *R, int T)
+{
+    PhaseTimer tm;
+    const size_t block = reader_block((size_t)1 << 20);
+    // ---- A. lines of both files; R1 in T ranges (the threads' shares), R2 in finer blocks (to find a record's start)
+    const int B2 = 16 * T;
+    std::vector<uint64_t> nl1, nl2;
+    uint64_t lines1 = 0, lines2 = 0;
+    int rc;
+    if ((rc = count_lines_blocks(fd1, n1, T, T, nl1, lines1, r1))) return rc;
+    if ((rc = count_lines_blocks(fd2, n2, B2, T, nl2, lines2, r2))) return rc;
+    const uint64_t full = std::min(lines1 / 4, lines2 / 4);     // records that are complete in both files
+    tm.lap("lines");
+    // ---- the grammar latch: first header, R1 before R2 record by record, that carries a tag
+    PairLatch L{UINT64_MAX, MODE_UNSET};
+    {
+        UnitReader a(fd1, 0, n1, reader_block((size_t)1 << 16)), b(fd2, 0, n2, reader_block((size_t)1 << 16));
+        UnitLines u, v;
+        for (uint64_t r = 0; r < full && a.next(u, 4) && b.next(v, 4); ++r) {
+            if (find_bxz(u.p[0], u.n[0]) != NPOS) { L = PairLatch{2 * r, MODE_10X}; break; }
+            if (find_chr(u.p[0], u.n[0], '#', 0) != NPOS) { L = PairLatch{2 * r, MODE_STLFR}; break; }
+            if (find_bxz(v.p[0], v.n[0]) != NPOS) { L = PairLatch{2 * r + 1, MODE_10X}; break; }
+            if (find_chr(v.p[0], v.n[0], '#', 0) != NPOS) { L = PairLatch{2 * r + 1, MODE_STLFR}; break; }
+        }
+        if (a.io_error() || b.io_error()) return pg_fail(PG_EIO, "read error in %s", r1);
+    }
+    tm.lap("latch");
+    // ---- B. every thread: first record of its R1 range, the same record in R2, then pairs up to the next thread's first record
+    std::vector<uint64_t> rec0(T + 1, full);
+    std::vector<char> at_line_start(T, 1), bad(T, 0);
+    for (int t = 0; t < T; ++t) {
+        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)T);
+        if (t > 0 && a > 0) { char c = 0; if (pread(fd1, &c, 1, (off_t)(a - 1)) != 1) return pg_fail(PG_EIO, "read error in %s", r1); at_line_start[t] = c == '\n'; }
+        const uint64_t line = nl1[t] + (at_line_start[t] ? 0 : 1);       // first line that starts in the range
+        rec0[t] = std::min<uint64_t>((line + 3) / 4, full);
+    }
+    std::vector<PairSink> out(T + 1);                           // [T] = the tail
+    std::vector<uint64_t> bad_rec(T, UINT64_MAX);
+    run_threads(T, [&](int t) {
+        PairSink &o = out[t];
+        const uint64_t ra = rec0[t], rb = rec0[t + 1];
+        if (ra >= rb) return;
+        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)T);
+        UnitReader rd1(fd1, a, n1, block);
+        uint64_t line = nl1[t];
+        if (!at_line_start[t]) { if (!rd1.skip_line()) { bad[t] = 2; return; } ++line; }
+        for (; line < 4 * ra; ++line) if (!rd1.skip_line()) { bad[t] = 3; return; }
+        size_t off2 = 0;
+        if (offset_of_line(fd2, n2, B2, nl2, 4 * ra, off2, r2)) { bad[t] = 4; return; }
+        UnitReader rd2(fd2, off2, n2, block);
+        o.main.codes.reserve((size_t)(rb - ra) * 10 + 64);
+        o.main.valid.reserve((size_t)(rb - ra) * 10 + 64);
+        o.main.lowq.reserve((size_t)(rb - ra) * 10 + 64);
+        UnitLines u, v;
+        for (uint64_t r = ra; r < rb; ++r) {
+            if (!rd1.next(u, 4) || !rd2.next(v, 4) || u.count < 4 || v.count < 4) { bad[t] = 5; return; }
+            int m1 = mode_of(L, 2 * r), m2 = mode_of(L, 2 * r + 1);
+            Span a1, c1, a2, c2;
+            if (!header_fields(u.p[0], u.n[0], m1, a1, c1) || !header_fields(v.p[0], v.n[0], m2, a2, c2)) { bad_rec[t] = r; return; }
+            if (same_span(u.p[0], a1, v.p[0], a2) && same_span(u.p[0], c1, v.p[0], c2))
+                o.keep(u.p[1], u.n[1], u.p[3], u.n[3], v.p[1], v.n[1], v.p[3], v.n[3], u.p[0] + c1.b, c1.n);
+            else {
+                o.unpaired++;
+                o.skip(u.p[1], u.n[1], u.p[3], u.n[3], v.p[1], v.n[1], v.p[3], v.n[3]);
+            }
+        }
+        if (rd1.io_error() || rd2.io_error()) bad[t] = 6;
+    });
+    uint64_t first_bad = UINT64_MAX;
+    for (int t = 0; t < T; ++t) {
+        if (bad[t]) return pg_fail(PG_EIO, "read error in %s / %s (stage %d, thread %d)", r1, r2, (int)bad[t], t);
+        first_bad = std::min(first_bad, bad_rec[t]);
+    }
+    if (first_bad != UINT64_MAX)
+        return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag (the reference aborts here)", r1, (unsigned long long)(first_bad * 4 + 1));
+    tm.lap("parse+pack");
+    // ---- the tail, by the serial rules
+    int mode = MODE_UNSET;
+    {
+        size_t a1 = 0, a2 = 0;
+        if ((rc = offset_of_line(fd1, n1, T, nl1, 4 * full, a1, r1)) || (rc = offset_of_line(fd2, n2, B2, nl2, 4 * full, a2, r2))) return rc;
+        if ((rc = paired_tail(fd1, a1, n1, fd2, a2, n2, full, L, mode, out[T], r1))) return rc;
+        if (L.header != UINT64_MAX) mode = L.mode;
+    }
+    // ---- C. place: kept pairs of the threads and of the tail, then the reads of the skipped pairs in the same order
+    std::vector<LocalStream *> piece;
+    for (int t = 0; t <= T; ++t) { out[t].main.finish(); piece.push_back(&out[t].main); }
+    for (int t = 0; t <= T; ++t) { out[t].orph.finish(); piece.push_back(&out[t].orph); }
+    const int P = (int)piece.size();
+    std::vector<int64_t> cstart(P + 1, 0);
+    for (int i = 0; i < P; ++i) cstart[i + 1] = cstart[i] + piece[i]->n;
+    const int64_t total = cstart[P];
+    if (!R->alloc_stream(total)) return pg_fail(PG_ENOMEM, "out of memory while ingesting %s", r1);
+    uint64_t *gc = R->codes_w; uint32_t *gv = R->valid_w;
+    bool any_q = false, any_lower = false;
+    for (int i = 0; i < P; ++i) { any_q |= piece[i]->any_q; any_lower |= !piece[i]->lower.empty(); }
+    if (any_q) R->lowq_plane.assign((size_t)R->n_words, 0u);
+    uint32_t *gq = any_q ? R->lowq_plane.data() : nullptr;
+    for (int64_t w = (total + 31) >> 5; w < R->n_words; ++w) { gc[w] = 0; gv[w] = 0; }
+    for (int i = 0; i < P; ++i)
+        if (piece[i]->n) {
+            const int64_t a = cstart[i] >> 5, b = (cstart[i + 1] - 1) >> 5;
+            gc[a] = 0; gv[a] = 0; gc[b] = 0; gv[b] = 0;
+        }
+    run_threads(T, [&](int t) {
+        for (int i = t; i < P; i += T) {
+            const LocalStream &ls = *piece[i];
+            if (ls.n == 0) continue;
+            const int64_t w0 = cstart[i] >> 5, w1 = (cstart[i + 1] - 1) >> 5;
+            const int sh = (int)(cstart[i] & 31);
+            const int64_t nw = (int64_t)ls.codes.size();
+            for (int64_t g = w0; g <= w1; ++g) {
+                const int64_t k = g - w0;
+                uint64_t c = k < nw ? ls.codes[k] << (2 * sh) : 0;
+                uint32_t v = k < nw ? ls.valid[k] << sh : 0;
+                uint32_t q = gq && k < nw ? ls.lowq[k] << sh : 0;
+                if (sh && k > 0) { c |= ls.codes[k - 1] >> (64 - 2 * sh); v |= ls.valid[k - 1] >> (32 - sh); if (gq) q |= ls.lowq[k - 1] >> (32 - sh); }
+                if (g == w0 || g == w1) {
+                    __atomic_fetch_or(&gc[g], c, __ATOMIC_RELAXED); __atomic_fetch_or(&gv[g], v, __ATOMIC_RELAXED);
+                    if (gq) __atomic_fetch_or(&gq[g], q, __ATOMIC_RELAXED);
+                } else { gc[g] = c; gv[g] = v; if (gq) gq[g] = q; }
+            }
+        }
+    });
+    if (any_q) R->lowq_w = R->lowq_plane.data();
+    if (any_lower) {
+        R->lower_plane.assign((size_t)R->n_words, 0u);
+        for (int i = 0; i < P; ++i)
+            for (const LowerMask &m : piece[i]->lower) {
+                const int64_t pos = cstart[i] + m.pos;
+                const int sh = (int)(pos & 31);
+                R->lower_plane[(size_t)(pos >> 5)] |= m.mask << sh;
+                if (sh && (m.mask >> (32 - sh))) R->lower_plane[(size_t)(pos >> 5) + 1] |= m.mask >> (32 - sh);
+            }
+        R->lower_w = R->lower_plane.data();
+    }
+    tm.lap("place");
+    // ---- D. runs (as in the interleaved form); the skipped pairs' reads lie behind the last run
+    R->mode = mode;
+    R->run_off.push_back(0);
+    std::string none;
+    const std::string *last = &none;
+    for (int t = 0; t <= T; ++t) {
+        R->n_pairs += out[t].pairs;
+        R->n_unpaired += out[t].unpaired;
+        if (!out[t].any) continue;
+        if (out[t].first != *last) { R->run_off.push_back(cstart[t] + out[t].first_end); R->run_name.push_back(*last); }
+        for (const Change &c : out[t].changes) { R->run_off.push_back(cstart[t] + c.end_pos); R->run_name.push_back(c.prev); }
+        last = &out[t].last;
+    }
+    R->run_off.push_back(cstart[T + 1]);
+    R->run_name.push_back(*last);
+    tm.lap("runs");
+    return PG_OK;
+}
+
 }  // namespace
 
 extern "C" void pg_set_ingest_threads(int n) { g_ingest_threads = n > 0 ? n : 0; }
@@ -756,6 +1095,25 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
             return PG_OK;
         }
         close(fd);
+    }
+    if (r2 && T > 1) {            // two uncompressed files of some size: threaded as well
+        int fd1, fd2; size_t n1 = 0, n2 = 0; bool p1, p2;
+        if ((rc = open_plain(r1, fd1, n1, p1))) return rc;
+        if ((rc = open_plain(r2, fd2, n2, p2))) { close(fd1); return rc; }
+        if (p1 && p2 && n1 >= ((size_t)1 << 16) * (size_t)T) {
+            pg_reads *R = new (std::nothrow) pg_reads();
+            if (!R) { close(fd1); close(fd2); return pg_fail(PG_ENOMEM, "out of memory"); }
+            try {
+                rc = ingest_paired_threaded(fd1, n1, fd2, n2, r1, r2, R, T);
+            } catch (const std::bad_alloc &) {
+                rc = pg_fail(PG_ENOMEM, "out of memory while ingesting %s", r1);
+            }
+            close(fd1); close(fd2);
+            if (rc) { delete R; return rc; }
+            *out = R;
+            return PG_OK;
+        }
+        close(fd1); close(fd2);
     }
     FileBuf f1, f2;
     rc = slurp(r1, f1);

@@ -184,6 +184,16 @@ def test_parallel_ingest_equals_serial(tmp_path):
             assert np.array_equal(ref.codes.numpy(), got.codes.numpy()) and np.array_equal(ref.valid.numpy(), got.valid.numpy())
             assert np.array_equal(ref.run_off, got.run_off) and ref.run_names == got.run_names
             assert (ref.n_chars, ref.n_pairs, ref.mode) == (got.n_chars, got.n_pairs, got.mode)
+        # a last line without its newline (the threaded reader used to hand out stale line positions there)
+        bare = str(tmp_path / "bare.fq")
+        open(bare, "w").write(open(fq).read().rstrip("\n"))
+        L.pg_set_ingest_threads(1)
+        want = ReadStream.from_fastq(bare)
+        for T in (2, 5):
+            L.pg_set_ingest_threads(T)
+            got = ReadStream.from_fastq(bare)
+            assert np.array_equal(want.codes.numpy(), got.codes.numpy()) and np.array_equal(want.valid.numpy(), got.valid.numpy())
+            assert np.array_equal(want.run_off, got.run_off) and want.run_names == got.run_names and want.n_pairs == got.n_pairs
     finally:
         L.pg_set_ingest_threads(0)
     rd = oracle.Reads(fq)
@@ -360,3 +370,80 @@ def test_lower_case_plane_of_the_ingest(tmp_path):
         os.environ.pop("PG_INGEST_BLOCK", None)
     plain = ReadStream.from_fastq(os.path.join(GOLDEN, "tenx_clean.fq.gz"))
     assert plain.valid_lower is None
+
+
+def _same_stream(a, b):
+    def plane(x):
+        return None if x is None else x.numpy()
+    ok = np.array_equal(a.codes.numpy(), b.codes.numpy()) and np.array_equal(a.valid.numpy(), b.valid.numpy())
+    for x, y in ((a.valid_lower, b.valid_lower), (a.valid_lowq, b.valid_lowq)):
+        ok = ok and ((x is None) == (y is None)) and (x is None or np.array_equal(plane(x), plane(y)))
+    return (ok and np.array_equal(a.run_off, b.run_off) and a.run_names == b.run_names
+            and (a.n_chars, a.n_pairs, a.n_unpaired, a.mode) == (b.n_chars, b.n_pairs, b.n_unpaired, b.mode))
+
+
+def test_parallel_paired_ingest_equals_serial(tmp_path):
+    """-1 / -2 input through the threaded reader (records cut by R1 byte ranges, the same record located in R2, the serial rules
+    on the tail) gives the very same stream, planes (lower case, quality below '?'), runs and counters as the sequential loop:
+    mismatched names and barcodes, a grammar that latches late and in R2 first, ragged read lengths, a record cut short, an R2
+    that is shorter or longer than R1, CRLF"""
+    from pangaea_amd import synth
+    L = _lib.load()
+    rs = np.random.RandomState(12)
+    cfg = synth.SynthConfig(n_pairs=6000, n_barcodes=29, n_genomes=2, genome_len=30_000, fragment=5_000, n_rate=0.3, unbarcoded=0.05)
+    fq = str(tmp_path / "i.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, fq)
+    lines = open(fq).read().splitlines()
+    recs = [lines[i:i + 4] for i in range(0, len(lines), 4)]
+    r1, r2 = recs[0::2], recs[1::2]
+
+    def qual(n):
+        return "".join(rs.choice(list("#+5>?@FI"), size=n))
+
+    def soften(s):
+        a = rs.randint(0, max(1, len(s) - 5))
+        return s[:a] + s[a:a + 4].lower() + s[a + 4:]
+    for i, (a, b) in enumerate(zip(r1, r2)):
+        a[1] = a[1][:rs.randint(20, len(a[1]) + 1)]
+        a[3], b[3] = qual(len(a[1])), qual(len(b[1]) - (i % 7 == 0))          # (some quality lines one short)
+        if i % 11 == 0:
+            a[1] = soften(a[1])
+        if i % 13 == 0:
+            b[0] = b[0].replace("@", "@x", 1)                                     # other name: the pair is skipped
+        if i % 17 == 0 and "BX:Z:" in b[0]:
+            b[0] = b[0].replace("BX:Z:A", "BX:Z:C").replace("BX:Z:G", "BX:Z:T")  # other barcode: skipped
+    head1 = [[f"@u{i}", "ACGTNACGTTTGA", "+", "IIIII5IIIIIII"] for i in range(500)]
+    head2 = [[f"@u{i}", "TTGCANNA", "+", "II#IIIII"] for i in range(500)]
+    head2[320][0] += " BX:Z:ACGT-1"                                              # the grammar latches on an R2 header first
+
+    def text(rr, eol="\n"):
+        return "".join(eol.join(r) + eol for r in rr)
+    variants = {
+        "even": (text(head1 + r1), text(head2 + r2)),
+        "cut": (text(head1 + r1)[:-37], text(head2 + r2)),                       # R1's last record cut inside its quality line
+        "short2": (text(head1 + r1), text(head2 + r2[:-40] + [r2[-40][:2]])),    # R2 ends early, inside a record
+        "long2": (text(head1 + r1[:-25]), text(head2 + r2)),                     # R2 records beyond the end of R1
+        "crlf": (text(head1 + r1, "\r\n"), text(head2 + r2, "\r\n")),
+        "noeol": (text(head1 + r1).rstrip("\n"), text(head2 + r2).rstrip("\n")),
+    }
+    try:
+        for name, (t1, t2) in variants.items():
+            p1, p2 = str(tmp_path / f"{name}_1.fq"), str(tmp_path / f"{name}_2.fq")
+            open(p1, "w", newline="").write(t1)
+            open(p2, "w", newline="").write(t2)
+            L.pg_set_ingest_threads(1)
+            ref = ReadStream.from_fastq(p1, p2)
+            assert ref.n_unpaired > 100 and ref.valid_lowq is not None and ref.valid_lower is not None, name
+            for T, block in ((2, None), (5, "100"), (8, None), (13, "4096")):
+                L.pg_set_ingest_threads(T)
+                if block:
+                    os.environ["PG_INGEST_BLOCK"] = block
+                else:
+                    os.environ.pop("PG_INGEST_BLOCK", None)
+                got = ReadStream.from_fastq(p1, p2)
+                assert _same_stream(ref, got), (name, T, block)
+    finally:
+        L.pg_set_ingest_threads(0)
+        os.environ.pop("PG_INGEST_BLOCK", None)
+    rd = oracle.Reads(p1, p2)
+    assert ref.run_names == rd.names and ref.n_pairs == rd.n_pairs

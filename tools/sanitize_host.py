@@ -30,8 +30,24 @@ with open(big, "w") as out:
             for m in (1, 2):
                 seq = "".join("ACGTN"[x] for x in rng.randint(0, 5, rng.randint(30, 160)))
                 out.write(f"@r{b}_{p} BX:Z:{bc}-1\n{seq}\n+\n{'I' * len(seq)}\n")
+# the same reads as two files (-1 / -2) for the threaded paired reader: some names that do not match, qualities below '?', a
+# quality line one short, lower-case bases, R2 a few records longer, no newline at the end of R1
+big1, big2 = os.path.join(tmp, "big_1.fq"), os.path.join(tmp, "big_2.fq")
+recs = open(big).read().splitlines()
+recs = [recs[i:i + 4] for i in range(0, len(recs), 4)]
+with open(big1, "w") as o1, open(big2, "w") as o2:
+    for i, (a, b) in enumerate(zip(recs[0::2], recs[1::2])):
+        a[3] = "".join("#5?I"[x] for x in rng.randint(0, 4, len(a[1])))
+        b[3] = b[3][:len(b[3]) - (i % 5 == 0)]
+        if i % 9 == 0:
+            b[0] = b[0].replace("@r", "@q", 1)
+        if i % 4 == 0:
+            a[1] = a[1][:7].lower() + a[1][7:]
+        o2.write("\n".join(b) + "\n")
+        if i < len(recs) // 2 - 6:
+            o1.write("\n".join(a) + ("\n" if i < len(recs) // 2 - 7 else ""))
 inputs = [(os.path.join(G, f), None) for f in ("tenx_mixed.fq", "tenx_clean.fq.gz", "stlfr.fq", "tenx_crlf.fq", "tenx_single.fq", "polya.fq.gz")]
-inputs += [(os.path.join(G, "pair_R1.fq"), os.path.join(G, "pair_R2.fq")), (big, None)]
+inputs += [(os.path.join(G, "pair_R1.fq"), os.path.join(G, "pair_R2.fq")), (big, None), (big1, big2)]
 ref = {}
 for threads in (1, 2, 5, 16):
     lib.pg_set_ingest_threads(threads)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""time pg_ingest_fastq on a synthetic interleaved FASTQ for several thread counts (host-only; no GPU work)"""
+"""time pg_ingest_fastq on a synthetic interleaved FASTQ, and on the same reads as an R1 / R2 pair of files, for several
+thread counts (host-only; no GPU work)"""
 import ctypes as C
 import os
 import sys
@@ -24,4 +25,24 @@ for T in (1, 2, 4, 8, 16, 32):
         best = min(best, time.perf_counter() - t)
         L.pg_reads_free(h)
     print(f"threads {T:2d}: {best * 1e3:7.1f} ms  {n_pairs / best / 1e6:6.2f} M pairs/s")
-os.remove(path)
+# the same reads as -1 / -2 files
+p1, p2 = path + ".1", path + ".2"
+with open(path) as f, open(p1, "w") as o1, open(p2, "w") as o2:
+    while True:
+        rec = [f.readline() for _ in range(8)]
+        if not rec[0]:
+            break
+        o1.writelines(rec[:4]); o2.writelines(rec[4:])
+print("paired files (-1 / -2):")
+for T in (1, 4, 16, 32):
+    L.pg_set_ingest_threads(T)
+    best = 1e9
+    for _ in range(2 if T == 1 else 3):
+        h = C.c_void_p()
+        t = time.perf_counter()
+        _lib.check(L.pg_ingest_fastq(p1.encode(), p2.encode(), C.byref(h)))
+        best = min(best, time.perf_counter() - t)
+        L.pg_reads_free(h)
+    print(f"threads {T:2d}: {best * 1e3:7.1f} ms  {n_pairs / best / 1e6:6.2f} M pairs/s")
+for q in (path, p1, p2):
+    os.remove(q)
