@@ -773,6 +773,35 @@ int open_plain(const char *path, int &fd, size_t &size, bool &plain)
     return PG_OK;
 }
 
+// a gzip file for the threaded readers: inflated (one stream = one thread, as pigz -dc in feature.py:76-91) into an anonymous
+// in-memory file, which pread serves like any other -- the parse that follows is then threaded instead of serial.  fd < 0
+// on return (with PG_OK) means "not worth it / not possible here": the caller takes the serial path.
+int inflate_to_memfd(const char *path, int &fd, size_t &size)
+{
+    fd = -1; size = 0;
+    gzFile f = gzopen(path, "rb");
+    if (!f) return pg_fail(PG_EIO, "cannot open %s", path);
+    gzbuffer(f, 1 << 22);
+    int m = memfd_create("pg_inflate", MFD_CLOEXEC);
+    if (m < 0) { gzclose(f); return PG_OK; }
+    std::vector<char> buf((size_t)1 << 22);
+    for (;;) {
+        const int got = gzread(f, buf.data(), (unsigned)buf.size());
+        if (got < 0) { gzclose(f); close(m); return pg_fail(PG_EIO, "read error in %s", path); }
+        if (got == 0) break;
+        size_t done = 0;
+        while (done < (size_t)got) {
+            const ssize_t w = write(m, buf.data() + done, (size_t)got - done);
+            if (w <= 0) { gzclose(f); close(m); return PG_OK; }           // (no memory for it: serial path, which reports its own errors)
+            done += (size_t)w;
+        }
+        size += (size_t)got;
+    }
+    gzclose(f);
+    fd = m;
+    return PG_OK;
+}
+
 // ------------------------------------------------------------------------------------ parallel paired ingest (-1 / -2)
 //
 // Same result as the serial paired loop of pg_ingest_fastq (count_tnf.cpp:174-231: lines of the two files in lockstep, a pair
@@ -1078,6 +1107,12 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
     if (!r2 && T > 1) {           // an uncompressed interleaved file of some size: threaded, streamed from the file
         int fd; size_t size = 0; bool plain;
         if ((rc = open_plain(r1, fd, size, plain))) return rc;
+        if (!plain && size >= ((size_t)1 << 14) * (size_t)T) {        // gzip of some size: inflate once, then parse by threads
+            close(fd);
+            if ((rc = inflate_to_memfd(r1, fd, size))) return rc;
+            if (fd < 0) { if ((rc = open_plain(r1, fd, size, plain))) return rc; plain = false; }
+            else plain = true;
+        }
         if (plain && size >= ((size_t)1 << 16) * (size_t)T) {
             pg_reads *R = new (std::nothrow) pg_reads();
             if (!R) { close(fd); return pg_fail(PG_ENOMEM, "out of memory"); }
@@ -1100,6 +1135,17 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
         int fd1, fd2; size_t n1 = 0, n2 = 0; bool p1, p2;
         if ((rc = open_plain(r1, fd1, n1, p1))) return rc;
         if ((rc = open_plain(r2, fd2, n2, p2))) { close(fd1); return rc; }
+        if ((!p1 || !p2) && n1 >= ((size_t)1 << 14) * (size_t)T) {     // gzip: the two streams are inflated side by side
+            int g1 = -1, g2 = -1; size_t m1 = 0, m2 = 0; int rc1 = PG_OK, rc2 = PG_OK;
+            std::thread other([&] { if (!p2) rc2 = inflate_to_memfd(r2, g2, m2); });
+            if (!p1) rc1 = inflate_to_memfd(r1, g1, m1);
+            other.join();
+            if (rc1 || rc2) { close(fd1); close(fd2); if (g1 >= 0) close(g1); if (g2 >= 0) close(g2); return rc1 ? rc1 : rc2; }
+            if ((p1 || g1 >= 0) && (p2 || g2 >= 0)) {
+                if (!p1) { close(fd1); fd1 = g1; n1 = m1; p1 = true; }
+                if (!p2) { close(fd2); fd2 = g2; n2 = m2; p2 = true; }
+            } else { if (g1 >= 0) close(g1); if (g2 >= 0) close(g2); }
+        }
         if (p1 && p2 && n1 >= ((size_t)1 << 16) * (size_t)T) {
             pg_reads *R = new (std::nothrow) pg_reads();
             if (!R) { close(fd1); close(fd2); return pg_fail(PG_ENOMEM, "out of memory"); }

@@ -184,6 +184,15 @@ def test_parallel_ingest_equals_serial(tmp_path):
             assert np.array_equal(ref.codes.numpy(), got.codes.numpy()) and np.array_equal(ref.valid.numpy(), got.valid.numpy())
             assert np.array_equal(ref.run_off, got.run_off) and ref.run_names == got.run_names
             assert (ref.n_chars, ref.n_pairs, ref.mode) == (got.n_chars, got.n_pairs, got.mode)
+        # gzip input: inflated once (into an in-memory file), then parsed by the same threads
+        gz = str(tmp_path / "a.fq.gz")
+        with gzip.open(gz, "wb", compresslevel=1) as f:
+            f.write(open(fq, "rb").read())
+        for T in (1, 4):
+            L.pg_set_ingest_threads(T)
+            got = ReadStream.from_fastq(gz)
+            assert np.array_equal(ref.codes.numpy(), got.codes.numpy()) and np.array_equal(ref.valid.numpy(), got.valid.numpy())
+            assert np.array_equal(ref.run_off, got.run_off) and ref.run_names == got.run_names and ref.n_pairs == got.n_pairs
         # a last line without its newline (the threaded reader used to hand out stale line positions there)
         bare = str(tmp_path / "bare.fq")
         open(bare, "w").write(open(fq).read().rstrip("\n"))
@@ -442,6 +451,15 @@ def test_parallel_paired_ingest_equals_serial(tmp_path):
                     os.environ.pop("PG_INGEST_BLOCK", None)
                 got = ReadStream.from_fastq(p1, p2)
                 assert _same_stream(ref, got), (name, T, block)
+            if name in ("even", "long2"):                       # gzip of one file or of both: inflated side by side, then threaded
+                for which in ((1,), (1, 2)):
+                    q = [p1, p2]
+                    for w in which:
+                        q[w - 1] = [p1, p2][w - 1] + ".gz"
+                        with gzip.open(q[w - 1], "wb", compresslevel=1) as f:
+                            f.write(open([p1, p2][w - 1], "rb").read())
+                    L.pg_set_ingest_threads(6)
+                    assert _same_stream(ref, ReadStream.from_fastq(q[0], q[1])), (name, which)
     finally:
         L.pg_set_ingest_threads(0)
         os.environ.pop("PG_INGEST_BLOCK", None)

@@ -44,5 +44,21 @@ for T in (1, 4, 16, 32):
         best = min(best, time.perf_counter() - t)
         L.pg_reads_free(h)
     print(f"threads {T:2d}: {best * 1e3:7.1f} ms  {n_pairs / best / 1e6:6.2f} M pairs/s")
+# gzip (level 1, as sequencers and pigz -1 write it): one inflate stream per file, then the threaded parse
+import gzip  # noqa: E402
+import shutil  # noqa: E402
+for q in (path, p1, p2):
+    with open(q, "rb") as fi, gzip.open(q + ".gz", "wb", compresslevel=1) as fo:
+        shutil.copyfileobj(fi, fo, 1 << 24)
+for label, a, b in (("interleaved .gz", path + ".gz", None), ("paired .gz", p1 + ".gz", p2 + ".gz")):
+    for T in (1, 32):
+        L.pg_set_ingest_threads(T)
+        h = C.c_void_p()
+        t = time.perf_counter()
+        _lib.check(L.pg_ingest_fastq(a.encode(), b.encode() if b else None, C.byref(h)))
+        dt = time.perf_counter() - t
+        L.pg_reads_free(h)
+        print(f"{label:16s} threads {T:2d}: {dt * 1e3:7.1f} ms  {n_pairs / dt / 1e6:6.2f} M pairs/s")
 for q in (path, p1, p2):
     os.remove(q)
+    os.remove(q + ".gz")
