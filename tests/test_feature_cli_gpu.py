@@ -183,3 +183,43 @@ def test_packed_stream_cache_feeds_a_second_pass(tmp_path, monkeypatch):
     ref_t = pd.read_csv(os.path.join(GOLDEN, "tenx_clean.tnf.k5.l1000.csv"), header=None)
     assert (n2 == ref_a[0].to_numpy()).all()
     assert np.array_equal(t2, ref_t.drop(columns=0).to_numpy()) and np.array_equal(a2, ref_a.drop(columns=0).to_numpy())
+
+
+def test_feature_on_paired_files_through_the_threaded_reader(tmp_path, monkeypatch):
+    """-1 / -2 files large enough for the threaded paired reader (records cut by byte ranges of R1, located in R2): names,
+    abundance and TNF through ``Feature`` equal the oracle's reading of the same two files under jellyfish's rules (bases of
+    quality below '?' leave the table, skipped pairs still feed it), serial and threaded ingest give the same matrices"""
+    from oracle import oracle
+    from pangaea_amd import _lib, synth
+    from pangaea_amd.feature import Feature
+    rs = np.random.RandomState(3)
+    cfg = synth.SynthConfig(n_pairs=5000, n_barcodes=23, n_genomes=2, genome_len=30_000, fragment=6_000, n_rate=0.2, unbarcoded=0.03)
+    fq = str(tmp_path / "i.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, fq)
+    lines = open(fq).read().splitlines()
+    recs = [lines[i:i + 4] for i in range(0, len(lines), 4)]
+    p1, p2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    with open(p1, "w") as o1, open(p2, "w") as o2:
+        for i, (a, b) in enumerate(zip(recs[0::2], recs[1::2])):
+            a[3] = "".join(rs.choice(list("#5?FI"), size=len(a[1]), p=[0.03, 0.07, 0.1, 0.3, 0.5]))
+            b[3] = "".join(rs.choice(list("#5?FI"), size=len(b[1]), p=[0.03, 0.07, 0.1, 0.3, 0.5]))
+            if i % 29 == 0:
+                b[0] = b[0].replace("@", "@x", 1)
+            o1.write("\n".join(a) + "\n")
+            o2.write("\n".join(b) + "\n")
+    assert os.path.getsize(p1) > (1 << 16) * 4
+    rd = oracle.Reads(p1, p2)
+    table = oracle.Table(15, threads=4).count(np.frombuffer(rd.all_seq(), dtype=np.uint8))
+    names_o, tnf_o, abd_o = rd.features(1000, k_tnf=4, k_abd=15, table=table, window=2, vsize=100, threads=4)
+    out = {}
+    try:
+        for T in (4, 1):
+            _lib.load().pg_set_ingest_threads(T)
+            args = _args(tmp_path / f"t{T}", reads1=p1, reads2=p2, min_length=1000, kmer=15, window_size=2, vector_size=100)
+            out[T] = Feature(args, ROOT).extract_features()
+    finally:
+        _lib.load().pg_set_ingest_threads(0)
+    names, abd, tnf = out[4]
+    assert list(names) == list(names_o) and len(names) > 10
+    assert np.array_equal(abd, abd_o) and np.array_equal(tnf, tnf_o)
+    assert all(np.array_equal(x, y) for x, y in zip(out[4], out[1]))
