@@ -1752,6 +1752,180 @@ int extract_interleaved_parallel(int fd, size_t size, const char *path, const st
     return PG_OK;
 }
 
+// The -1 / -2 form, byte for byte the files of the serial branch below (extract_reads.cpp:57-190, paired input): records cut by R1
+// byte ranges and located in R2 as in ingest_paired_threaded, two passes over the records that are complete in both files
+// (sizes per thread and cluster, then pwrite at exact offsets), the serial rules on whatever lies behind them, appended.
+int extract_paired_parallel(int fd1, size_t n1, int fd2, size_t n2, const char *r1, const char *r2,
+                            const std::unordered_map<std::string, uint32_t> &cluster_of, const std::vector<std::string> &stems, int T,
+                            int64_t *pairs_written)
+{
+    const size_t n_bins = stems.size();
+    const size_t block = reader_block((size_t)1 << 20);
+    const int B2 = 16 * T;
+    std::vector<uint64_t> nl1, nl2;
+    uint64_t lines1 = 0, lines2 = 0;
+    int rc;
+    if ((rc = count_lines_blocks(fd1, n1, T, T, nl1, lines1, r1))) return rc;
+    if ((rc = count_lines_blocks(fd2, n2, B2, T, nl2, lines2, r2))) return rc;
+    const uint64_t full = std::min(lines1 / 4, lines2 / 4);
+    PairLatch L{UINT64_MAX, MODE_UNSET};
+    {
+        UnitReader a(fd1, 0, n1, reader_block((size_t)1 << 16)), b(fd2, 0, n2, reader_block((size_t)1 << 16));
+        UnitLines u, v;
+        for (uint64_t r = 0; r < full && a.next(u, 4) && b.next(v, 4); ++r) {
+            if (find_bxz(u.p[0], u.n[0]) != NPOS) { L = PairLatch{2 * r, MODE_10X}; break; }
+            if (find_chr(u.p[0], u.n[0], '#', 0) != NPOS) { L = PairLatch{2 * r, MODE_STLFR}; break; }
+            if (find_bxz(v.p[0], v.n[0]) != NPOS) { L = PairLatch{2 * r + 1, MODE_10X}; break; }
+            if (find_chr(v.p[0], v.n[0], '#', 0) != NPOS) { L = PairLatch{2 * r + 1, MODE_STLFR}; break; }
+        }
+        if (a.io_error() || b.io_error()) return pg_fail(PG_EIO, "read error in %s", r1);
+    }
+    std::vector<uint64_t> rec0(T + 1, full);
+    std::vector<char> at_line_start(T, 1);
+    for (int t = 0; t < T; ++t) {
+        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)T);
+        if (t > 0 && a > 0) { char c = 0; if (pread(fd1, &c, 1, (off_t)(a - 1)) != 1) return pg_fail(PG_EIO, "read error in %s", r1); at_line_start[t] = c == '\n'; }
+        const uint64_t line = nl1[t] + (at_line_start[t] ? 0 : 1);
+        rec0[t] = std::min<uint64_t>((line + 3) / 4, full);
+    }
+    struct Out { std::vector<uint64_t> fq, bc; uint64_t bad_rec = UINT64_MAX; bool io_error = false; int64_t pairs = 0; };
+    std::vector<Out> out(T);
+    auto walk = [&](int t, auto &&visit) {
+        Out &o = out[t];
+        const uint64_t ra = rec0[t], rb = rec0[t + 1];
+        if (ra >= rb) return;
+        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)T);
+        UnitReader rd1(fd1, a, n1, block);
+        uint64_t line = nl1[t];
+        if (!at_line_start[t]) { if (!rd1.skip_line()) { o.io_error = true; return; } ++line; }
+        for (; line < 4 * ra; ++line) if (!rd1.skip_line()) { o.io_error = true; return; }
+        size_t off2 = 0;
+        if (offset_of_line(fd2, n2, B2, nl2, 4 * ra, off2, r2)) { o.io_error = true; return; }
+        UnitReader rd2(fd2, off2, n2, block);
+        UnitLines u, v;
+        std::string barcode;
+        for (uint64_t r = ra; r < rb; ++r) {
+            if (!rd1.next(u, 4) || !rd2.next(v, 4) || u.count < 4 || v.count < 4) { o.io_error = true; return; }
+            int m1 = mode_of(L, 2 * r), m2 = mode_of(L, 2 * r + 1);
+            Span a1, c1, a2, c2;
+            if (!header_fields(u.p[0], u.n[0], m1, a1, c1) || !header_fields(v.p[0], v.n[0], m2, a2, c2)) { o.bad_rec = r; return; }
+            barcode.assign(u.p[0] + c1.b, c1.n);
+            auto it = cluster_of.find(barcode);
+            if (it != cluster_of.end() && same_span(u.p[0], a1, v.p[0], a2) && same_span(u.p[0], c1, v.p[0], c2))
+                visit(it->second, u, v, a1, a2, barcode);
+        }
+        if (rd1.io_error() || rd2.io_error()) o.io_error = true;
+    };
+    run_threads(T, [&](int t) {
+        out[t].fq.assign(n_bins, 0); out[t].bc.assign(n_bins, 0);
+        walk(t, [&](uint32_t id, const UnitLines &u, const UnitLines &v, const Span &a1, const Span &a2, const std::string &barcode) {
+            uint64_t bytes = a1.n + a2.n + 2 * (6 + barcode.size() + 3);
+            for (int k = 1; k < 4; ++k) bytes += u.n[k] + 1 + v.n[k] + 1;
+            out[t].fq[id] += bytes;
+            out[t].bc[id] += barcode.size() + 1;
+            ++out[t].pairs;
+        });
+    });
+    uint64_t first_bad = UINT64_MAX;
+    int64_t written = 0;
+    for (int t = 0; t < T; ++t) {
+        if (out[t].io_error) return pg_fail(PG_EIO, "read error in %s / %s", r1, r2);
+        first_bad = std::min(first_bad, out[t].bad_rec);
+        written += out[t].pairs;
+    }
+    if (first_bad != UINT64_MAX)
+        return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag", r1, (unsigned long long)(first_bad * 4 + 1));
+    std::vector<std::vector<uint64_t>> fq_at(T, std::vector<uint64_t>(n_bins)), bc_at(T, std::vector<uint64_t>(n_bins));
+    std::vector<int> fq_fd(n_bins, -1), bc_fd(n_bins, -1);
+    std::vector<uint64_t> fq_end(n_bins, 0), bc_end(n_bins, 0);
+    for (size_t b = 0; b < n_bins && !rc; ++b) {
+        uint64_t f = 0, c = 0;
+        for (int t = 0; t < T; ++t) { fq_at[t][b] = f; f += out[t].fq[b]; bc_at[t][b] = c; c += out[t].bc[b]; }
+        fq_end[b] = f; bc_end[b] = c;
+        fq_fd[b] = open((stems[b] + ".fq").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        bc_fd[b] = open((stems[b] + ".barcode").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fq_fd[b] < 0 || bc_fd[b] < 0 || ftruncate(fq_fd[b], (off_t)f) != 0 || ftruncate(bc_fd[b], (off_t)c) != 0)
+            rc = pg_fail(PG_EIO, "cannot create %s.{fq,barcode}", stems[b].c_str());
+    }
+    std::vector<char> wr_bad(T + 1, 0);
+    if (!rc) run_threads(T, [&](int t) {
+        std::vector<std::string> fq_buf(n_bins), bc_buf(n_bins);
+        auto flush = [&](size_t b, bool all) {
+            if (!fq_buf[b].empty() && (all || fq_buf[b].size() > ((size_t)1 << 18))) {
+                if (pwrite(fq_fd[b], fq_buf[b].data(), fq_buf[b].size(), (off_t)fq_at[t][b]) != (ssize_t)fq_buf[b].size()) wr_bad[t] = 1;
+                fq_at[t][b] += fq_buf[b].size(); fq_buf[b].clear();
+            }
+            if (!bc_buf[b].empty() && (all || bc_buf[b].size() > ((size_t)1 << 16))) {
+                if (pwrite(bc_fd[b], bc_buf[b].data(), bc_buf[b].size(), (off_t)bc_at[t][b]) != (ssize_t)bc_buf[b].size()) wr_bad[t] = 1;
+                bc_at[t][b] += bc_buf[b].size(); bc_buf[b].clear();
+            }
+        };
+        walk(t, [&](uint32_t id, const UnitLines &u, const UnitLines &v, const Span &a1, const Span &a2, const std::string &barcode) {
+            std::string &f = fq_buf[id];
+            f.append(u.p[0] + a1.b, a1.n).append("\tBX:Z:").append(barcode).append("-1\n");
+            for (int k = 1; k < 4; ++k) { f.append(u.p[k], u.n[k]); f.push_back('\n'); }
+            f.append(v.p[0] + a2.b, a2.n).append("\tBX:Z:").append(barcode).append("-1\n");
+            for (int k = 1; k < 4; ++k) { f.append(v.p[k], v.n[k]); f.push_back('\n'); }
+            bc_buf[id].append(barcode).push_back('\n');
+            flush(id, false);
+        });
+        for (size_t b = 0; b < n_bins; ++b) flush(b, true);
+    });
+    // the tail (a record cut short, an R2 of another length): the serial rules, appended behind the threads' shares
+    if (!rc) {
+        size_t a1 = 0, a2 = 0;
+        if ((rc = offset_of_line(fd1, n1, T, nl1, 4 * full, a1, r1)) == 0 && (rc = offset_of_line(fd2, n2, B2, nl2, 4 * full, a2, r2)) == 0) {
+            std::vector<char> t1(n1 - a1), t2(n2 - a2);
+            if ((!t1.empty() && pread(fd1, t1.data(), t1.size(), (off_t)a1) != (ssize_t)t1.size()) ||
+                (!t2.empty() && pread(fd2, t2.data(), t2.size(), (off_t)a2) != (ssize_t)t2.size()))
+                rc = pg_fail(PG_EIO, "read error in %s", r1);
+            int mode = L.header != UINT64_MAX && 2 * full >= L.header ? L.mode : (int)MODE_UNSET;
+            Lines L1(t1.data(), t1.size()), L2(t2.data(), t2.size());
+            uint64_t line_no = 0;
+            bool keep = false;
+            uint32_t id = 0;
+            std::string rec1, rec2, barcode;
+            const char *b, *c; size_t len, clen;
+            while (!rc && L1.next(b, len)) {
+                if (!L2.next(c, clen)) { c = ""; clen = 0; }
+                const int ph = (int)(++line_no % 4);
+                if (ph == 1) {
+                    Span s1, b1, s2, b2;
+                    if (!header_fields(b, len, mode, s1, b1) || !header_fields(c, clen, mode, s2, b2)) {
+                        rc = pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag", r1, (unsigned long long)(4 * full + line_no));
+                        break;
+                    }
+                    barcode.assign(b + b1.b, b1.n);
+                    auto it = cluster_of.find(barcode);
+                    keep = it != cluster_of.end() && same_span(b, s1, c, s2) && same_span(b, b1, c, b2);
+                    rec1.clear(); rec2.clear();
+                    if (keep) {
+                        id = it->second;
+                        rec1.append(b + s1.b, s1.n).append("\tBX:Z:").append(barcode).append("-1\n");
+                        rec2.append(c + s2.b, s2.n).append("\tBX:Z:").append(barcode).append("-1\n");
+                    }
+                } else if (keep) {
+                    rec1.append(b, len).push_back('\n');
+                    rec2.append(c, clen).push_back('\n');
+                    if (ph == 0) {
+                        const std::string both = rec1 + rec2, bl = barcode + "\n";
+                        if (pwrite(fq_fd[id], both.data(), both.size(), (off_t)fq_end[id]) != (ssize_t)both.size() ||
+                            pwrite(bc_fd[id], bl.data(), bl.size(), (off_t)bc_end[id]) != (ssize_t)bl.size()) wr_bad[T] = 1;
+                        fq_end[id] += both.size(); bc_end[id] += bl.size();
+                        ++written;
+                        rec1.clear(); rec2.clear();
+                    }
+                }
+            }
+        }
+    }
+    for (size_t b = 0; b < n_bins; ++b) { if (fq_fd[b] >= 0) close(fq_fd[b]); if (bc_fd[b] >= 0) close(bc_fd[b]); }
+    if (rc) return rc;
+    for (char x : wr_bad) if (x) return pg_fail(PG_EIO, "write error in %s_bin*", r1);
+    if (pairs_written) *pairs_written = written;
+    return PG_OK;
+}
+
 }  // namespace
 
 extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clusters_tsv, const char *out_prefix, int64_t *pairs_written)
@@ -1814,6 +1988,20 @@ extern "C" int pg_extract_reads(const char *r1, const char *r2, const char *clus
             return rc0;
         }
         close(fd);
+    }
+    if (r2 && T > 1) {                // two uncompressed files of some size: threaded as well
+        int fd1, fd2; size_t n1 = 0, n2 = 0; bool p1, p2;
+        int rc0 = open_plain(r1, fd1, n1, p1);
+        if (rc0) { close_all(); return rc0; }
+        if ((rc0 = open_plain(r2, fd2, n2, p2))) { close(fd1); close_all(); return rc0; }
+        if (p1 && p2 && n1 >= ((size_t)1 << 16) * (size_t)T) {
+            close_all();
+            try { rc0 = extract_paired_parallel(fd1, n1, fd2, n2, r1, r2, cluster_of, stems, T, pairs_written); }
+            catch (const std::bad_alloc &) { rc0 = pg_fail(PG_ENOMEM, "out of memory while writing the bins of %s", r1); }
+            close(fd1); close(fd2);
+            return rc0;
+        }
+        close(fd1); close(fd2);
     }
     FileBuf f1, f2;
     int rc = slurp(r1, f1);

@@ -106,3 +106,52 @@ def test_threaded_bin_writer_writes_the_same_bytes(style, tmp_path):
         d.mkdir()
         subprocess.run([oracle.ref_tool("extract_reads"), "-i", fq, "-c", tsv, "-o", str(d / "cluster")], check=True, stdout=subprocess.DEVNULL)
         assert {fn: (d / fn).read_bytes() for fn in sorted(os.listdir(d))} == outs["serial"][1]
+
+
+def test_threaded_paired_bin_writer_writes_the_same_bytes(tmp_path):
+    """-1 / -2 files big enough for the threaded form: the same cluster files as the sequential loop for any thread count and
+    block size -- pairs whose names or barcodes differ are left out, the last R1 record is cut short, R2 is longer -- and as
+    the reference's extract_reads on the same two files"""
+    from pangaea_amd import synth
+    cfg = synth.SynthConfig(n_pairs=7000, n_barcodes=60, n_genomes=2, genome_len=30_000, fragment=5_000, unbarcoded=0.1, seed=5)
+    fq = str(tmp_path / "i.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, fq)
+    lines = open(fq).read().splitlines()
+    recs = [lines[i:i + 4] for i in range(0, len(lines), 4)]
+    p1, p2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    with open(p1, "w") as o1, open(p2, "w") as o2:
+        for i, (a, b) in enumerate(zip(recs[0::2], recs[1::2])):
+            if i % 19 == 0:
+                b[0] = b[0].replace("@", "@y", 1)
+            if i % 23 == 0 and "BX:Z:" in b[0]:
+                b[0] = b[0].replace("BX:Z:A", "BX:Z:C").replace("BX:Z:G", "BX:Z:T")
+            o2.write("\n".join(b) + "\n")
+            if i < len(recs) // 2 - 9:
+                o1.write("\n".join(a) + "\n")
+            elif i == len(recs) // 2 - 9:
+                o1.write("\n".join(a[:3]) + "\n")                   # cut short: never written
+    barcodes = sorted({n for n in oracle.Reads(fq).names if n})
+    rng = random.Random(8)
+    tsv = str(tmp_path / "clusters.tsv")
+    write_clusters_tsv(tsv, [rng.choice([-1, 0, 1, 2, 5]) for _ in barcodes], barcodes)
+    L = _lib.load()
+    outs = {}
+    try:
+        for tag, threads, block in (("serial", 1, None), ("t3", 3, None), ("t6_small_blocks", 6, "500")):
+            L.pg_set_ingest_threads(threads)
+            if block:
+                os.environ["PG_INGEST_BLOCK"] = block
+            d = tmp_path / tag
+            d.mkdir()
+            n = extract_reads(p1, p2, tsv, str(d / "cluster"))
+            outs[tag] = (n, {fn: (d / fn).read_bytes() for fn in sorted(os.listdir(d))})
+    finally:
+        L.pg_set_ingest_threads(0)
+        os.environ.pop("PG_INGEST_BLOCK", None)
+    assert outs["serial"][0] > 1000 and len(outs["serial"][1]) == 8
+    assert outs["t3"] == outs["serial"] and outs["t6_small_blocks"] == outs["serial"]
+    if oracle.ref_tool("extract_reads") is not None:
+        d = tmp_path / "ref"
+        d.mkdir()
+        subprocess.run([oracle.ref_tool("extract_reads"), "-1", p1, "-2", p2, "-c", tsv, "-o", str(d / "cluster")], check=True, stdout=subprocess.DEVNULL)
+        assert {fn: (d / fn).read_bytes() for fn in sorted(os.listdir(d))} == outs["serial"][1]

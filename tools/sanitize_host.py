@@ -130,6 +130,17 @@ for threads, block in ((1, None), (4, None), (6, "300")):
     assert wrote.value > 0 and (sizes is None or got == sizes)
     sizes = got
 os.environ.pop("PG_INGEST_BLOCK", None)
+# ... and on the same reads as -1 / -2 files
+sizes = None
+for threads, block in ((1, None), (3, None), (5, "300")):
+    lib.pg_set_ingest_threads(threads)
+    if block:
+        os.environ["PG_INGEST_BLOCK"] = block
+    assert lib.pg_extract_reads(big1.encode(), big2.encode(), tsv2.encode(), os.path.join(tmp, f"p{threads}").encode(), C.byref(wrote)) == 0, lib.pg_last_error()
+    got = sorted((os.path.basename(f)[2:], open(f, "rb").read()) for f in glob.glob(os.path.join(tmp, f"p{threads}_bin*")))
+    assert wrote.value > 0 and (sizes is None or got == sizes)
+    sizes = got
+os.environ.pop("PG_INGEST_BLOCK", None)
 for f in glob.glob(os.path.join(tmp, "*")):
     os.remove(f)
 os.rmdir(tmp)
