@@ -619,8 +619,13 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
     unsigned long long *dbg = word_cursor + 7;                   // header[8..]: phase cycle sums (diagnostic build only)
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #define PG_STAMP(K) do { __syncthreads(); if (threadIdx.x == 0) atomicAdd(&dbg[K], (unsigned long long)(__builtin_amdgcn_s_memtime() - st0)); } while (0)
+    // per-wave laps inside the count loop: dbg[32 + K] += time since the previous lap (everything in flight is waited for first)
+    unsigned long long wl = st0, wacc[5] = {0, 0, 0, 0, 0};
+#define PG_WLAP(K) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                        wacc[K] += now_ - wl; wl = now_; } while (0)
 #else
 #define PG_STAMP(K) do { } while (0)
+#define PG_WLAP(K) do { } while (0)
 #endif
     for (uint32_t i = threadIdx.x; i < tab_units; i += BIG_BLOCK) tab[i] = 0ull;
     if (threadIdx.x == 0) { emitted = 0; n_lookups = 0; }
@@ -689,6 +694,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         uint64_t R = i < rb ? bases[i] : 0ull;
         uint32_t m = i < rb ? meta[i] : 0xffffffffu;
         for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BIG_BLOCK) {
+            PG_WLAP(0);                                          // (loop top: the record has arrived, last batch's stores are out)
             const bool live = i0 + lane < rb;
             const int n = live ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
             const uint32_t row = m >> META_ROW_SHIFT;
@@ -706,76 +712,96 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             }
             R = i < rb ? bases[i] : 0ull;
             m = i < rb ? meta[i] : 0xffffffffu;
+            // Straight-line code from here to the ballots: the reads and the adds go out for every lane (a lane without a j-th k-mer
+            // reads some slot and adds 0 to it), so that no predicate crosses a branch -- a predicate that does comes back as
+            // v_cndmask + v_cmp per use, and the branches around each predicated add cost more than the add
             uint64_t code[CX];
             uint32_t sl[CX];
             unsigned long long cur[CX];
 #pragma unroll
             for (int j = 0; j < CX; ++j) {                       // every first probe of the record in flight
-                const uint64_t fw = (FW >> (2 * j)) & kmask, rc = (RC >> (rc_sh0 - 2 * j)) & kmask;
-                code[j] = fw < rc ? fw : rc;
+                // k-mer j and its reverse complement, both pushed up to bit 63 (what lies below them is the same junk for the
+                // comparison's purposes: the 2k bits on top decide, a palindrome gives the same code either way)
+                const uint64_t fw = FW << ((rc_sh0 - 2 * j) & 63), rc = RC << (2 * j);        // (j beyond the cap: no such k-mer, any value will do)
+                code[j] = (fw < rc ? fw : rc) >> rc_sh0;
                 sl[j] = mini_slot_hash<WIDE>(code[j]) & smask;
-                cur[j] = j < n ? tab[sl[j]] : 0ull;
+                cur[j] = tab[sl[j]];
             }
-            uint32_t hits = 0;                                   // bit j: settled by the first probe
+            // (ballots of single comparisons, combined as scalars: the ballot of a compound predicate is compiled as
+            // v_cndmask + v_cmp on top of the scalar logic)
+            const unsigned long long in_row_m = __builtin_amdgcn_ballot_w64(row != MINI_ROW_NONE);
+            PG_WLAP(1);                                          // (codes, hashes, first probes back)
+            unsigned long long pm[CX], qm[CX];                   // lanes whose j-th k-mer was settled by the first probe inside a row / is still pending
 #pragma unroll
             for (int j = 0; j < CX; ++j) {
-                bool hit;
+                const unsigned long long act = __builtin_amdgcn_ballot_w64(j < n);
+                unsigned long long hit;
                 if (WIDE) {
-                    hit = j < n && cur[j] == code[j] + 1ull;
-                    if (hit) atomicAdd(&cnts[sl[j]], 1u);
+                    hit = act & __builtin_amdgcn_ballot_w64(cur[j] == code[j] + 1ull);
+                    __hip_atomic_fetch_add(&cnts[sl[j]], __builtin_amdgcn_inverse_ballot_w64(hit) ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    hit = j < n && cur[j] != 0 && (cur[j] >> HASH_CBITS) == code[j];
+                    hit = act & __builtin_amdgcn_ballot_w64(cur[j] != 0) & __builtin_amdgcn_ballot_w64((cur[j] >> HASH_CBITS) == code[j]);
                     // (the count sits in the low 22 bits of the slot's low dword and stops far below 2^22: a 32-bit LDS add is enough)
-                    if (hit && (uint32_t)(cur[j] & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[sl[j]]), 1u);
+                    const unsigned long long room = __builtin_amdgcn_ballot_w64(((uint32_t)cur[j] & HASH_SAT) == 0);
+                    __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(&tab[sl[j]]), __builtin_amdgcn_inverse_ballot_w64(hit & room) ? 1u : 0u,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if (hit) hits |= 1u << j;
+                pm[j] = hit & in_row_m;
+                qm[j] = act & ~hit;
             }
-            unsigned long long pm[CX];
             uint32_t at = 0;
             if (emit_slots) {
                 // positions for the provisional words of the hits: the claim is issued here and used behind the ring pushes
                 uint32_t total = 0;
 #pragma unroll
-                for (int j = 0; j < CX; ++j) {
-                    pm[j] = __ballot(in_row && ((hits >> j) & 1u));
-                    total += (uint32_t)__popcll(pm[j]);
-                }
+                for (int j = 0; j < CX; ++j) total += (uint32_t)__popcll(pm[j]);
                 if (total) at = claim(total);                    // (uniform)
             }
+            PG_WLAP(2);                                          // (hits added, positions claimed)
 #pragma unroll
             for (int j = 0; j < CX; ++j) {
-                const bool pend = j < n && !((hits >> j) & 1u);
-                const unsigned long long mask = __ballot(pend);
+                const unsigned long long mask = qm[j];
                 if (mask) {                                      // (uniform)
-                    if (pend) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
                         const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
                         ring[at] = code[j];
                         if (emit_slots) ring_row[at] = row;
                     }
                     tail += (uint32_t)__popcll(mask);
                     if (tail - head >= 64) {
+#ifdef PG_MINI_STAMPS
+                        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+#endif
                         slow_round(true);
                         head += 64;
+#ifdef PG_MINI_STAMPS
+                        if (lane == 0) atomicAdd(&dbg[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - ts));     // per-wave time in the general insert
+#endif
                     }
                 }
             }
+            PG_WLAP(3);                                          // (ring pushes, general inserts)
             if (emit_slots) {
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
                 // shuffle do not like runs of equal words).  (Deferring these stores to the next iteration's top, behind its
                 // vmcnt wait, changed nothing: 17.33 ms either way.)
 #pragma unroll
                 for (int j = 0; j < CX; ++j) {
-                    if ((pm[j] >> lane) & 1ull) prov_b[at + lanes_below(pm[j])] = (row << lb) | sl[j];
+                    if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) prov_b[at + lanes_below(pm[j])] = (row << lb) | sl[j];
                     at += (uint32_t)__popcll(pm[j]);
                 }
             }
+            PG_WLAP(4);                                          // (the words' stores, waited for)
         }
     };
     count_range(std::integral_constant<int, (CAP > SHORT_MAX ? SHORT_MAX : CAP)>{}, r0, rs);
     count_range(std::integral_constant<int, CAP>{}, rs, r1);
     if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
 #ifdef PG_MINI_STAMPS
-    if (lane == 0) atomicAdd(&dbg[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - st0));     // per-wave end of the count loop
+    if (lane == 0) {
+        atomicAdd(&dbg[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - st0));     // per-wave end of the count loop
+        for (int q = 0; q < 5; ++q) atomicAdd(&dbg[32 + q], wacc[q]);
+    }
 #endif
     PG_STAMP(1);
     if (full) atomicOr(status, 1u);
@@ -833,64 +859,87 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
 #else
 #define PG_LAP(K) do { } while (0)
 #endif
-        // Software pipeline: the next tile's words are fetched while this tile is placed and copied out, and every barrier in
-        // the loop is an LDS-only one (lds_sync) -- the stores of a copy-out, the prefetch and the cursor adds stay in flight
+        // Software pipeline.  Every barrier in the loop is an LDS-only one (lds_sync), and there is ONE wait for global memory per
+        // tile, in front of the copy-out: by then the next tile's words (requested at the top of the tile), the cursor adds
+        // (requested as soon as the ranks, and with them the digits' counts, exist: in front of the scan) and the stores of the
+        // previous tile's copy-out have had the whole tile to come back.  (vmcnt counts loads and stores in one queue: a wait
+        // for the next words at the top of a tile would wait for the copy-out stores issued just before it.)
         uint32_t w[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t i = j * BIG_BLOCK + threadIdx.x;
             w[j] = i < np ? prov_b[i] : 0xffffffffu;
         }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): the first tile's words (no wait for w inside the loop)
         for (uint32_t t0 = 0; t0 < np; t0 += F_TILE) {
             cnt[threadIdx.x] = 0;
-            lds_sync();                                          // (also: every wavefront is done with the previous tile's buffer)
-            PG_LAP(16);
-            uint32_t dr[16];
-            uint32_t live = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t i = t0 + j * BIG_BLOCK + threadIdx.x;
-                const uint32_t b1 = bins16[w[j] & smask];
-                if (i < np && b1 != 0 && b1 != 0xffffu) {
-                    w[j] = ((w[j] >> lb) << vbits) | (b1 - 1u);
-                    const uint32_t d = (w[j] >> sh.dshift) & dmask;
-                    dr[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
-                    live |= 1u << j;
-                }
-            }
-            lds_sync();
-            PG_LAP(17);
-            scan_digits<1024, true>(cnt, start, wave_tot);
-            PG_LAP(18);
-            unsigned long long gpos = 0;
-            {
-                const uint32_t d = threadIdx.x;
-                const uint32_t c = start[d + 1] - start[d];
-                if (c) gpos = sh.goff[(uint64_t)d << sh.gb2] + atomicAdd(&sh.gcur1[d], (unsigned long long)c) - start[d];
-            }
-            uint32_t wn[16];                                     // the next tile's words: in flight until the loop comes round
+            uint32_t wn[16];                                     // the next tile's words: in flight until the wait in front of the copy-out
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const uint32_t i = t0 + F_TILE + j * BIG_BLOCK + threadIdx.x;
                 wn[j] = i < np ? prov_b[i] : 0xffffffffu;
             }
+            lds_sync();                                          // (also: every wavefront is done with the previous tile's buffer)
+            PG_LAP(16);
+            // Every step below is written for all 16 words of the lane at once and without branches around the LDS operations -- 16
+            // reads in flight and one wait, then 16 returning adds in flight and one wait (a word that is not placed adds 0 to some
+            // counter): compiled from a per-word `if`, every word waited twice for a full LDS round trip
+            uint32_t dr[16];
+            uint32_t live = 0;
+            {
+                uint32_t b1[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if ((live >> j) & 1u) buf[start[dr[j] >> 16] + (dr[j] & 0xffffu)] = w[j];
-            gbase[threadIdx.x] = gpos;
+                for (int j = 0; j < 16; ++j) b1[j] = bins16[w[j] & smask];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t i = t0 + j * BIG_BLOCK + threadIdx.x;
+                    const bool ok = i < np && (uint32_t)(b1[j] - 1u) < 0xfffeu;        // a bin: not 0 (slot never filled), not 0xffff (out of range)
+                    w[j] = ((w[j] >> lb) << vbits) | (b1[j] - 1u);
+                    const uint32_t d = (w[j] >> sh.dshift) & dmask;
+                    dr[j] = (d << 16) | __hip_atomic_fetch_add(&cnt[d], ok ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    live |= ok ? 1u << j : 0u;
+                }
+            }
+            lds_sync();
+            PG_LAP(17);
+            // this lane's digit: its words of the tile go to a range of the digit's region claimed with one global add
+            const uint32_t c_mine = cnt[threadIdx.x];
+            unsigned long long g_region = 0, g_claimed = 0;
+            if (c_mine) {
+                g_region = sh.goff[(uint64_t)threadIdx.x << sh.gb2];
+                g_claimed = atomicAdd(&sh.gcur1[threadIdx.x], (unsigned long long)c_mine);
+            }
+            scan_digits<1024, true>(cnt, start, wave_tot);
+            PG_LAP(18);
+            {
+                uint32_t at[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) at[j] = start[dr[j] >> 16] + (dr[j] & 0xffffu);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if ((live >> j) & 1u) buf[at[j]] = w[j];
+            }
+            gbase[threadIdx.x] = g_region + g_claimed - start[threadIdx.x];      // (the wait for global memory; unused for an empty digit)
             lds_sync();
             PG_LAP(19);
             const uint32_t total = start[1024];
-            if (sh.narrow) {                                     // (the group region implies the rows' upper bits)
-                uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
-                for (uint32_t i = threadIdx.x; i < total; i += BIG_BLOCK) {
-                    const uint32_t r = buf[i];
-                    out16[gbase[(r >> sh.dshift) & dmask] + i] = (uint16_t)(r & 0x7fffu);
-                }
-            } else {
-                for (uint32_t i = threadIdx.x; i < total; i += BIG_BLOCK) {
-                    const uint32_t r = buf[i];
-                    sh.words_out[gbase[(r >> sh.dshift) & dmask] + i] = r;
+            // copy-out, four words of the lane at a time (their LDS reads in flight together)
+            for (uint32_t i0 = 0; i0 < total; i0 += 4 * BIG_BLOCK) {
+                uint32_t r[4];
+                unsigned long long g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = buf[i0 + u * BIG_BLOCK + threadIdx.x];            // (< F_TILE: total <= F_TILE = 16 blocks)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BIG_BLOCK + threadIdx.x;
+                if (sh.narrow) {                                 // (the group region implies the rows' upper bits)
+                    uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u * BIG_BLOCK + threadIdx.x < total) out16[g[u]] = (uint16_t)(r[u] & 0x7fffu);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u * BIG_BLOCK + threadIdx.x < total) sh.words_out[g[u]] = r[u];
                 }
             }
 #pragma unroll
@@ -1077,7 +1126,7 @@ int plan_mini(const pg_table *t, int64_t n_words, MiniPlan *p)
     const size_t nb = (size_t)1 << p->bits;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
-    p->header_off = take(256);
+    p->header_off = take(512);
     p->rtot_off = take(((size_t)1 << MINI_MAX_BITS1) * 8);          // plan: records per region
     p->roff_off = take((((size_t)1 << MINI_MAX_BITS1) + 1) * 8);    // plan: where every region starts
     p->off_off = take((nb + 1) * 8);                                // count: where every bucket starts
