@@ -794,7 +794,10 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             PG_WLAP(4);                                          // (the words' stores, waited for)
         }
     };
-    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? SHORT_MAX : CAP)>{}, r0, rs);
+#ifndef PG_SHORT_CX
+#define PG_SHORT_CX SHORT_MAX
+#endif
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs);       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
     count_range(std::integral_constant<int, CAP>{}, rs, r1);
     if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
 #ifdef PG_MINI_STAMPS
