@@ -570,6 +570,9 @@ __device__ __forceinline__ uint32_t mini_lookup_slow(const unsigned long long *t
 #ifndef PG_SHORT_MAX
 #define PG_SHORT_MAX 4
 #endif
+#ifndef PG_DIAG_COUNT
+#define PG_DIAG_COUNT 0                  // diagnostic builds only (results are wrong): 1 = no word stores in the count loop, 2 = no lookup phase, 4 = no copy-out stores in the lookup phase
+#endif
 // where the SLOTS form scatters its (row, bin) words: straight into the row shuffle's group regions (pg_shuffle_ctx)
 struct ShufArgs {
     const unsigned long long *goff;
@@ -787,7 +790,9 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                 // vmcnt wait, changed nothing: 17.33 ms either way.)
 #pragma unroll
                 for (int j = 0; j < CX; ++j) {
+#if !(PG_DIAG_COUNT & 1)
                     if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) prov_b[at + lanes_below(pm[j])] = (row << lb) | sl[j];
+#endif
                     at += (uint32_t)__popcll(pm[j]);
                 }
             }
@@ -814,6 +819,9 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         if (lane == 0 && mine) atomicAdd(&n_lookups, mine);
     }
     __syncthreads();
+#if PG_DIAG_COUNT & 2
+    if (emit_slots) return;                                      // (diagnostic: the count phase alone, with or without its stores)
+#endif
     if (emit_slots) {
         // the packed slice (an empty table needs no clearing: every slot is written), and the table shrinks to 2-byte bins:
         // 0 = slot never filled, 0xffff = bin out of range, else bin + 1.  (Every lane first reads all its slots -- the bins
@@ -934,6 +942,10 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                 for (int u = 0; u < 4; ++u) r[u] = buf[i0 + u * BIG_BLOCK + threadIdx.x];            // (< F_TILE: total <= F_TILE = 16 blocks)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BIG_BLOCK + threadIdx.x;
+#if PG_DIAG_COUNT & 4
+                asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
+                continue;                                        // (diagnostic: everything but the copy-out's stores)
+#endif
                 if (sh.narrow) {                                 // (the group region implies the rows' upper bits)
                     uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
 #pragma unroll
