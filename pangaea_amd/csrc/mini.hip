@@ -298,6 +298,32 @@ __device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start
     sync();
 }
 
+// the same for N digits on BLK <= N threads: thread t owns the digits [t * N / BLK, (t + 1) * N / BLK)
+template <int N, int BLK, bool LDS_ONLY = false>
+__device__ __forceinline__ void scan_digits_blk(const uint32_t *cnt, uint32_t *start, uint32_t *wave_tot)
+{
+    constexpr int PER = N / BLK;
+    static_assert(PER >= 1 && PER * BLK == N, "whole digits per thread");
+    auto sync = [] { if (LDS_ONLY) lds_sync(); else __syncthreads(); };
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { v[q] = cnt[threadIdx.x * PER + q]; sum += v[q]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    sync();
+    uint32_t base = incl - sum;
+    for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) base += wave_tot[wv];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { start[threadIdx.x * PER + q] = base; base += v[q]; }
+    if (threadIdx.x == BLK - 1) start[N] = base;
+    sync();
+}
+
 // ---- A1': stream -> regions
 template <int N1> struct Scatter1Lds {                              // N1 regions: 256, or 512 for a table of 2^16 buckets
     uint64_t bases[STAGE_CAP];
@@ -582,13 +608,15 @@ struct ShufArgs {
     int narrow;                                                  // one-pass shuffle: 2-byte words (row inside its group, bin)
 };
 // LDS of that scatter (bytes from the start of the dynamic area; the table has become 2-byte bins by then)
-constexpr uint32_t F_TILE = 16 * BIG_BLOCK;                  // words per tile: 16 per lane
-constexpr uint32_t F_BUF = 32 * 1024, F_CNT = F_BUF + 4 * F_TILE, F_START = F_CNT + 4 * 1024, F_GBASE = F_START + 4 * 1032,
-                   F_WAVE = F_GBASE + 8 * 1024, F_END = F_WAVE + 64;
+template <int BLK> struct LookupLds {                          // BLK threads: 1024, or 512 (buckets of at most 2^13 slots: two workgroups per CU)
+    static constexpr uint32_t TILE = 16 * BLK;                  // words per tile: 16 per lane
+    static constexpr uint32_t BUF = BLK == 1024 ? 32 * 1024 : 16 * 1024;        // (the 2-byte bins of the table's slots lie in front)
+    static constexpr uint32_t CNT = BUF + 4 * TILE, START = CNT + 4 * 1024, GBASE = START + 4 * 1032, WAVE = GBASE + 8 * 1024, END = WAVE + 64;
+};
 constexpr int SHORT_MAX = PG_SHORT_MAX;                                 // a record with at most this many k-mers is "short"
 
-template <int CAP, bool SLOTS, bool WIDE>
-__global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
+template <int CAP, bool SLOTS, bool WIDE, int BLK>
+__global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
                                                                const unsigned long long *__restrict__ off,
                                                                const unsigned long long *__restrict__ n_short,
                                                                const unsigned long long *__restrict__ kwords, MiniView t,
@@ -597,10 +625,12 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                                                                unsigned long long *__restrict__ wbeg, unsigned long long *__restrict__ emit_end,
                                                                ShufArgs sh, uint32_t *status)
 {
+    using FL = LookupLds<BLK>;
+    constexpr int DPT = 1024 / BLK;                              // row-group digits per thread (1024 of them)
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ uint32_t emitted;
     __shared__ unsigned long long n_lookups, wbase;
-    __shared__ unsigned long long wave_words[COUNT_WAVES];
+    __shared__ unsigned long long wave_words[(BLK / 64)];
     const uint32_t n_slots = 1u << t.log2_bucket;
     const uint32_t smask = n_slots - 1;
     const uint32_t limit = n_slots < MAX_PROBE ? n_slots : MAX_PROBE;
@@ -608,7 +638,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
     uint32_t *const cnts = reinterpret_cast<uint32_t *>(tab + n_slots);             // WIDE: the count plane behind the key plane
     const uint32_t tab_units = WIDE ? n_slots + n_slots / 2 : n_slots;              // 8-byte units of the table
     unsigned long long *ring = tab + tab_units + wave * RING;                        // [RING] codes of this wavefront
-    uint32_t *ring_row = reinterpret_cast<uint32_t *>(tab + tab_units + COUNT_WAVES * RING) + wave * RING;
+    uint32_t *ring_row = reinterpret_cast<uint32_t *>(tab + tab_units + (BLK / 64) * RING) + wave * RING;
     const int k = t.k, lb = t.log2_bucket;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const int rc_sh0 = 2 * (32 - k);
@@ -630,7 +660,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
 #define PG_STAMP(K) do { } while (0)
 #define PG_WLAP(K) do { } while (0)
 #endif
-    for (uint32_t i = threadIdx.x; i < tab_units; i += BIG_BLOCK) tab[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < tab_units; i += BLK) tab[i] = 0ull;
     if (threadIdx.x == 0) { emitted = 0; n_lookups = 0; }
     if (emit_slots) {
         // every occurrence that lies in a row leaves exactly one word: the bucket's word range is claimed before the first word is
@@ -643,7 +673,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             }
         } else {
             unsigned long long mine = 0;
-            for (int64_t i0 = r0 + threadIdx.x; i0 < r1; i0 += BIG_BLOCK) {
+            for (int64_t i0 = r0 + threadIdx.x; i0 < r1; i0 += BLK) {
                 const uint32_t m = meta[i0];
                 if ((m >> META_ROW_SHIFT) != MINI_ROW_NONE) mine += ((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1;
             }
@@ -653,7 +683,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             __syncthreads();
             if (threadIdx.x == 0) {
                 unsigned long long run = 0;
-                for (int w = 0; w < COUNT_WAVES; ++w) run += wave_words[w];
+                for (int w = 0; w < (BLK / 64); ++w) run += wave_words[w];
                 n_lookups = run;
                 wbase = atomicAdd(word_cursor, run);
             }
@@ -696,7 +726,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         int64_t i = ra + (int64_t)wave * 64 + lane;
         uint64_t R = i < rb ? bases[i] : 0ull;
         uint32_t m = i < rb ? meta[i] : 0xffffffffu;
-        for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BIG_BLOCK) {
+        for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BLK) {
             PG_WLAP(0);                                          // (loop top: the record has arrived, last batch's stores are out)
             const bool live = i0 + lane < rb;
             const int n = live ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
@@ -704,7 +734,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             const bool in_row = live && row != MINI_ROW_NONE;
             if (in_row) mine += (unsigned long long)n;
             const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
-            i = i0 + BIG_BLOCK + lane;                           // the next batch's loads fly during this one
+            i = i0 + BLK + lane;                           // the next batch's loads fly during this one
             {
                 // ... provided they are issued BEHIND the wait for this batch's record: the compiler hoists them to the top of the
                 // loop, in front of that wait, and -- the loads being conditional -- the wait is an s_waitcnt vmcnt(0) that then
@@ -829,7 +859,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         uint16_t mybin[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const uint32_t i = q * BIG_BLOCK + threadIdx.x;
+            const uint32_t i = q * BLK + threadIdx.x;
             mybin[q] = 0;
             if (i < n_slots) {
                 const unsigned long long v = tab[i];
@@ -851,7 +881,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         uint16_t *bins16 = reinterpret_cast<uint16_t *>(tab);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const uint32_t i = q * BIG_BLOCK + threadIdx.x;
+            const uint32_t i = q * BLK + threadIdx.x;
             if (i < n_slots) bins16[i] = mybin[q];
         }
         PG_STAMP(2);
@@ -859,9 +889,9 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         // the row shuffle's regions (an LDS multisplit per tile of 16 Ki words, one global cursor add per digit and tile): the
         // final words never make a trip of their own through HBM
         unsigned char *lds = reinterpret_cast<unsigned char *>(tab);
-        uint32_t *buf = reinterpret_cast<uint32_t *>(lds + F_BUF), *cnt = reinterpret_cast<uint32_t *>(lds + F_CNT);
-        uint32_t *start = reinterpret_cast<uint32_t *>(lds + F_START), *wave_tot = reinterpret_cast<uint32_t *>(lds + F_WAVE);
-        unsigned long long *gbase = reinterpret_cast<unsigned long long *>(lds + F_GBASE);
+        uint32_t *buf = reinterpret_cast<uint32_t *>(lds + FL::BUF), *cnt = reinterpret_cast<uint32_t *>(lds + FL::CNT);
+        uint32_t *start = reinterpret_cast<uint32_t *>(lds + FL::START), *wave_tot = reinterpret_cast<uint32_t *>(lds + FL::WAVE);
+        unsigned long long *gbase = reinterpret_cast<unsigned long long *>(lds + FL::GBASE);
         const uint32_t np = (uint32_t)n_lookups;
         const uint32_t dmask = (1u << sh.gb1) - 1u;
 #ifdef PG_MINI_STAMPS
@@ -878,16 +908,17 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         uint32_t w[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t i = j * BIG_BLOCK + threadIdx.x;
+            const uint32_t i = j * BLK + threadIdx.x;
             w[j] = i < np ? prov_b[i] : 0xffffffffu;
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): the first tile's words (no wait for w inside the loop)
-        for (uint32_t t0 = 0; t0 < np; t0 += F_TILE) {
-            cnt[threadIdx.x] = 0;
+        for (uint32_t t0 = 0; t0 < np; t0 += FL::TILE) {
+#pragma unroll
+            for (int q = 0; q < DPT; ++q) cnt[threadIdx.x * DPT + q] = 0;
             uint32_t wn[16];                                     // the next tile's words: in flight until the wait in front of the copy-out
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const uint32_t i = t0 + F_TILE + j * BIG_BLOCK + threadIdx.x;
+                const uint32_t i = t0 + FL::TILE + j * BLK + threadIdx.x;
                 wn[j] = i < np ? prov_b[i] : 0xffffffffu;
             }
             lds_sync();                                          // (also: every wavefront is done with the previous tile's buffer)
@@ -903,7 +934,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                 for (int j = 0; j < 16; ++j) b1[j] = bins16[w[j] & smask];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const uint32_t i = t0 + j * BIG_BLOCK + threadIdx.x;
+                    const uint32_t i = t0 + j * BLK + threadIdx.x;
                     const bool ok = i < np && (uint32_t)(b1[j] - 1u) < 0xfffeu;        // a bin: not 0 (slot never filled), not 0xffff (out of range)
                     w[j] = ((w[j] >> lb) << vbits) | (b1[j] - 1u);
                     const uint32_t d = (w[j] >> sh.dshift) & dmask;
@@ -913,14 +944,18 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
             }
             lds_sync();
             PG_LAP(17);
-            // this lane's digit: its words of the tile go to a range of the digit's region claimed with one global add
-            const uint32_t c_mine = cnt[threadIdx.x];
-            unsigned long long g_region = 0, g_claimed = 0;
-            if (c_mine) {
-                g_region = sh.goff[(uint64_t)threadIdx.x << sh.gb2];
-                g_claimed = atomicAdd(&sh.gcur1[threadIdx.x], (unsigned long long)c_mine);
+            // this lane's digits: their words of the tile go to a range of the digit's region claimed with one global add
+            unsigned long long g_region[DPT], g_claimed[DPT];
+#pragma unroll
+            for (int q = 0; q < DPT; ++q) {
+                const uint32_t d = threadIdx.x * DPT + q, c_mine = cnt[d];
+                g_region[q] = g_claimed[q] = 0;
+                if (c_mine) {
+                    g_region[q] = sh.goff[(uint64_t)d << sh.gb2];
+                    g_claimed[q] = atomicAdd(&sh.gcur1[d], (unsigned long long)c_mine);
+                }
             }
-            scan_digits<1024, true>(cnt, start, wave_tot);
+            scan_digits_blk<1024, BLK, true>(cnt, start, wave_tot);
             PG_LAP(18);
             {
                 uint32_t at[16];
@@ -930,18 +965,20 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                 for (int j = 0; j < 16; ++j)
                     if ((live >> j) & 1u) buf[at[j]] = w[j];
             }
-            gbase[threadIdx.x] = g_region + g_claimed - start[threadIdx.x];      // (the wait for global memory; unused for an empty digit)
+#pragma unroll
+            for (int q = 0; q < DPT; ++q)                         // (the wait for global memory; unused for an empty digit)
+                gbase[threadIdx.x * DPT + q] = g_region[q] + g_claimed[q] - start[threadIdx.x * DPT + q];
             lds_sync();
             PG_LAP(19);
             const uint32_t total = start[1024];
             // copy-out, four words of the lane at a time (their LDS reads in flight together)
-            for (uint32_t i0 = 0; i0 < total; i0 += 4 * BIG_BLOCK) {
+            for (uint32_t i0 = 0; i0 < total; i0 += 4 * BLK) {
                 uint32_t r[4];
                 unsigned long long g[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) r[u] = buf[i0 + u * BIG_BLOCK + threadIdx.x];            // (< F_TILE: total <= F_TILE = 16 blocks)
+                for (int u = 0; u < 4; ++u) r[u] = buf[i0 + u * BLK + threadIdx.x];            // (< FL::TILE: total <= FL::TILE = 16 blocks)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BIG_BLOCK + threadIdx.x;
+                for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BLK + threadIdx.x;
 #if PG_DIAG_COUNT & 4
                 asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
                 continue;                                        // (diagnostic: everything but the copy-out's stores)
@@ -950,11 +987,11 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
                     uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (i0 + u * BIG_BLOCK + threadIdx.x < total) out16[g[u]] = (uint16_t)(r[u] & 0x7fffu);
+                        if (i0 + u * BLK + threadIdx.x < total) out16[g[u]] = (uint16_t)(r[u] & 0x7fffu);
                 } else {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (i0 + u * BIG_BLOCK + threadIdx.x < total) sh.words_out[g[u]] = r[u];
+                        if (i0 + u * BLK + threadIdx.x < total) sh.words_out[g[u]] = r[u];
                 }
             }
 #pragma unroll
@@ -965,7 +1002,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         return;
     }
     // the packed slice (an empty table needs no clearing: every slot is written); then counts -> bins, in place
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BLK) {
         const unsigned long long v = tab[i];
         if (WIDE) {
             const uint32_t c = cnts[i];
@@ -1010,12 +1047,12 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_count_kernel(const uint64_t *_
         int64_t i = r0 + (int64_t)wave * 64 + lane;
         uint64_t R = i < r1 ? bases[i] : 0ull;
         uint32_t m = i < r1 ? meta[i] : 0xffffffffu;
-        for (int64_t i0 = r0 + (int64_t)wave * 64; i0 < r1; i0 += BIG_BLOCK) {
+        for (int64_t i0 = r0 + (int64_t)wave * 64; i0 < r1; i0 += BLK) {
             const bool live = i0 + lane < r1;
             const uint32_t row = m >> META_ROW_SHIFT;
             const int n = live && row != MINI_ROW_NONE ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
             const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
-            i = i0 + BIG_BLOCK + lane;
+            i = i0 + BLK + lane;
             R = i < r1 ? bases[i] : 0ull;
             m = i < r1 ? meta[i] : 0xffffffffu;
             uint64_t code[CAP];
@@ -1345,7 +1382,8 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
             return pg_fail(PG_EINVAL, "pg_mini_count: shuffle workspace of %lld bytes (256-byte aligned), %lld needed", (long long)shuffle_ws_bytes, (long long)sl.total);
     }
     const bool wide = t->kind == PG_TABLE_MINI_WIDE;              // 8-byte keys + 4-byte counts per slot
-    const size_t slice_lds = ((size_t)(wide ? 12 : 8) << t->log2_bucket_slots) + (size_t)COUNT_WAVES * RING * 12;      // table + the wavefronts' rings
+    const size_t table_lds = (size_t)(wide ? 12 : 8) << t->log2_bucket_slots;
+    const size_t slice_lds = table_lds + (size_t)COUNT_WAVES * RING * 12;      // table + the wavefronts' rings (1024 threads)
     if (word_end > word_begin) {
 #define PG_MINI_LAUNCH_SCATTER(N1_)                                                                                          \
         PG_MINI_DISPATCH_W(t->k,                                                                                            \
@@ -1386,19 +1424,25 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
     ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0, 0};
     size_t count_lds = slice_lds;
+    // Buckets of at most 2^13 8-byte slots (64 KiB): 512-thread workgroups, TWO per CU -- one can be in its count loop (VALU, waits)
+    // while the other is in its lookup phase (LDS throughput).  PG_COUNT_BLOCK=1024: the one-workgroup form for such tables too.
+    const char *blk_env = getenv("PG_COUNT_BLOCK");
+    const bool half_block = !wide && window > 0 && mini_slots_form(t, rows) && t->log2_bucket_slots <= 13 && !(blk_env && atoi(blk_env) == 1024);
+    if (half_block) count_lds = table_lds + (size_t)(512 / 64) * RING * 12;
     if (slots_form) {
         // the count kernel scatters its words into the row shuffle's group regions itself: offsets and cursors must be ready
         pg_shuffle_ctx ctx;
         if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx))) return rc;
         sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, ctx.narrow};
         words_a = ctx.words_in;                          // the provisional words wait in the shuffle's input buffer
-        if (count_lds < F_END) count_lds = F_END;
+        const size_t lookup_lds = half_block ? LookupLds<512>::END : LookupLds<BIG_BLOCK>::END;
+        if (count_lds < lookup_lds) count_lds = lookup_lds;
     }
     unsigned long long *emit_end = window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
-#define PG_MINI_LAUNCH_COUNT_(CAP_, SLOTS_, WIDE_, LDS_)                                                                     \
+#define PG_MINI_LAUNCH_COUNT_(CAP_, SLOTS_, WIDE_, BLK_, LDS_)                                                               \
     do {                                                                                                                    \
-        if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_>), LDS_, "pg_mini_count"))) return rc; \
-        hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_>), dim3(nb), dim3(BIG_BLOCK), LDS_, s,                     \
+        if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_>), LDS_, "pg_mini_count"))) return rc; \
+        hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_>), dim3(nb), dim3(BLK_), LDS_, s,                    \
                            (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a),  \
                            (const unsigned long long *)off, n_short, p.bits2 ? (const unsigned long long *)kwords : (const unsigned long long *)nullptr, \
                            mini_view(t), (uint32_t)window, (uint32_t)vsize,                                                 \
@@ -1406,8 +1450,9 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     } while (0)
 #define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \
     do {                                                                                                                    \
-        if (wide) { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, true, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, slice_lds); } \
-        else { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, slice_lds); }    \
+        if (wide) { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, true, BIG_BLOCK, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, BIG_BLOCK, slice_lds); } \
+        else if (half_block) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, 512, count_lds);                                       \
+        else { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, BIG_BLOCK, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, BIG_BLOCK, slice_lds); } \
     } while (0)
     switch (mini_cap(t->k)) {                                          // k-mers per record at most (as the first pass cuts them)
     case 1: case 2: case 3: case 4: PG_MINI_LAUNCH_COUNT(4); break;

@@ -124,6 +124,9 @@ class KmerTable:
         """``mini`` (k <= 21: packed 8-byte slots) or ``miniw`` (22 <= k <= 31: keys + counts planes, as ``wide``)"""
         top = cls.mini_max_log2_bucket(k)
         lb = min(top, log2_slots) if log2_bucket is None else log2_bucket
+        want = os.environ.get("PG_MINI_LOG2_BUCKET")            # tuning / comparison: bucket size of tables whose caller named none
+        if log2_bucket is None and want and cls.mini_applies(k, log2_slots, min(int(want), lb)):
+            lb = min(int(want), lb)
         if not cls.mini_applies(k, log2_slots, lb):
             raise ValueError(f"mini tables need {_lib.MINI_MIN_K} <= k <= {_lib.WIDE_MAX_K} and at most 2^{_lib.MINI_MAX_LOG2_BUCKETS} buckets "
                              f"of at most 2^{top} slots (k {k}, 2^{log2_slots} slots, buckets of 2^{lb})")

@@ -83,6 +83,30 @@ def test_mini_table_and_rows_against_oracle(k, log2_slots, log2_bucket, window, 
     assert torch.equal(abd2, abd) and _same_items(t.items(), otab.items())
 
 
+@pytest.mark.parametrize("log2_slots,log2_bucket", [(24, 13), (24, 9)])
+def test_mini_two_workgroups_per_cu_form_equals_the_one_workgroup_form(log2_slots, log2_bucket, monkeypatch):
+    """buckets of at most 2^13 slots are counted by 512-thread workgroups (two per CU, 1024 row-group digits on 512 threads);
+    PG_COUNT_BLOCK=1024 runs the same table through the 1024-thread form: same table, same rows, and the oracle's"""
+    cfg = synth.SynthConfig(n_pairs=60_000, n_barcodes=700, n_genomes=5, genome_len=60_000, fragment=20_000, sub_rate=0.01, n_rate=0.1, seed=77)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    got = []
+    for form in (None, "1024"):
+        if form:
+            monkeypatch.setenv("PG_COUNT_BLOCK", form)
+        t = kmer.KmerTable.mini_with_slots(21, DEV, log2_slots, log2_bucket)
+        t.count(s, rows=plan, emit=(10, 400))
+        _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
+        got.append((t.items(), abd))
+    assert _same_items(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    otab = oracle.Table(21, threads=4).count(s.decode())
+    assert _same_items(got[0][0], otab.items())
+    text = s.decode()
+    for r in range(0, len(rows), max(1, len(rows) // 12)):
+        assert np.array_equal(got[0][1][r].cpu().numpy(), oracle.abd_row(text[rows.start[r]:rows.end[r]], 21, otab, 10, 400))
+
+
 @pytest.mark.parametrize("k,log2_slots,log2_bucket", [(21, 22, 10), (18, 19, 14), (27, 20, 11), (31, 19, 13)])
 def test_mini_general_lookup_form(k, log2_slots, log2_bucket, monkeypatch):
     """the lookups' general form (records read and probed a second time: what row sets too large for the (row, slot) words
