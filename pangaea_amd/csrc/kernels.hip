@@ -1772,7 +1772,7 @@ struct ShufflePlan {
     size_t emit_off, caps_off, goff_off, gcur1_off, gcur2_off, dhist_off, words_e_off, words_a_off, words_b_off, total;
 };
 
-int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, ShufflePlan *p)
+int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, ShufflePlan *p, int one_pass_bits = WIDE_FAN_BITS)
 {
     if (vsize < 1 || vsize > PG_SHUFFLE_MAX_VSIZE)
         return pg_fail(PG_EINVAL, "the shuffle path needs 1 <= vector size <= %d (got %d)", PG_SHUFFLE_MAX_VSIZE, vsize);
@@ -1783,7 +1783,9 @@ int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, Shuf
     p->gbits = 0;
     while (((int64_t)1 << p->gbits) < p->n_groups) ++p->gbits;
     p->gb1 = p->gbits < 8 ? p->gbits : 8;
-    if (p->gbits == WIDE_FAN_BITS && !getenv("PG_S2_TWO_PASS")) p->gb1 = WIDE_FAN_BITS;    // <= 65536 rows: one pass
+    // one pass up to 2^one_pass_bits row groups: 2^10 (65536 rows) for the scatter kernels of this file; a lookup pass that
+    // scatters by itself may manage more (mini.hip: 2^11)
+    if (p->gbits <= one_pass_bits && !getenv("PG_S2_TWO_PASS")) p->gb1 = p->gbits;
     p->gb2 = p->gbits - p->gb1;
     if (p->gb2 > MAX_FAN_BITS) return pg_fail(PG_EINVAL, "too many rows for two scatter passes");
     p->n_groups_padded = (int64_t)1 << p->gbits;
@@ -2227,10 +2229,10 @@ static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begi
 
 // for the other translation units (pg_internal.h): where the lookup pass of another pipeline leaves its words, and the
 // row shuffle that finishes them
-int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out)
+int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out, int one_pass_bits)
 {
     ShufflePlan sp;
-    int rc = plan_shuffle(cap, n_rows, vsize, 0, &sp);
+    int rc = plan_shuffle(cap, n_rows, vsize, 0, &sp, one_pass_bits);
     if (rc) return rc;
     out->vbits = sp.vbits;
     out->emit_off = sp.emit_off;
@@ -2394,18 +2396,18 @@ static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begi
 }
 
 // the two outer parts for a lookup pass that does the first scatter itself: `ctx` tells it where the group regions are
-int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize)
+int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize, int one_pass_bits)
 {
     ShufflePlan sp;
-    if (plan_shuffle(cap, n_rows, vsize, 0, &sp)) return 0;
+    if (plan_shuffle(cap, n_rows, vsize, 0, &sp, one_pass_bits)) return 0;
     return sp.gb2 == 0 && sp.vbits + GROUP_ROWS_LOG2 <= 15 && !getenv("PG_WIDE_WORDS");
 }
 
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
-                                pg_shuffle_ctx *ctx)
+                                pg_shuffle_ctx *ctx, int one_pass_bits)
 {
     ShufflePlan sp;
-    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp);
+    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits);
     if (rc) return rc;
     if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
     char *ws = (char *)workspace;
@@ -2417,16 +2419,16 @@ int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, voi
     ctx->gb1 = sp.gb1;
     ctx->gb2 = sp.gb2;
     ctx->dshift = sp.vbits + GROUP_ROWS_LOG2 + sp.gb2;
-    ctx->narrow = pg_internal_shuffle_is_narrow(cap, rows->n_rows, vsize);
+    ctx->narrow = pg_internal_shuffle_is_narrow(cap, rows->n_rows, vsize, one_pass_bits);
     if (rows->n_rows == 0) return PG_OK;
     return shuffle_prepare(sp, rows, ws, (hipStream_t)stream);
 }
 
 int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
-                               int narrow)
+                               int narrow, int one_pass_bits)
 {
     ShufflePlan sp;
-    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp);
+    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits);
     if (rc) return rc;
     if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
     if (rows->n_rows == 0) return PG_OK;

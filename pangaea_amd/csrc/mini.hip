@@ -608,14 +608,14 @@ struct ShufArgs {
     int narrow;                                                  // one-pass shuffle: 2-byte words (row inside its group, bin)
 };
 // LDS of that scatter (bytes from the start of the dynamic area; the table has become 2-byte bins by then)
-template <int BLK> struct LookupLds {                          // BLK threads: 1024, or 512 (buckets of at most 2^13 slots: two workgroups per CU)
-    static constexpr uint32_t TILE = 16 * BLK;                  // words per tile: 16 per lane
+template <int BLK, int DIG> struct LookupLds {                 // BLK threads: 1024, or 512 (buckets of at most 2^13 slots: two workgroups per CU);
+    static constexpr uint32_t TILE = 16 * BLK;                  // DIG row-group digits: 1024, or 2048 (65 537 .. 131 072 rows in one pass).  Words per tile: 16 per lane
     static constexpr uint32_t BUF = BLK == 1024 ? 32 * 1024 : 16 * 1024;        // (the 2-byte bins of the table's slots lie in front)
-    static constexpr uint32_t CNT = BUF + 4 * TILE, START = CNT + 4 * 1024, GBASE = START + 4 * 1032, WAVE = GBASE + 8 * 1024, END = WAVE + 64;
+    static constexpr uint32_t CNT = BUF + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
 };
 constexpr int SHORT_MAX = PG_SHORT_MAX;                                 // a record with at most this many k-mers is "short"
 
-template <int CAP, bool SLOTS, bool WIDE, int BLK>
+template <int CAP, bool SLOTS, bool WIDE, int BLK, int DIG>
 __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
                                                                const unsigned long long *__restrict__ off,
                                                                const unsigned long long *__restrict__ n_short,
@@ -625,8 +625,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                                                                unsigned long long *__restrict__ wbeg, unsigned long long *__restrict__ emit_end,
                                                                ShufArgs sh, uint32_t *status)
 {
-    using FL = LookupLds<BLK>;
-    constexpr int DPT = 1024 / BLK;                              // row-group digits per thread (1024 of them)
+    using FL = LookupLds<BLK, DIG>;
+    constexpr int DPT = DIG / BLK;                               // row-group digits per thread
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ uint32_t emitted;
     __shared__ unsigned long long n_lookups, wbase;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     g_claimed[q] = atomicAdd(&sh.gcur1[d], (unsigned long long)c_mine);
                 }
             }
-            scan_digits_blk<1024, BLK, true>(cnt, start, wave_tot);
+            scan_digits_blk<DIG, BLK, true>(cnt, start, wave_tot);
             PG_LAP(18);
             {
                 uint32_t at[16];
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 gbase[threadIdx.x * DPT + q] = g_region[q] + g_claimed[q] - start[threadIdx.x * DPT + q];
             lds_sync();
             PG_LAP(19);
-            const uint32_t total = start[1024];
+            const uint32_t total = start[DIG];
             // copy-out, four words of the lane at a time (their LDS reads in flight together)
             for (uint32_t i0 = 0; i0 < total; i0 += 4 * BLK) {
                 uint32_t r[4];
@@ -1204,6 +1204,8 @@ MiniView mini_view(const pg_table *t)
 }
 
 // the SLOTS form of the lookups needs a row and a slot index in one 32-bit word (PG_MINI_PROBE_TWICE forces the general form)
+// row groups that the count kernel's own scatter reaches in one pass: 2^11 (131 072 rows; 2048 digits in its lookup tiles)
+constexpr int MINI_ONE_PASS_BITS = 11;
 bool mini_slots_form(const pg_table *t, const pg_rows *rows)
 {
     return rows && rows->n_rows > 0 && rows->n_rows < ((int64_t)1 << (32 - t->log2_bucket_slots)) - 1 && !getenv("PG_MINI_PROBE_TWICE");
@@ -1239,10 +1241,12 @@ extern "C" int64_t pg_mini_records_bytes(int64_t n_records)
 extern "C" int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize)
 {
     if (n_words < 0 || n_rows < 0) return pg_fail(PG_EINVAL, "negative size");
-    pg_shuffle_layout sl;
+    // (enough for either form of the row shuffle: the count kernel scattering into up to 2^11 row groups itself, or the general form)
+    pg_shuffle_layout sl, sl1;
     int rc = pg_internal_shuffle_layout(n_words * 32, n_rows, vsize, &sl);
     if (rc) return rc;
-    return (int64_t)sl.total;
+    if ((rc = pg_internal_shuffle_layout(n_words * 32, n_rows, vsize, &sl1, MINI_ONE_PASS_BITS))) return rc;
+    return (int64_t)(sl.total > sl1.total ? sl.total : sl1.total);
 }
 
 // the first-pass kernels are instantiated per window length (registers of the rolling minimum); k > 21 runs the delayed
@@ -1377,7 +1381,8 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         return pg_fail(PG_EHIP, "pg_mini_count: memset failed");
     pg_shuffle_layout sl{0, 0, 0, 0, 0};
     if (window > 0) {
-        if ((rc = pg_internal_shuffle_layout((word_end - word_begin) * 32, rows->n_rows, vsize, &sl))) return rc;
+        if ((rc = pg_internal_shuffle_layout((word_end - word_begin) * 32, rows->n_rows, vsize, &sl, mini_slots_form(t, rows) ? MINI_ONE_PASS_BITS : PG_SHUFFLE_ONE_PASS_BITS)))
+            return rc;
         if ((int64_t)sl.total > shuffle_ws_bytes || (reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0)
             return pg_fail(PG_EINVAL, "pg_mini_count: shuffle workspace of %lld bytes (256-byte aligned), %lld needed", (long long)shuffle_ws_bytes, (long long)sl.total);
     }
@@ -1427,32 +1432,39 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     // Buckets of at most 2^13 8-byte slots (64 KiB): 512-thread workgroups, TWO per CU -- one can be in its count loop (VALU, waits)
     // while the other is in its lookup phase (LDS throughput).  PG_COUNT_BLOCK=1024: the one-workgroup form for such tables too.
     const char *blk_env = getenv("PG_COUNT_BLOCK");
-    const bool half_block = !wide && window > 0 && mini_slots_form(t, rows) && t->log2_bucket_slots <= 13 && !(blk_env && atoi(blk_env) == 1024);
+    const bool many_groups = window > 0 && rows && rows->n_rows > ((int64_t)1 << (PG_SHUFFLE_ONE_PASS_BITS + 6));     // more than 2^10 row groups: 2048 digits
+    const bool half_block = !wide && window > 0 && mini_slots_form(t, rows) && t->log2_bucket_slots <= 13 && !many_groups && !(blk_env && atoi(blk_env) == 1024);
     if (half_block) count_lds = table_lds + (size_t)(512 / 64) * RING * 12;
     if (slots_form) {
         // the count kernel scatters its words into the row shuffle's group regions itself: offsets and cursors must be ready
         pg_shuffle_ctx ctx;
-        if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx))) return rc;
+        if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS))) return rc;
         sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, ctx.narrow};
         words_a = ctx.words_in;                          // the provisional words wait in the shuffle's input buffer
-        const size_t lookup_lds = half_block ? LookupLds<512>::END : LookupLds<BIG_BLOCK>::END;
+        const size_t lookup_lds = half_block ? LookupLds<512, 1024>::END : sh.gb1 > 10 ? LookupLds<BIG_BLOCK, 2048>::END : LookupLds<BIG_BLOCK, 1024>::END;
+        if (sh.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_count: %d first-pass digits of the row shuffle", sh.gb1);
         if (count_lds < lookup_lds) count_lds = lookup_lds;
     }
     unsigned long long *emit_end = window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
-#define PG_MINI_LAUNCH_COUNT_(CAP_, SLOTS_, WIDE_, BLK_, LDS_)                                                               \
+#define PG_MINI_LAUNCH_COUNT_(CAP_, SLOTS_, WIDE_, BLK_, DIG_, LDS_)                                                         \
     do {                                                                                                                    \
-        if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_>), LDS_, "pg_mini_count"))) return rc; \
-        hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_>), dim3(nb), dim3(BLK_), LDS_, s,                    \
+        if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_, DIG_>), LDS_, "pg_mini_count"))) return rc; \
+        hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_, DIG_>), dim3(nb), dim3(BLK_), LDS_, s,              \
                            (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a),  \
                            (const unsigned long long *)off, n_short, p.bits2 ? (const unsigned long long *)kwords : (const unsigned long long *)nullptr, \
                            mini_view(t), (uint32_t)window, (uint32_t)vsize,                                                 \
                            sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                             \
     } while (0)
+#define PG_MINI_LAUNCH_SLOTS(CAP_, WIDE_)                                                                                   \
+    do {                                                                                                                    \
+        if (sh.gb1 > 10) PG_MINI_LAUNCH_COUNT_(CAP_, true, WIDE_, BIG_BLOCK, 2048, count_lds);                               \
+        else PG_MINI_LAUNCH_COUNT_(CAP_, true, WIDE_, BIG_BLOCK, 1024, count_lds);                                           \
+    } while (0)
 #define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \
     do {                                                                                                                    \
-        if (wide) { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, true, BIG_BLOCK, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, BIG_BLOCK, slice_lds); } \
-        else if (half_block) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, 512, count_lds);                                       \
-        else { if (slots_form) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, BIG_BLOCK, count_lds); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, BIG_BLOCK, slice_lds); } \
+        if (wide) { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, true); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, BIG_BLOCK, 1024, slice_lds); } \
+        else if (half_block) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, 512, 1024, count_lds);                                 \
+        else { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, false); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, BIG_BLOCK, 1024, slice_lds); } \
     } while (0)
     switch (mini_cap(t->k)) {                                          // k-mers per record at most (as the first pass cuts them)
     case 1: case 2: case 3: case 4: PG_MINI_LAUNCH_COUNT(4); break;
@@ -1461,6 +1473,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     default: PG_MINI_LAUNCH_COUNT(9); break;        // (cap <= W <= 9: see mini_cap)
     }
 #undef PG_MINI_LAUNCH_COUNT
+#undef PG_MINI_LAUNCH_SLOTS
 #undef PG_MINI_LAUNCH_COUNT_
     return check_launch("pg_mini_count");
 }
@@ -1479,7 +1492,7 @@ extern "C" int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *
     if ((reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: workspace must be 256-byte aligned");
     if (mini_slots_form(t, rows))        // the count kernel has scattered the words by row group already
         return pg_internal_shuffle_finish(n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream,
-                                          pg_internal_shuffle_is_narrow(n_words_counted * 32, rows->n_rows, vsize));
+                                          pg_internal_shuffle_is_narrow(n_words_counted * 32, rows->n_rows, vsize, MINI_ONE_PASS_BITS), MINI_ONE_PASS_BITS);
     const auto *wbeg = (const unsigned long long *)((const char *)plan_ws + p.wbeg_off);
     return pg_internal_shuffle_rows(wbeg, 1 << p.bits, n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
 }

@@ -13,11 +13,14 @@ struct pg_shuffle_layout {
     int vbits;
     size_t emit_off, words_e_off, words_a_off, total;      // words_a: the shuffle's second word buffer, free until it runs
 };
-int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out);
+// one_pass_bits: up to 2^one_pass_bits row groups the first scatter is the only one (PG_SHUFFLE_ONE_PASS_BITS = what the scatter kernels of
+// kernels.hip manage; a lookup pass that scatters by itself may manage more and must then name the same number in every call)
+#define PG_SHUFFLE_ONE_PASS_BITS 10
+int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
 // a lookup pass that scatters its (row, bin) words by row group itself (mini.hip): prepare fills `ctx` and clears the cursors;
 // the pass puts a word whose first digit is d = (word >> dshift) & (2^gb1 - 1) at words_out[goff[d << gb2] + (atomicAdd on
-// gcur1[d])]; finish runs what is left (second pass for more than 2^10 row groups, row histograms).
-// `narrow` (one pass only, i.e. at most 2^10 row groups): a group region already says which 64 rows a word belongs to, so the
+// gcur1[d])]; finish runs what is left (second pass for more than 2^one_pass_bits row groups, row histograms).
+// `narrow` (one pass only, i.e. at most 2^one_pass_bits row groups): a group region already says which 64 rows a word belongs to, so the
 // pass stores 2-byte words -- (row & 63) << vbits | bin, 15 bits at most -- at the same element offsets of words_out taken as
 // uint16_t: half the bytes written by the pass and read by the row histograms.  finish must be told (same flag).
 struct pg_shuffle_ctx {
@@ -27,11 +30,11 @@ struct pg_shuffle_ctx {
     int vbits, gb1, gb2, dshift;
     int narrow;
 };
-int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize);       // what prepare will put into ctx->narrow
+int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);       // what prepare will put into ctx->narrow
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
-                                pg_shuffle_ctx *ctx);
+                                pg_shuffle_ctx *ctx, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
 int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
-                               int narrow);
+                               int narrow, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
 int pg_internal_shuffle_rows(const unsigned long long *in_begin, int nb, int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out,
                              void *workspace, int64_t workspace_bytes, void *stream);
 

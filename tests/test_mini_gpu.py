@@ -311,3 +311,38 @@ def test_mini_more_rows_than_a_slot_word_holds():
     _, want = kmer.features(s, rows, k_tnf=None, table=h, window=1, vsize=8, seg_chars=32)
     assert torch.equal(abd, want) and int(abd.sum()) > 250_000
     assert _same_items(t.items(), h.items())
+
+
+@pytest.mark.parametrize("n_rows", [20_000, 40_000, 100_000, 131_072])
+def test_one_pass_row_shuffle_for_every_row_count_it_reaches(n_rows, monkeypatch):
+    """2^14 < rows <= 2^16 (257 .. 1024 row groups): the (row, bin) words reach their row groups in ONE pass -- in the count kernel
+    of the super-k-mer pipeline and in the key-partitioned pipeline's row scatter alike; up to 2^17 rows (2048 groups: 2048 digits in
+    the count kernel's lookup tiles) in the super-k-mer pipeline.  PG_S2_TWO_PASS=1 is the two-pass form.  All against the lookup
+    kernel; k = 21 and a k > 21 table."""
+    rng = np.random.RandomState(n_rows)
+    n = 4 * n_rows + 200
+    text = bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8))
+    s = ReadStream.from_runs([("x", text)], device=DEV)
+    start = 50 + 4 * np.arange(n_rows, dtype=np.int64)
+    rows = Rows(np.zeros(n_rows, dtype=np.int64), [""] * n_rows, start, start + 4)
+    plan = kmer.Plan(rows, DEV)
+    h = kmer.count_kmers(s, 21, kind="hash")
+    _, want = kmer.features(s, rows, k_tnf=None, table=h, window=1, vsize=8, seg_chars=32)
+    assert int(want.sum()) == n_rows * 4
+    for two_pass in (False, True):
+        if two_pass:
+            monkeypatch.setenv("PG_S2_TWO_PASS", "1")
+        t = kmer.KmerTable.mini_with_slots(21, DEV, 20, 12 if n_rows < 50_000 else 14).count(s, rows=plan, emit=(1, 8))
+        _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=1, vsize=8)
+        assert torch.equal(abd, want)
+        b = kmer.KmerTable.with_slots(21, DEV, 20).count(s, rows=plan, emit=(1, 8))
+        _, abd_b = kmer.features(s, plan, k_tnf=None, table=b, window=1, vsize=8)
+        assert torch.equal(abd_b, want)
+    w = kmer.KmerTable.mini_with_slots(25, DEV, 20, 13).count(s, rows=plan, emit=(1, 8))      # (two-pass form: the switch is still set)
+    _, abd_w = kmer.features(s, plan, k_tnf=None, table=w, window=1, vsize=8)
+    monkeypatch.delenv("PG_S2_TWO_PASS")
+    w1 = kmer.KmerTable.mini_with_slots(25, DEV, 20, 13).count(s, rows=plan, emit=(1, 8))
+    _, abd_w1 = kmer.features(s, plan, k_tnf=None, table=w1, window=1, vsize=8)
+    h25 = kmer.count_kmers(s, 25, kind="wide")
+    _, want25 = kmer.features(s, rows, k_tnf=None, table=h25, window=1, vsize=8, seg_chars=32)
+    assert torch.equal(abd_w, want25) and torch.equal(abd_w1, want25)
