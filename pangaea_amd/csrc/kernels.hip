@@ -1501,10 +1501,14 @@ __global__ __launch_bounds__(BLOCK) void group_caps_kernel(const int64_t *__rest
 template <typename WORD>
 __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restrict__ words, const unsigned long long *__restrict__ goff,
                                                              const unsigned long long *__restrict__ gcnt, int vbits, uint32_t vsize,
-                                                             int64_t n_rows, int32_t *__restrict__ abd_out)
+                                                             int64_t n_rows, int32_t *__restrict__ abd_out, int64_t g0, int split)
 {
+    // split > 1: `split` workgroups share a group -- each takes a slice of its words and ADDS its partial histogram to rows that
+    // were cleared beforehand.  For the groups of a last, mostly empty round of workgroups (one per CU: the histogram fills LDS):
+    // 782 groups on 256 CUs are four rounds of which the last holds 14 groups.
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    const int64_t g = blockIdx.x;
+    const int64_t g = g0 + (int64_t)(blockIdx.x / (unsigned)split);
+    const int part = (int)(blockIdx.x % (unsigned)split);
     const int64_t row0 = g << GROUP_ROWS_LOG2;
     const int64_t rows_here = n_rows - row0 < (1 << GROUP_ROWS_LOG2) ? n_rows - row0 : (1 << GROUP_ROWS_LOG2);
     // rows lie `stride` words apart in LDS, an ODD number: with the matrix's own stride (V = 400 = 16 mod 32) the same bin of all
@@ -1513,7 +1517,12 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restr
     const uint32_t n_bins = (uint32_t)rows_here * stride;
     for (uint32_t i = threadIdx.x; i < n_bins; i += BIG_BLOCK) hist[i] = 0;
     __syncthreads();
-    const int64_t a = (int64_t)goff[g], b = a + (int64_t)gcnt[g];
+    int64_t a = (int64_t)goff[g], b = a + (int64_t)gcnt[g];
+    if (split > 1) {
+        const int64_t len = b - a, lo = a + len * part / split, hi = a + len * (part + 1) / split;
+        a = lo;
+        b = hi;
+    }
     const uint32_t bmask = (1u << vbits) - 1u;
     constexpr uint32_t NONE = (uint32_t)(WORD)~(WORD)0;
     // (one workgroup per CU -- the histogram fills LDS -- so nothing else hides the load latency: the next batch's 8 loads per
@@ -1555,6 +1564,13 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restr
     __syncthreads();
     int32_t *dst = abd_out + row0 * (int64_t)vsize;
     const uint32_t n_out = (uint32_t)rows_here * vsize;
+    if (split > 1) {
+        for (uint32_t i = threadIdx.x; i < n_out; i += BIG_BLOCK) {
+            const uint32_t v = hist[(i / vsize) * stride + i % vsize];
+            if (v) atomicAdd(&dst[i], (int32_t)v);
+        }
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < n_out; i += BIG_BLOCK) dst[i] = (int32_t)hist[(i / vsize) * stride + i % vsize];
 }
 
@@ -2355,13 +2371,38 @@ static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize,
         gcnt = gcur2;
         final_words = words_b;
     }
-    // S3: LDS row histograms -> rows of the matrix
-    if (narrow)
-        hipLaunchKernelGGL(row_hist_kernel<uint16_t>, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, (const uint16_t *)final_words,
-                           (const unsigned long long *)goff, gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
-    else
-        hipLaunchKernelGGL(row_hist_kernel<uint32_t>, dim3((unsigned)sp.n_groups), dim3(BIG_BLOCK), hist_lds, s, final_words,
-                           (const unsigned long long *)goff, gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out);
+    // S3: LDS row histograms -> rows of the matrix.  One workgroup per group and CU: the groups of a last round that would leave most
+    // CUs idle (at most a quarter of them busy) are shared out instead, `split` workgroups each (PG_ROW_HIST_SPLIT="groups,split"
+    // forces a split, "0" none)
+    static int n_cus = 0;
+    if (!n_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0) n_cus = 256;
+    }
+    int64_t n_tail = sp.n_groups > n_cus ? sp.n_groups % n_cus : 0;
+    int split = n_tail > 0 && n_tail <= n_cus / 4 ? (int)std::min<int64_t>(32, n_cus / n_tail) : 1;
+    if (const char *force = getenv("PG_ROW_HIST_SPLIT")) {
+        long long fg = 0, fs = 1;
+        if (sscanf(force, "%lld,%lld", &fg, &fs) == 2 && fg > 0 && fs > 1) { n_tail = std::min<int64_t>(fg, sp.n_groups); split = (int)std::min<long long>(fs, 64); }
+        else { n_tail = 0; split = 1; }
+    }
+    if (split <= 1) n_tail = 0;
+    const int64_t n_main = sp.n_groups - n_tail;
+    if (n_tail) {
+        const int64_t row0 = n_main << GROUP_ROWS_LOG2;
+        if (row0 < rows->n_rows && hipMemsetAsync(abd_out + row0 * (int64_t)vsize, 0, (size_t)(rows->n_rows - row0) * vsize * sizeof(int32_t), s) != hipSuccess)
+            return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
+    }
+#define PG_ROW_HIST(WORD_, WORDS_)                                                                                           \
+    do {                                                                                                                    \
+        if (n_main) hipLaunchKernelGGL(row_hist_kernel<WORD_>, dim3((unsigned)n_main), dim3(BIG_BLOCK), hist_lds, s, WORDS_, (const unsigned long long *)goff, \
+                                       gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out, (int64_t)0, 1);               \
+        if (n_tail) hipLaunchKernelGGL(row_hist_kernel<WORD_>, dim3((unsigned)(n_tail * split)), dim3(BIG_BLOCK), hist_lds, s, WORDS_,                       \
+                                       (const unsigned long long *)goff, gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out, n_main, split); \
+    } while (0)
+    if (narrow) PG_ROW_HIST(uint16_t, (const uint16_t *)final_words);
+    else PG_ROW_HIST(uint32_t, final_words);
+#undef PG_ROW_HIST
     return check_launch("pg_abundance_from_records");
 }
 

@@ -346,3 +346,32 @@ def test_one_pass_row_shuffle_for_every_row_count_it_reaches(n_rows, monkeypatch
     h25 = kmer.count_kmers(s, 25, kind="wide")
     _, want25 = kmer.features(s, rows, k_tnf=None, table=h25, window=1, vsize=8, seg_chars=32)
     assert torch.equal(abd_w, want25) and torch.equal(abd_w1, want25)
+
+
+@pytest.mark.parametrize("force", ["5,7", "40,3", "1000,2"])
+def test_row_histograms_shared_among_workgroups_give_the_same_rows(force, monkeypatch):
+    """the row groups of a last, mostly empty round of workgroups are histogrammed by several workgroups each, which add their
+    partial rows (PG_ROW_HIST_SPLIT forces it at this size): same matrix as one workgroup per group -- 2-byte words (one pass),
+    4-byte words (two passes), both pipelines"""
+    cfg = synth.SynthConfig(n_pairs=30_000, n_barcodes=2500, n_genomes=4, genome_len=50_000, fragment=10_000, sub_rate=0.01, n_rate=0.05, seed=91)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(600)
+    plan = kmer.Plan(rows, DEV)
+    assert len(rows) > 64 * 30
+    got = {}
+    for mode in ("0", force):
+        monkeypatch.setenv("PG_ROW_HIST_SPLIT", mode)
+        for two_pass in (False, True):
+            if two_pass:
+                monkeypatch.setenv("PG_S2_TWO_PASS", "1")
+            else:
+                monkeypatch.delenv("PG_S2_TWO_PASS", raising=False)
+            t = kmer.KmerTable.mini_with_slots(21, DEV, 22, 12).count(s, rows=plan, emit=(10, 400))
+            _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
+            b = kmer.KmerTable.with_slots(21, DEV, 22).count(s, rows=plan, emit=(10, 400))
+            _, abd_b = kmer.features(s, plan, k_tnf=None, table=b, window=10, vsize=400)
+            got[(mode, two_pass)] = (abd, abd_b)
+    ref = got[("0", False)][0]
+    assert int(ref.sum()) > 1_000_000
+    for v in got.values():
+        assert torch.equal(v[0], ref) and torch.equal(v[1], ref)
