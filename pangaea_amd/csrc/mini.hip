@@ -110,25 +110,27 @@ template <int W, bool DELAY, int M, class Emit>
 __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_t ok_row, uint32_t cuts, int k, int off, int bits, int cap, Emit &&emit)
 {
     constexpr uint32_t MMASK = (1u << (2 * M)) - 1u;
-    uint32_t fwm = 0, rcm = 0;
     uint32_t win[W];                                            // win[0] = newest hashed canonical M-mer
     uint32_t dl[DELAY ? MINI_MAX_OFF : 1];                      // dl[i] = window minimum i + 1 characters ago
 #pragma unroll
     for (int i = 0; i < W; ++i) win[i] = 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < (DELAY ? MINI_MAX_OFF : 1); ++i) dl[i] = 0xffffffffu;
-    // pre-roll the characters before the word (DELAY: all 32 of the previous word -- more than the k - 1 that belong to the
-    // word's k-mers, which only completes M-mers earlier); only the M-mers that end at the last W - 1 (+ MINI_MAX_OFF) of them
-    // are wanted in the window
-    constexpr int PRE = W - 1 + (DELAY ? MINI_MAX_OFF : 0);
-    for (int c = DELAY ? 0 : 33 - k; c < 32 - PRE; ++c) {
-        const uint32_t ch = (uint32_t)(x.pw >> (2 * c)) & 3u;
-        fwm = ((fwm << 2) | ch) & MMASK;
-        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (M - 1)));
-    }
-    auto step = [&](uint32_t ch) -> uint32_t {                  // one character in; the minimizer value of the k-mer that ends here
-        fwm = ((fwm << 2) | ch) & MMASK;
-        rcm = (rcm >> 2) | ((ch ^ 2u) << (2 * (M - 1)));
+    // The M-mer that ends at character q of the 64 characters (pw, cw) is cut straight out of them -- its reverse complement out of
+    // the words as they are (oldest character lowest, complemented: ^ 2 per character), the M-mer itself out of the character-
+    // reversed words (newest character lowest) --, at offsets that are constants once the loops below are unrolled: one funnel
+    // shift + one mask each, no rolling state, no pre-roll of the characters in front of the first wanted M-mer.  (The values
+    // are those of the rolling forms fwm = ((fwm << 2) | ch) & MMASK, rcm = (rcm >> 2) | ((ch ^ 2) << 2 (M - 1)).)
+    const uint64_t rlo = rev2_64(x.cw), rhi = rev2_64(x.pw);
+    auto cut = [](uint64_t lo, uint64_t hi, int b) -> uint32_t {                  // 32 bits from bit b of (hi:lo)
+        return b == 0 ? (uint32_t)lo : b < 64 ? (uint32_t)((lo >> b) | (hi << (64 - b))) : (uint32_t)(hi >> (b - 64));
+    };
+    constexpr uint32_t COMPL = 0xAAAAAAAAu & MMASK;
+    constexpr int PRE = W - 1 + (DELAY ? MINI_MAX_OFF : 0);     // M-mers in front of the word that are wanted in the window
+    static_assert(32 - PRE >= M - 1, "the first wanted M-mer lies inside the previous word");
+    auto step = [&](int q) -> uint32_t {                         // the minimizer value of the k-mer that ends at character q
+        const uint32_t fwm = cut(rlo, rhi, 2 * (63 - q)) & MMASK;
+        const uint32_t rcm = (cut(x.pw, x.cw, 2 * (q - (M - 1))) & MMASK) ^ COMPL;
 #pragma unroll
         for (int i = W - 1; i > 0; --i) win[i] = win[i - 1];
         win[0] = mhash(fwm < rcm ? fwm : rcm);
@@ -145,7 +147,7 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
         return use;
     };
 #pragma unroll
-    for (int c = 32 - PRE; c < 32; ++c) step((uint32_t)(x.pw >> (2 * c)) & 3u);
+    for (int c = 32 - PRE; c < 32; ++c) step(c);
     // a k-mer may continue the open record if it is valid, of the same kind (row-counting or not) as its predecessor and
     // no row boundary lies at its last character -- and if it has the same minimizer (its bucket follows from that: the bucket
     // is computed once per record, not per character)
@@ -154,7 +156,7 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
     uint32_t cur_mv = 0;
 #pragma unroll
     for (int p = 0; p < 32; ++p) {
-        const uint32_t mv = step((uint32_t)(x.cw >> (2 * p)) & 3u);
+        const uint32_t mv = step(32 + p);
         const bool v = (ok >> p) & 1u;
         // the open record ends at p - 1 unless this k-mer continues it (a record cannot end before the word starts)
         const bool cont = ((same >> p) & 1u) && n > 0 && mv == cur_mv && n < cap;
