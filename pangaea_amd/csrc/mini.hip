@@ -1079,6 +1079,21 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 pm[j] = __ballot(hit && bin1[j] != BIN_NONE);
                 total += (uint32_t)__popcll(pm[j]);
             }
+#ifdef PG_MINI_STAMPS
+            {   // how many words would be left if equal neighbouring words of a record travelled as one (dbg[10] words, dbg[11] runs)
+                uint32_t nw = 0, nr = 0;
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) {
+                    const bool wj = (pm[j] >> lane) & 1ull;
+                    const bool same = j > 0 && ((pm[j > 0 ? j - 1 : 0] >> lane) & 1ull) && bin1[j] == bin1[j > 0 ? j - 1 : 0];
+                    nw += wj;
+                    nr += wj && !same;
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { nw += __shfl_down(nw, d); nr += __shfl_down(nr, d); }
+                if (lane == 0) { atomicAdd(&dbg[10], (unsigned long long)nw); atomicAdd(&dbg[11], (unsigned long long)nr); }
+            }
+#endif
             if (total) {                                         // (uniform)
                 uint32_t at = 0;
                 if (lane == 0) at = atomicAdd(&emitted, total);
