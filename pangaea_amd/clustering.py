@@ -38,44 +38,108 @@ def _sq_dists(x: torch.Tensor, c: torch.Tensor, x2: torch.Tensor | None = None) 
     return d.clamp_(min=0)
 
 
+def _all_reduce(t: torch.Tensor, group, op=None) -> torch.Tensor:
+    """in-place all-reduce of a small tensor over the ranks that share the rows (gloo cannot take device tensors: staged)"""
+    import torch.distributed as dist
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 @torch.no_grad()
-def lloyd(x: torch.Tensor, centers: torch.Tensor, max_iter: int = 300, tol: float = 1e-4, sample_weight: torch.Tensor | None = None):
+def lloyd(x: torch.Tensor, centers: torch.Tensor, max_iter: int = 300, tol: float = 1e-4, sample_weight: torch.Tensor | None = None,
+          group=None, sharded: bool = False):
     """sklearn ``KMeans(init=centers, n_init=1)`` semantics (algorithm "lloyd"): stop when the labels repeat or the
     squared centre shift falls below tol * mean feature variance; an empty cluster takes the point farthest from its
-    centre.  Returns (labels int64 [N], centers [K,D], inertia float, n_iter)."""
+    centre.  Returns (labels int64 [N], centers [K,D], inertia float, n_iter).
+
+    ``sharded`` (rph_kmeans_.py:152-160 runs this on one matrix): ``x`` holds THIS rank's rows only.  Distances and
+    assignments are local; per iteration one all-reduce sums the [K, D] coordinate sums and the [K] counts of all ranks
+    (K x (D + 1) values: 5 KB for K = 40, D = 32), a second, one-word one agrees on "no label changed anywhere"; the feature
+    variance behind the tolerance, the candidates for an empty cluster and the final inertia are reduced the same way.
+    Every rank ends with the same centres, inertia and iteration count, and with the labels of its own rows."""
     n, dim = x.shape
     k = centers.shape[0]
     w = torch.ones(n, dtype=x.dtype, device=x.device) if sample_weight is None else sample_weight.to(x)
     x2 = (x * x).sum(1, keepdim=True)
-    tol_abs = float(x.var(dim=0, unbiased=False).mean().item()) * tol
+    if sharded:
+        import torch.distributed as dist
+        mom = torch.cat([x.double().sum(0), (x.double() ** 2).sum(0), torch.tensor([float(n)], dtype=torch.float64, device=x.device)])
+        _all_reduce(mom, group)
+        n_all = float(mom[-1].item())
+        mean = mom[:dim] / n_all
+        tol_abs = float((mom[dim:2 * dim] / n_all - mean * mean).clamp(min=0).mean().item()) * tol
+    else:
+        tol_abs = float(x.var(dim=0, unbiased=False).mean().item()) * tol
     centers = centers.to(x).clone()
     labels_old = None
     n_iter = 0
     for n_iter in range(1, max_iter + 1):
         d = _sq_dists(x, centers, x2)
-        mind, labels = d.min(dim=1)
+        mind, labels = (d.min(dim=1) if n else (x.new_zeros(0), torch.zeros(0, dtype=torch.int64, device=x.device)))
         sums = torch.zeros((k, dim), dtype=x.dtype, device=x.device).index_add_(0, labels, x * w[:, None])
         cnt = torch.zeros(k, dtype=x.dtype, device=x.device).index_add_(0, labels, w)
+        if sharded:
+            both = torch.cat([sums, cnt[:, None]], dim=1)
+            _all_reduce(both, group)
+            sums, cnt = both[:, :dim].contiguous(), both[:, dim].contiguous()
         empty = torch.nonzero(cnt == 0).flatten()
-        if empty.numel():                                   # relocate empty clusters to the farthest points
+        if empty.numel() and not sharded:                   # relocate empty clusters to the farthest points
             far = torch.argsort(mind, descending=True)[:empty.numel()]
             for e, f in zip(empty.tolist(), far.tolist()):
                 old = int(labels[f])
                 sums[old] -= x[f] * w[f]; cnt[old] -= w[f]
                 sums[e] = x[f] * w[f]; cnt[e] = w[f]
                 labels[f] = e
+        elif empty.numel():
+            # the same, over all ranks' rows: every rank offers its own farthest points (distance, weight, label, owner, index,
+            # coordinates), the offers are gathered and every rank applies the same relocations to the reduced sums; the owner
+            # of a relocated point also changes that point's label
+            n_e = int(empty.numel())
+            me, world = dist.get_rank(group), dist.get_world_size(group)
+            offer = torch.full((n_e, 5 + dim), -1.0, dtype=torch.float64, device=x.device)
+            take = min(n_e, n)
+            if take:
+                far = torch.argsort(mind, descending=True)[:take]
+                offer[:take, 0] = mind[far].double(); offer[:take, 1] = w[far].double(); offer[:take, 2] = labels[far].double()
+                offer[:take, 3] = float(me); offer[:take, 4] = far.double(); offer[:take, 5:] = x[far].double()
+            offers = torch.zeros((world, n_e, 5 + dim), dtype=torch.float64, device=x.device)
+            offers[me] = offer
+            _all_reduce(offers, group)                      # (a sum over one-hot rank slots = an all-gather, staged like the rest)
+            flat = offers.view(-1, 5 + dim)
+            order = torch.argsort(flat[:, 0], descending=True, stable=True)[:n_e]
+            for e, row in zip(empty.tolist(), flat[order].tolist()):
+                if row[0] < 0:
+                    continue                                # (fewer points than empty clusters)
+                old, wf = int(row[2]), row[1]
+                xf = torch.tensor(row[5:], dtype=x.dtype, device=x.device)
+                sums[old] -= xf * wf; cnt[old] -= wf
+                sums[e] = xf * wf; cnt[e] = wf
+                if int(row[3]) == me:
+                    labels[int(row[4])] = e
         new_centers = sums / cnt.clamp(min=1e-30)[:, None]
         shift = float(((new_centers - centers) ** 2).sum().item())
         centers = new_centers
-        if labels_old is not None and torch.equal(labels, labels_old):
+        same = labels_old is not None and torch.equal(labels, labels_old)
+        if sharded:
+            flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=x.device)
+            same = bool(_all_reduce(flag, group, dist.ReduceOp.MIN).item())
+        if same:
             break
         labels_old = labels
         if shift <= tol_abs:
             break
     d = _sq_dists(x, centers, x2)
-    mind, labels = d.min(dim=1)
-    inertia = float((mind * w).sum().item())
-    return labels, centers, inertia, n_iter
+    mind, labels = (d.min(dim=1) if n else (x.new_zeros(0), torch.zeros(0, dtype=torch.int64, device=x.device)))
+    total = (mind * w).sum().double().reshape(1)
+    if sharded:
+        _all_reduce(total, group)
+    return labels, centers, float(total.item()), n_iter
 
 
 @torch.no_grad()
@@ -216,6 +280,41 @@ def clustering_rph_kmeans(embedding, k):
         return clt.fit_predict(embedding)
 
 
+@torch.no_grad()
+def clustering_rph_kmeans_sharded(mu_local: torch.Tensor, mu_all, k: int, n_init: int = 20, group=None, device=None):
+    """``clustering_rph_kmeans`` with the latent rows sharded over the ranks of ``group``: rank 0, which holds every
+    row anyway (it writes latent.npz), reduces the points and seeds the centres exactly as the one-process fit does (same
+    numpy draws in the same order); the centres are broadcast (K x 32 floats) and the Lloyd iterations over ALL points --
+    rph_kmeans_.py:152-160 -- run on every rank's own rows with the per-iteration all-reduce of ``lloyd(sharded=True)``.
+    Returns the labels of all rows in rank order on rank 0 (int32, as the one-process call), None elsewhere."""
+    import torch.distributed as dist
+    from . import dist as pdist
+    me = dist.get_rank(group)
+    x = torch.as_tensor(mu_local)
+    if device is not None:
+        x = x.to(device)
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.float()
+    clt = None
+    if me == 0:
+        clt = RPHKMeans(n_init=n_init, n_clusters=k, verbose=0, device=x.device)
+        full = torch.as_tensor(mu_all).to(x)
+    best = None
+    for _ in range(n_init):
+        centers0 = clt.init_centers(full)[0].to(x).contiguous() if me == 0 else torch.empty((k, x.shape[1]), dtype=x.dtype, device=x.device)
+        if x.is_cuda and dist.get_backend(group) == "gloo":
+            h = centers0.cpu()
+            dist.broadcast(h, src=0, group=group)
+            centers0.copy_(h)
+        else:
+            dist.broadcast(centers0, src=0, group=group)
+        labels, _, inertia, _ = lloyd(x, centers0, group=group, sharded=True)
+        if best is None or inertia < best[1]:               # (the inertia is the reduced one: the same choice on every rank)
+            best = (labels, inertia)
+    got = pdist.gather_rows(best[0].to(torch.int32)[:, None], dst=0, group=group)
+    return got[:, 0].cpu().numpy().astype(np.int32) if me == 0 else None
+
+
 def write_clusters_tsv(path: str, clusters, barcodes) -> None:
     """``<label>\\t<bc1>,<bc2>,...`` per label in first-seen order (clustering.py:107-112)"""
     cluster2barcodes = defaultdict(list)
@@ -226,9 +325,10 @@ def write_clusters_tsv(path: str, clusters, barcodes) -> None:
             tsv.write("{}\t{}\n".format(cluster_id, ",".join(cluster2barcodes[cluster_id])))
 
 
-def cluster_barcode_reads(args, model_path, cluster_path, script_path):
+def cluster_barcode_reads(args, model_path, cluster_path, script_path, clusters=None):
     """step 3 of pangaea.py: latent.npz/barcodes.npz -> clusters.npz, clusters.tsv, cluster_bin<label>.{fq,barcode},
-    clustering_finished -- the on-disk bin layout the unchanged reassembly stage reads (bin_assembly.sh:18)."""
+    clustering_finished -- the on-disk bin layout the unchanged reassembly stage reads (bin_assembly.sh:18).
+    ``clusters``: labels already computed for the rows of latent.npz (the sharded Lloyd of a multi-rank run)."""
     from .binwriter import extract_reads
     output_npz = os.path.join(cluster_path, "clusters.npz")
     output_tsv = os.path.join(cluster_path, "clusters.tsv")
@@ -236,7 +336,13 @@ def cluster_barcode_reads(args, model_path, cluster_path, script_path):
     barcodes_path = os.path.join(model_path, "barcodes.npz")
     if not os.path.isfile(embedding_path) or not os.path.isfile(barcodes_path):
         raise FileNotFoundError(f"{embedding_path} or {barcodes_path} not found")
-    if not os.path.isfile(output_tsv):
+    if not os.path.isfile(output_tsv) and clusters is not None:
+        barcodes = np.load(barcodes_path)["arr_0"]
+        assert len(clusters) == len(barcodes)
+        np.savez(output_npz, clusters)
+        logging.info("saving clustering tsv")
+        write_clusters_tsv(output_tsv, clusters, barcodes)
+    elif not os.path.isfile(output_tsv):
         embedding = np.load(embedding_path)["arr_0"]
         barcodes = np.load(barcodes_path)["arr_0"]
         if args.clusters:

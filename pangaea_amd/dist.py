@@ -26,6 +26,54 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+# ---- the control plane.  A rank that waits for ANOTHER rank's host-side work (rank 0 training the VAE, writing the cache
+# files, running the assemblers) must not wait inside a collective of the data group: RCCL's watchdog aborts the process
+# once a collective has been pending for the group's timeout (10 minutes by default), and torchrun then tears the working
+# rank down with it.  Such waits -- and the tiny host-side decisions next to them -- go over a gloo group of their own whose
+# timeout is a month; the data group only ever carries collectives that every rank enters at about the same time.
+_CONTROL = None
+CONTROL_TIMEOUT_DAYS = 30
+
+
+def control_group():
+    """the gloo control group over all ranks (created on first use: EVERY rank must make that first call at the same point of
+    the program, which ``pangaea.run`` does right after ``init_process_group``); None outside a multi-rank run"""
+    global _CONTROL
+    if not is_distributed():
+        return None
+    if _CONTROL is None:
+        import datetime
+        _CONTROL = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=CONTROL_TIMEOUT_DAYS))
+    return _CONTROL
+
+
+def agreed(value, src: int = 0):
+    """rank ``src``'s value on every rank (control plane: may be waited for as long as ``src`` takes to get here)"""
+    if not is_distributed():
+        return value
+    box = [value]
+    dist.broadcast_object_list(box, src=src, group=control_group())
+    return box[0]
+
+
+def wait_for_all() -> None:
+    """a barrier on the control plane: safe to sit in while another rank does minutes or hours of host work"""
+    if is_distributed():
+        dist.barrier(group=control_group())
+
+
+def leave() -> None:
+    """behind the LAST collective of a run: every rank meets once on the control plane and the process groups are destroyed.
+    Ranks without further work return to their caller and exit; the one that goes on (file writing, bin extraction, the
+    assembly stage) does so without a group -- nobody is left waiting in a collective for it."""
+    global _CONTROL
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1:
+            dist.barrier(group=control_group())
+        _CONTROL = None
+        dist.destroy_process_group()
+
+
 def balanced_run_ranges(run_off: np.ndarray, world: int) -> list[tuple[int, int]]:
     """contiguous run ranges [(first, last+1)] per rank with roughly equal character counts; ranges tile all runs"""
     n = len(run_off) - 1
@@ -160,7 +208,10 @@ def gather_pairs(local: torch.Tensor, group=None) -> list[torch.Tensor]:
 
 def everyone(flag: bool, group=None) -> bool:
     """the same answer on every rank: did ALL ranks say yes?  (decisions that select between collectives -- or between doing
-    one and not -- must not be taken rank by rank)"""
+    one and not -- must not be taken rank by rank).  ``group=None``: the control plane when there is one, so that the
+    question may be asked right behind a long stretch of one rank's host work."""
+    if group is None and _CONTROL is not None:
+        group = _CONTROL
     t = torch.tensor([1 if flag else 0], dtype=torch.int32)
     if dist.get_backend(group) == "nccl":
         t = t.to(torch.device("cuda", torch.cuda.current_device()))

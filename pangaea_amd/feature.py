@@ -243,7 +243,8 @@ class Feature:
             with open(os.path.join(self.feature_dir, "feature_finished"), "w") as f:
                 f.write("feature finished")
             result = (readnames1, abundance, tnf)
-        torch.distributed.barrier()                  # the caches and the marker are complete before anybody moves on
+        pdist.wait_for_all()                         # the caches and the marker are complete before anybody moves on (control plane:
+                                                     # writing them can take rank 0 longer than a data collective may wait)
         if self.rank != 0:
             if self.local is None:
                 return np.zeros(0, dtype=object), np.zeros((0, int(self.vs)), dtype=np.int64), np.zeros((0, 0), dtype=np.int64)

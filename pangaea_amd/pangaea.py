@@ -73,46 +73,58 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
-def _encode_sharded(args, feat, vae, model_path) -> None:
+def _encode_sharded(args, feat, vae, model_path):
     """step 2's encode on several ranks: the rows never left the rank that made them, so every rank normalises
     and encodes its own block with a replica of the trained network (2.2 MB of weights travel, not gigabytes of count
-    matrices), and only ``mu`` [N, 32] and the names are gathered on rank 0, which writes the reference's files"""
+    matrices), and only ``mu`` [N, 32] and the names are gathered on rank 0, which writes the reference's files.
+    Returns (this rank's mu, all ranks' mu on rank 0 / None elsewhere).  The weights come over the control plane: the other
+    ranks wait here for as long as rank 0 trains."""
     import torch.distributed as dist
     from . import dist as pdist
     from .data import Data
     from .models.VAENET import VAENET
     rank = dist.get_rank()
     names, tnf, abd = feat.local
+    state = None
     if rank == 0:
         state = {k: v.cpu() for k, v in torch.load(os.path.join(model_path, "train_model.pk"), map_location="cpu").items()}
-        box = [state]
     else:
-        box = [None]
         vae = VAENET(abd_dim=abd.shape[1], tnf_dim=tnf.shape[1], latent_size=args.latent_dim, num_classes=args.clusters,
                      epochs=args.epochs, cuda=torch.cuda.is_available(), num_gpus=args.num_gpus, lr=args.lr, dropout=args.dropout,
                      alpha=args.weight_alpha, w_kl=args.weight_kl, weight_decay=args.weight_decay)
-    dist.broadcast_object_list(box, src=0)
-    vae.network.load_state_dict(box[0])
+    state = pdist.agreed(state)
+    vae.network.load_state_dict(state)
     vae.network.eval()
     mu = vae.encode(Data(np.asarray(names, dtype=object), abd, tnf))
     all_mu = pdist.gather_rows(mu, dst=0)
     gathered = [None] * dist.get_world_size() if rank == 0 else None
-    dist.gather_object(list(names), gathered, dst=0)
+    dist.gather_object(list(names), gathered, dst=0, group=pdist.control_group())
     if rank == 0:
         VAENET.write_latent(model_path, all_mu.cpu().numpy(), [n for part in gathered for n in part])
+    return mu, all_mu
 
 
 def run(args, script_path):
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    from . import dist as pdist
     if world > 1 and not torch.distributed.is_initialized():
+        import datetime
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
-        torch.distributed.init_process_group(os.environ.get("PANGAEA_DIST_BACKEND", "nccl"))
+        # (PANGAEA_DIST_TIMEOUT_S: the data group's collective timeout -- RCCL's default is 10 minutes; tests shorten it to show
+        # that no rank waits for another rank's host work inside a data collective)
+        timeout = os.environ.get("PANGAEA_DIST_TIMEOUT_S")
+        kw = {"timeout": datetime.timedelta(seconds=float(timeout))} if timeout else {}
+        torch.distributed.init_process_group(os.environ.get("PANGAEA_DIST_BACKEND", "nccl"), **kw)
+    pdist.control_group()               # (every rank, here: waits for rank 0's host-side work go over this group)
     try:
         _run(args, script_path)
-    finally:
-        if torch.distributed.is_initialized():      # every rank leaves together, and leaves the group behind it
-            torch.distributed.barrier()
+    except BaseException:
+        # a rank that fails leaves at once (no barrier: its peers may be anywhere; the launcher ends them)
+        if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
+        raise
+    finally:
+        pdist.leave()                   # (a no-op when _run has left already, as it does behind its last collective)
 
 
 def _run(args, script_path):
@@ -138,13 +150,7 @@ def _run(args, script_path):
     read_specify = abundance = tnf = None
     feat = None
 
-    def agreed(flag: bool) -> bool:
-        """rank 0's reading of the output directory decides for everybody (the steps' collectives need all ranks)"""
-        if not multi:
-            return flag
-        box = [flag]
-        torch.distributed.broadcast_object_list(box, src=0)
-        return bool(box[0])
+    agreed = pdist.agreed               # rank 0's reading of the output directory decides for everybody (control plane)
 
     # step 1: feature extraction (every rank takes part: its own runs, one table exchange; rank 0 writes the caches)
     if not check_steps_required(args.steps, "1"):
@@ -159,6 +165,7 @@ def _run(args, script_path):
         sys.exit()
 
     # step 2: training (rank 0: the loop is small and sequential) + encode (every rank, its own rows)
+    mu_local = mu_all = None
     if not check_steps_required(args.steps, "2"):
         logging.info("skip step 2: training")
     elif agreed(check_steps_finish(args, "2")):
@@ -181,7 +188,20 @@ def _run(args, script_path):
                          alpha=args.weight_alpha, w_kl=args.weight_kl, weight_decay=args.weight_decay)
             vae.train(train, test, original, model_path, args.patience, encode=not sharded)
         if sharded:
-            _encode_sharded(args, feat, vae, model_path)
+            mu_local, mu_all = _encode_sharded(args, feat, vae, model_path)
+
+    # step 3, its collective part: with the latent rows still sharded, the Lloyd iterations of RPH-KMeans run on every rank's
+    # own rows (an all-reduce of the [k, 32] sums and [k] counts per iteration); rank 0 reduces the points and seeds
+    labels = None
+    do3 = check_steps_required(args.steps, "3") and not agreed(check_steps_finish(args, "3"))
+    if multi and do3 and pdist.everyone(mu_local is not None and bool(args.clusters)
+                                         and (not rank0 or not os.path.isfile(os.path.join(cluster_path, "clusters.tsv")))):
+        from .clustering import clustering_rph_kmeans_sharded
+        logging.info("start clustering (Lloyd iterations on every rank's rows)")
+        labels = clustering_rph_kmeans_sharded(mu_local, mu_all, args.clusters)
+    # the last collective is behind us: every rank leaves the group, rank 0 goes on alone (bin extraction and the assembly
+    # stage take minutes to hours of host time -- nobody may wait in a collective for them)
+    pdist.leave()
     if not rank0:
         return
 
@@ -194,7 +214,7 @@ def _run(args, script_path):
         logging.info("start clustering")
         os.makedirs(cluster_path, exist_ok=True)
         if have_reads:
-            cluster_barcode_reads(args, model_path, cluster_path, args.reference_src or script_path)
+            cluster_barcode_reads(args, model_path, cluster_path, args.reference_src or script_path, clusters=labels)
         else:
             logging.info("Please provide one or two input file(s):-1 and -2 for pair-end linked reads; -lr as long reads; -i for interleaved linked reads.")
             sys.exit()

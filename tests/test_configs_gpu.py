@@ -6,8 +6,10 @@ config 2   10 M pairs / 50 k barcodes / k = 21: the fused count + lookup paths (
 mid scale  2 M pairs: the WHOLE table and 25+ rows of both matrices == the oracle, for both fused pipelines
 config 3   one GPU's share (25 M pairs / 125 k barcodes): more than 65 536 rows -> the two-pass row shuffle
 config 4   stLFR headers, 1 M pairs written as FASTQ and taken through ``Feature`` (ingest, header grammar, caches)
-config 5   hybrid mode: long-read names as barcodes, Poisson(100) pairs each, far more than 65 536 rows, encode +
-           ``clustering_rph_kmeans(-c 40)``
+config 5   hybrid mode: long-read names as barcodes, Poisson(100) pairs each, encode + ``clustering_rph_kmeans(-c 40)``:
+           8 M pairs (78 k ragged rows: the count kernel's one-pass row scatter with 2048 digits) and one GPU's share of the
+           real configuration, 25 M pairs (~250 k ragged rows: 4-byte words, two-pass row shuffle, the (row, slot) word
+           within 5 % of its 2^18-row limit)
 Integer matrices bit for bit (count_tnf.cpp:78-113, count_kmer.cpp:55-108, jellyfish count -C of feature.py:94).
 """
 import argparse
@@ -203,6 +205,46 @@ def test_config5_hybrid_rows_encode_and_rph_kmeans():
     d = Data(np.array(rows.names, dtype=object), abd, tnf, device=torch.device(DEV))
     oa, ot, ow = oracle.data_normalize(abd[:512].cpu().numpy(), tnf[:512].cpu().numpy())
     assert np.array_equal(d.abd[:512], oa) and np.array_equal(d.tnf[:512], ot) and np.array_equal(d.weights[:512], ow)
+    vae = VAENET(400, 136, 32, 40, 1, True, 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+    vae.network.eval()
+    mu = vae.encode(d)
+    assert tuple(mu.shape) == (n_rows, 32) and bool(torch.isfinite(mu).all())
+    labels = clustering_rph_kmeans(mu.cpu().numpy(), 40)
+    assert labels.shape == (n_rows,) and 1 < len(np.unique(labels)) <= 40 and labels.min() >= 0
+
+
+def test_config5_one_gpu_share_hybrid_rows_encode_and_rph_kmeans():
+    """one GPU's share of BASELINE config 5 (200 M short pairs + 2 M long-read barcodes over 8 GPUs): 25 M pairs, Poisson(100)
+    pairs per long read -> ~250 k ragged rows.  That is past the 131 072 rows the count kernel scatters in one pass (so: 4-byte
+    (row, bin) words and the row shuffle's second pass) and just inside the 2^18 - 1 rows a (row, slot) provisional word can
+    name with 2^14-slot buckets.  The shipped path (count_kmers with emit), table total = valid 21-mers, shuffle == lookup rows
+    on a slice, TNF and abundance spot rows == the oracle (exact global counts of the rows' k-mers), then Data -> encode ->
+    RPH-KMeans -c 40 (assign_barcodes.cpp:156, clustering.py:14-19, count_kmer.cpp:55-108)."""
+    from pangaea_amd.clustering import clustering_rph_kmeans
+    from pangaea_amd.data import Data
+    from pangaea_amd.models.VAENET import VAENET
+    cfg = synth.SynthConfig(n_pairs=25_000_000, n_barcodes=1, poisson_mean=100.0, seed=78)
+    s = synth.generate(cfg, device=DEV, chunk_pairs=1 << 17, with_names=False)
+    rows = s.rows(2000)
+    n_rows = len(rows)
+    assert 131_072 < n_rows < (1 << 18) - 1 and len(set(np.diff(rows.start[:5000]).tolist())) > 50       # ragged, two-pass, slot form
+    plan = kmer.Plan(rows, DEV)
+    t = kmer.count_kmers(s, 21, rows=plan, emit=(10, 400))
+    assert t.kind == "mini" and t._emitted == (10, 400)
+    tnf, abd = kmer.features(s, plan, k_tnf=4, table=t, window=10, vsize=400)
+    assert int((t.compact() & ((1 << 22) - 1)).sum().item()) == _kmer_ends(s.valid, 21)
+    for lo in (0, 131_000, n_rows - 400):                          # either side of the one-pass limit, and the last rows
+        pick = np.arange(lo, lo + 400)
+        sub = Rows(pick, [rows.names[i] for i in pick], rows.start[pick], rows.end[pick])
+        tnf_s, abd_s = kmer.features(s, sub, k_tnf=4, table=t, window=10, vsize=400)
+        assert torch.equal(abd_s, abd[lo:lo + 400]) and torch.equal(tnf_s, tnf[lo:lo + 400])
+    text = _text(s)
+    _spot_rows_equal_oracle(s, rows, text, tnf, abd, [0, 65_535, 131_071, 131_072, n_rows // 2 + 1, n_rows - 1])
+    del text
+    torch.manual_seed(2021)
+    d = Data(np.array(rows.names, dtype=object), abd, tnf, device=torch.device(DEV))
+    oa, ot, ow = oracle.data_normalize(abd[-512:].cpu().numpy(), tnf[-512:].cpu().numpy())
+    assert np.array_equal(d.abd[-512:], oa) and np.array_equal(d.tnf[-512:], ot) and np.array_equal(d.weights[-512:], ow)
     vae = VAENET(400, 136, 32, 40, 1, True, 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
     vae.network.eval()
     mu = vae.encode(d)

@@ -327,9 +327,17 @@ def test_rows_stay_sharded_and_the_encode_is_replicated(world, tmp_path):
 
 
 def _pipeline_worker(rank, world, port, fq, out):
+    # the data group's collectives time out after 8 s, and rank 0 is slowed down by 10 s in its training and again in its tail
+    # (bin extraction): the other rank waits for the weights on the control plane and is gone before the tail starts
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                      PANGAEA_DIST_BACKEND="gloo")
-    from pangaea_amd import pangaea
+                      PANGAEA_DIST_BACKEND="gloo", PANGAEA_DIST_TIMEOUT_S="8")
+    import time
+    from pangaea_amd import clustering, pangaea
+    from pangaea_amd.models.VAENET import VAENET
+    train, tail = VAENET.train, clustering.cluster_barcode_reads
+    if rank == 0:
+        VAENET.train = lambda self, *a, **kw: (time.sleep(10), train(self, *a, **kw))[1]
+        clustering.cluster_barcode_reads = lambda *a, **kw: (time.sleep(10), tail(*a, **kw))[1]
     pangaea.main(["-i", fq, "-o", out, "-c", "4", "-k", "21", "-l", "2000", "-e", "2", "-b", "32", "-st", "1,2,3", "-t", "2"])
     assert not dist.is_initialized()                    # every rank left the group behind
 
@@ -371,3 +379,78 @@ def test_two_rank_pipeline_on_a_shared_output_directory(tmp_path):
     assert np.abs(latent - whole).max() <= 1e-5 * np.abs(whole).max()
     for rel in ("3.clustering/clusters.tsv", "3.clustering/clustering_finished", "2.vae/model_finished", "log"):
         assert os.path.isfile(os.path.join(out2, rel)), rel
+
+
+# ------------------------------------------------------------------ sharded Lloyd (last bullet) and the control plane
+
+
+def _blobs(n=3000, k=6, dim=32, seed=3):
+    rs = np.random.RandomState(seed)
+    centres = rs.normal(0, 6.0, size=(k, dim))
+    which = rs.randint(0, k, size=n)
+    return (centres[which] + rs.normal(0, 0.5, size=(n, dim))).astype(np.float32), which
+
+
+def _lloyd_worker(rank, world, port):
+    from pangaea_amd.clustering import RPHKMeans, clustering_rph_kmeans_sharded, lloyd
+    _init(rank, world, port)
+    try:
+        x, _ = _blobs()
+        cut = [0, 1100, 3000] if world == 2 else [0, 1100, 1100, 3000]              # (three ranks: one of them holds no row)
+        mine = torch.from_numpy(x[cut[rank]:cut[rank + 1]])
+        # (a) Lloyd from given centres, one of them so far out that its cluster starts empty: the relocation step too
+        rs = np.random.RandomState(5)
+        c0 = torch.from_numpy(np.concatenate([x[rs.choice(len(x), 5, replace=False)], np.full((1, 32), 1e3, dtype=np.float32)]))
+        lab, cen, inertia, n_iter = lloyd(mine, c0, sharded=True)
+        want_lab, want_cen, want_inertia, want_iter = lloyd(torch.from_numpy(x), c0)
+        assert torch.equal(lab, want_lab[cut[rank]:cut[rank + 1]]) and n_iter == want_iter
+        assert torch.allclose(cen, want_cen, rtol=1e-4, atol=1e-4) and abs(inertia - want_inertia) <= 1e-4 * want_inertia
+        # (b) the whole RPH-KMeans call: rank 0 reduces and seeds, every rank iterates on its rows: the one-process partition
+        np.random.seed(11)
+        labels = clustering_rph_kmeans_sharded(mine, x if rank == 0 else None, 6, n_init=3, device="cpu")
+        if rank == 0:
+            np.random.seed(11)
+            want = RPHKMeans(n_init=3, n_clusters=6, device="cpu").fit_predict(x)
+            assert labels.dtype == np.int32 and np.array_equal(labels, want)
+        else:
+            assert labels is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lloyd_gives_the_one_process_partition(world):
+    _spawn(_lloyd_worker, world)
+
+
+def _control_worker(rank, world, port):
+    """the data group's timeout is 2 s; rank 0 is busy for 5 s (training, cache files, assembly in the real run): the other ranks
+    wait for it on the control plane and nothing times out"""
+    import datetime
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=2))
+    try:
+        assert pdist.control_group() is not None
+        t0 = time.time()
+        if rank == 0:
+            time.sleep(5)
+        got = pdist.agreed({"weights": 42} if rank == 0 else None)
+        assert got == {"weights": 42} and (rank == 0 or time.time() - t0 > 4)
+        if rank == 0:
+            time.sleep(3)
+        assert pdist.everyone(True)                 # (routed over the control plane once it exists)
+        if rank == 0:
+            time.sleep(3)
+        pdist.wait_for_all()
+        t = torch.ones(1)
+        dist.all_reduce(t)                          # the data group still works: nothing was left pending on it
+        assert int(t.item()) == world
+    finally:
+        pdist.leave()
+    assert not dist.is_initialized() and pdist._CONTROL is None
+
+
+def test_waits_for_rank0_use_the_control_plane():
+    _spawn(_control_worker, 2)
