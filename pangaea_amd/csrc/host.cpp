@@ -773,12 +773,50 @@ int open_plain(const char *path, int &fd, size_t &size, bool &plain)
     return PG_OK;
 }
 
+// how many bytes of inflated text one gzip input may park in memory (an anonymous memfd is shmem: it has no quota of its own for
+// write() to fail against -- past the machine's or the cgroup's limit the kernel kills the process).  Half of what is
+// available right now, shared by the files inflated side by side; PG_INFLATE_MAX_BYTES overrides (0 = never inflate to memory).
+static uint64_t read_u64_file(const char *path)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return UINT64_MAX;
+    char buf[64] = {0};
+    const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!ok || buf[0] < '0' || buf[0] > '9') return UINT64_MAX;          // ("max": no limit)
+    return strtoull(buf, nullptr, 10);
+}
+uint64_t inflate_budget(int n_files)
+{
+    if (const char *e = getenv("PG_INFLATE_MAX_BYTES")) return strtoull(e, nullptr, 10);
+    uint64_t avail = UINT64_MAX;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            unsigned long long kb;
+            if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = (uint64_t)kb << 10; break; }
+        }
+        fclose(f);
+    }
+    // the cgroup's headroom (v2, then v1), where there is a limit
+    uint64_t lim = read_u64_file("/sys/fs/cgroup/memory.max"), cur = read_u64_file("/sys/fs/cgroup/memory.current");
+    if (lim == UINT64_MAX) { lim = read_u64_file("/sys/fs/cgroup/memory/memory.limit_in_bytes"); cur = read_u64_file("/sys/fs/cgroup/memory/memory.usage_in_bytes"); }
+    if (lim != UINT64_MAX && cur != UINT64_MAX && lim < ((uint64_t)1 << 60)) avail = std::min(avail, lim > cur ? lim - cur : 0);
+    if (avail == UINT64_MAX) return (uint64_t)1 << 30;                    // nothing known: a cautious gigabyte
+    return avail / 2 / (uint64_t)(n_files > 0 ? n_files : 1);
+}
+
 // a gzip file for the threaded readers: inflated (one stream = one thread, as pigz -dc in feature.py:76-91) into an anonymous
 // in-memory file, which pread serves like any other -- the parse that follows is then threaded instead of serial.  fd < 0
-// on return (with PG_OK) means "not worth it / not possible here": the caller takes the serial path.
-int inflate_to_memfd(const char *path, int &fd, size_t &size)
+// on return (with PG_OK) means "not worth it / not possible here": the caller takes the serial path, which streams the file
+// through zlib as the reference's pigz pipe does and holds nothing but the packed stream.  `budget`: bytes of text this file
+// may park in memory (inflate_budget); a file whose compressed size alone says it will not fit (FASTQ deflates to a quarter
+// or less) is not started, one that grows past the budget is dropped.
+int inflate_to_memfd(const char *path, int &fd, size_t &size, uint64_t budget)
 {
     fd = -1; size = 0;
+    struct stat st;
+    if (stat(path, &st) == 0 && (uint64_t)st.st_size * 2 > budget) return PG_OK;
     gzFile f = gzopen(path, "rb");
     if (!f) return pg_fail(PG_EIO, "cannot open %s", path);
     gzbuffer(f, 1 << 22);
@@ -789,10 +827,11 @@ int inflate_to_memfd(const char *path, int &fd, size_t &size)
         const int got = gzread(f, buf.data(), (unsigned)buf.size());
         if (got < 0) { gzclose(f); close(m); return pg_fail(PG_EIO, "read error in %s", path); }
         if (got == 0) break;
+        if ((uint64_t)size + (uint64_t)got > budget) { gzclose(f); close(m); size = 0; return PG_OK; }    // too big to park: serial path
         size_t done = 0;
         while (done < (size_t)got) {
             const ssize_t w = write(m, buf.data() + done, (size_t)got - done);
-            if (w <= 0) { gzclose(f); close(m); return PG_OK; }           // (no memory for it: serial path, which reports its own errors)
+            if (w <= 0) { gzclose(f); close(m); size = 0; return PG_OK; }           // (no memory for it: serial path, which reports its own errors)
             done += (size_t)w;
         }
         size += (size_t)got;
@@ -1109,7 +1148,7 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
         if ((rc = open_plain(r1, fd, size, plain))) return rc;
         if (!plain && size >= ((size_t)1 << 14) * (size_t)T) {        // gzip of some size: inflate once, then parse by threads
             close(fd);
-            if ((rc = inflate_to_memfd(r1, fd, size))) return rc;
+            if ((rc = inflate_to_memfd(r1, fd, size, inflate_budget(1)))) return rc;
             if (fd < 0) { if ((rc = open_plain(r1, fd, size, plain))) return rc; plain = false; }
             else plain = true;
         }
@@ -1137,8 +1176,9 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
         if ((rc = open_plain(r2, fd2, n2, p2))) { close(fd1); return rc; }
         if ((!p1 || !p2) && n1 >= ((size_t)1 << 14) * (size_t)T) {     // gzip: the two streams are inflated side by side
             int g1 = -1, g2 = -1; size_t m1 = 0, m2 = 0; int rc1 = PG_OK, rc2 = PG_OK;
-            std::thread other([&] { if (!p2) rc2 = inflate_to_memfd(r2, g2, m2); });
-            if (!p1) rc1 = inflate_to_memfd(r1, g1, m1);
+            const uint64_t budget = inflate_budget((p1 ? 0 : 1) + (p2 ? 0 : 1));
+            std::thread other([&] { if (!p2) rc2 = inflate_to_memfd(r2, g2, m2, budget); });
+            if (!p1) rc1 = inflate_to_memfd(r1, g1, m1, budget);
             other.join();
             if (rc1 || rc2) { close(fd1); close(fd2); if (g1 >= 0) close(g1); if (g2 >= 0) close(g2); return rc1 ? rc1 : rc2; }
             if ((p1 || g1 >= 0) && (p2 || g2 >= 0)) {
@@ -1208,7 +1248,7 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
         } else {
             Lines L1(f1), L2(f2);
             uint64_t line_no = 0;
-            std::string n1, n2, b1, b2;
+            std::string n1, n2, b1, b2, pair_bc;                    // pair_bc: the barcode of the pair that is staged (b1 moves on with the next header)
             struct ReadQ { const char *s; size_t n; const char *q; size_t qn; };
             std::vector<ReadQ> orphans;                             // reads of skipped pairs (still counted globally)
             const char *c; size_t clen;
@@ -1225,10 +1265,10 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
                 R->st.put_span_q(s1, l1, q1, q1n); R->st.put('N');
                 R->st.put_span_q(s2, l2, q2, q2n); R->st.put('N');
                 R->n_pairs++;
-                if (b1 != last) {
+                if (pair_bc != last) {
                     R->run_off.push_back(R->st.n);
                     R->run_name.push_back(last);
-                    last = b1;
+                    last = pair_bc;
                 }
             };
             while (L1.next(b, len)) {
@@ -1249,6 +1289,7 @@ extern "C" int pg_ingest_fastq(const char *r1, const char *r2, pg_reads **out)
                     keep_pair = !(n1 != n2 || b1 != b2);
                     if (!keep_pair) R->n_unpaired++;
                     s1 = b; l1 = len; s2 = c; l2 = clen;
+                    pair_bc = b1;
                     have_pair = true;
                     break;
                 case 0:

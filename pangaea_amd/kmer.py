@@ -403,7 +403,12 @@ class KmerTable:
         ws = self._mini_spare if self._mini_spare is not None and self._mini_spare.numel() == need else None
         self._mini_spare = None
         if ws is None:
-            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # a fresh workspace is allocated ON the side stream: a block the caching allocator hands out there is free of pending
+            # work of the current stream (with ``after`` set the side stream does not wait for that stream's tail).  The spare
+            # workspace was last read by the count BEFORE the one just enqueued, which every ``after`` event lies behind.
+            with torch.cuda.stream(side):
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws.record_stream(torch.cuda.current_stream(self.device))         # (the count that consumes it runs there)
         # ``after`` = an event recorded before this batch's count was enqueued: the plan then runs BESIDE the count (its kernel
         # is small enough to share the CUs with it) instead of behind it
         if after == "first-pass":
