@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--barcodes", type=int, default=0, help="barcodes per GPU (default pairs/200)")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="pairs in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-pairs", type=int, default=1_000_000, help="pairs of the end-to-end leg (FASTQ file -> mu); 0 = skip")
+    ap.add_argument("--e2e-pairs", type=int, default=-1, help="pairs of the end-to-end leg (FASTQ file -> mu); default: the whole workload; 0 = skip")
     ap.add_argument("--rehearse-dist", type=int, default=0, metavar="N",
                     help="one GPU: run the N-rank code path (deferred count, exchange over a one-rank RCCL group, table sized for N shards) -- not a result")
     ap.add_argument("--load", type=float, default=0.6, help="highest load of the hash table (its size is the next power of two)")
@@ -130,8 +130,8 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
 
     tmp = tempfile.mkdtemp(prefix="pg_e2e_")
     fq, warm = os.path.join(tmp, "reads.fq"), os.path.join(tmp, "warm.fq")
-    n = synth.write_fastq(stream, cfg, fq, n_pairs)
-    synth.write_fastq(stream, cfg, warm, min(20_000, n_pairs))
+    n = synth.write_fastq_fast(stream, cfg, fq, n_pairs)
+    synth.write_fastq_fast(stream, cfg, warm, min(20_000, n_pairs))
     size = os.path.getsize(fq)
 
     def run(path):
@@ -144,7 +144,7 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
         lap["h2d"] = time.perf_counter() - t; t = time.perf_counter()
         rows = s.rows(MIN_LEN)
         plan = kmer.Plan(rows, dev)
-        table = kmer.count_kmers(s, K_ABD, rows=plan, emit=(WINDOW, VSIZE))
+        table = kmer.count_kmers(s, K_ABD, rows=plan, emit=(WINDOW, VSIZE))          # (HyperLogLog sizing, allocation, partition plan, count + lookups)
         tnf, abd = kmer.features(s, plan, k_tnf=K_TNF, table=table, window=WINDOW, vsize=VSIZE)
         torch.cuda.synchronize()
         lap["table+rows"] = time.perf_counter() - t; t = time.perf_counter()
@@ -154,14 +154,16 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
         return time.perf_counter() - t0, lap, tuple(mu.shape)
 
     run(warm)                                           # first-call costs (code objects, allocator) stay out of the figure
-    total, lap, shape = min((run(fq) for _ in range(2)), key=lambda r: r[0])        # (the faster of two passes: the leg is ~35 ms)
+    passes = [run(fq) for _ in range(2)]
+    total, lap, shape = min(passes, key=lambda r: r[0])
     for f in (fq, warm):
         os.remove(f)
     os.rmdir(tmp)
     threads = min(32, len(os.sched_getaffinity(0)))
     return {"value": n / total, "unit": "pairs/s", "pairs": n, "fastq_bytes": size, "host_threads": threads,
-            "seconds": {k: round(v, 4) for k, v in lap.items()}, "mu_shape": list(shape),
-            "what": "plain interleaved FASTQ file -> ingest -> H2D -> table sizing + plan + count/lookups -> rows -> normalise -> encode, one GPU; faster of two passes"}
+            "first_pass": n / passes[0][0], "seconds": {k: round(v, 4) for k, v in lap.items()}, "mu_shape": list(shape),
+            "what": "plain interleaved FASTQ file (page cache) -> ingest -> H2D -> table sizing + allocation + plan + count/lookups -> rows -> "
+                    "normalise -> encode, one GPU; value = the faster of two passes, first_pass = the first of them"}
 
 
 def spawn_ranks(n: int) -> int:
@@ -236,12 +238,20 @@ def main():
     n_bc = args.barcodes or max(1, args.pairs // 200)
     cfg = synth.SynthConfig(n_pairs=args.pairs, n_barcodes=n_bc, read_len=READ_LEN, seed=2022, first_pair=rank * args.pairs)
     stream = synth.generate(cfg, device=dev, chunk_pairs=1 << 17, with_names=False)
+    t_s = time.perf_counter()
     rows = stream.rows(MIN_LEN)
     plan = kmer.Plan(rows, dev)
+    torch.cuda.synchronize()
+    rows_ms = (time.perf_counter() - t_s) * 1e3
     # table sized from HyperLogLog sketches, outside the timed region: the elementwise maximum of the ranks' sketches is the
     # sketch of the union, so every rank allocates the same table (geometry of the union) at load <= 0.6
+    # (what a NEW data set costs before its first step is reported as `setup_ms`: the device-resident figure leaves it out)
+    setup = {}
+    torch.cuda.synchronize(); t_s = time.perf_counter()
     regs = kmer.distinct_sketch(stream, K_ABD)
     local_distinct = kmer.sketch_estimate(regs)
+    setup["distinct_sketch"] = (time.perf_counter() - t_s) * 1e3
+    setup["rows+plan_segments"] = rows_ms
     if multi:
         union = regs if args.backend == "nccl" else regs.cpu()
         dist.all_reduce(union, op=dist.ReduceOp.MAX)
@@ -255,10 +265,23 @@ def main():
     fused = not multi and not args.no_fuse
     import math
     mini = fused and not args.no_mini and kmer.KmerTable.mini_applies(K_ABD, max(10, math.ceil(math.log2(max(1024, int(hint / args.load))))))
-    table = kmer.KmerTable.alloc(K_ABD, dev, "mini" if mini else "hash", distinct_hint=hint, load=args.load)
+    torch.cuda.synchronize(); t_s = time.perf_counter()
+    # N > 1 ranks: the super-k-mer pipeline on every rank's own reads, entries to bucket owners, bins back (dist.MiniSharded);
+    # --no-mini: round 1's key-partitioned pipeline with the replicated table
+    ms = None
+    if multi and not args.no_mini:
+        loc = torch.tensor([int(1.1 * local_distinct)], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+        log2_u, lb_u, lb_l = pdist.MiniSharded.geometry(hint, int(loc.item()), union_load=args.load)
+        if log2_u - lb_u <= 16:
+            ms = pdist.MiniSharded(K_ABD, dev, log2_u, lb_l, WINDOW, VSIZE, union_log2_bucket=lb_u)
+    table = ms.union if ms is not None else kmer.KmerTable.alloc(K_ABD, dev, "mini" if mini else "hash", distinct_hint=hint, load=args.load)
+    torch.cuda.synchronize()
+    setup["table_alloc"] = (time.perf_counter() - t_s) * 1e3
     # N > 1: a rank's own keys are 2^g times sparser than the union and are counted in deferred form (entries + fills for
     # the exchange; the rank's own sparse table is never written)
-    defer = pdist.deferred_group_for(table, int(1.1 * local_distinct)) if multi and not args.no_defer else None
+    defer = pdist.deferred_group_for(table, int(1.1 * local_distinct)) if multi and ms is None and not args.no_defer else None
     tnf = torch.zeros((len(rows), kmer.tnf_ncols(K_TNF)), dtype=torch.int32, device=dev)
     abd = torch.zeros((len(rows), VSIZE), dtype=torch.int32, device=dev)
     torch.manual_seed(2021)
@@ -272,7 +295,31 @@ def main():
 
     side = torch.cuda.Stream(device=dev)
 
+    def step_sharded(timed: bool):
+        """N > 1 ranks, super-k-mer form: count half | entries to owners, merged bins back | lookup half + rows + TNF"""
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        if args.plan != "once":
+            ms.local._mini_plan = None
+        ms.count_half(stream, plan)
+        e[1].record()
+        if args.plan == "ahead":
+            ms.local.prefetch_plan(stream, plan, side)
+        ms.exchange()
+        e[2].record()
+        ms.lookup_half()
+        kmer.features(stream, plan, k_tnf=K_TNF, table=ms.local, window=WINDOW, vsize=VSIZE, out_tnf=tnf, out_abd=abd)
+        e[3].record()
+        mu = vae.encode(Data(names, abd, tnf, device=dev))
+        if timed:
+            ev[k2].append((e[0], e[1]))
+            ev["exchange"].append((e[1], e[2]))
+            ev["features"].append((e[2], e[3]))
+        return mu
+
     def step(timed: bool):
+        if ms is not None:
+            return step_sharded(timed)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         table.reset()                   # bucketed tables are overwritten slice by slice: no 4 GB clear
@@ -311,16 +358,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        if i == 0:
+            torch.cuda.synchronize(); t_s = time.perf_counter()
         mu = step(False)
+        if i == 0:                      # the first pass over a data set: workspaces, code objects and -- super-k-mer pipeline -- the first plan
+            torch.cuda.synchronize()
+            setup["first_step_incl_allocations"] = (time.perf_counter() - t_s) * 1e3
     fence()
-    table.check_status()
+    ms.check_status() if ms is not None else table.check_status()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         mu = step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    table.check_status()
+    ms.check_status() if ms is not None else table.check_status()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -331,13 +383,14 @@ def main():
     table_load = table.occupancy() if table.kind == "hash" else None
     dominant = max((k for k in kern_ms if k != "exchange"), key=kern_ms.get)
     achieved = alg[dominant] * args.pairs / (kern_ms[dominant] * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_tag = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")        # per-launch HBM bytes from rocprofv3 --pmc passes
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("pairs") == args.pairs and tj.get("pipeline", "key") == ("mini" if mini else "key"):
             traffic = tj.get("kernels", {}).get(dominant)
+            traffic_tag = tj.get("tag")             # (which build the PMC passes were collected for: profiles/README.md)
 
     if rank == 0:
         out = {
@@ -356,27 +409,37 @@ def main():
             "config": {"workload": f"synthetic {args.pairs} x 150 bp read pairs and {n_bc} barcodes per GPU, k=21 hash table "
                                    f"(2^{table.log2_slots} slots), TNF k=4 + abundance V=400 W=10, L1-normalise, VAE 536-512-512-32 encode",
                        "pairs_per_gpu": args.pairs, "barcodes_per_gpu": n_bc, "rows_per_gpu": len(rows),
-                       "parallelism": (f"run-sharded x{world}, deferred count, " + ("owner-partitioned table exchange (all-to-all + all-gather of merged ranges, 6-byte entries)"
+                       "parallelism": ((f"run-sharded x{world}, super-k-mer count half per rank, entries to bucket owners (all-to-all, 8 B per distinct k-mer), "
+                                        f"merged bins back (all-to-all, 2 B), lookup half per rank ({args.backend})") if world > 1 and ms is not None
+                                       else f"run-sharded x{world}, deferred count, " + ("owner-partitioned table exchange (all-to-all + all-gather of merged ranges, 6-byte entries)"
                                                                                     if world >= 4 else "range-wise table all-gather (6-byte entries) overlapped with LDS rebuilds")
                                        + f" ({args.backend})" if world > 1
                                        else f"REHEARSAL of the {args.rehearse_dist}-rank path on one GPU (one-rank RCCL group)" if multi else "single GPU"),
-                       "pipeline": ("super-k-mers by minimizer bucket (12-byte records, LDS counting + lookups per bucket)" if mini
+                       "pipeline": ("super-k-mers by minimizer bucket (12-byte records, LDS counting per bucket; lookups of the provisional words once the owners' bins are back)"
+                                    if ms is not None else
+                                    "super-k-mers by minimizer bucket (12-byte records, LDS counting + lookups per bucket)" if mini
                                     else "k-mer occurrences by key (8-byte records, LDS counting" + (" + lookups" if fused else "") + " per bucket)"),
                        "partition_plan": ({"ahead": "computed in every step for the next batch, on a side stream under the row histograms and the encode",
                                             "in-step": "computed in every step, in front of the count",
                                             "once": "computed ONCE before the timed steps (comparison figure: only valid because the bench repeats one batch)"}[args.plan]
                                           if mini else "bucket histogram inside the step"),
-                       "records_per_pair": (table._mini_plan[2] / args.pairs if mini and table._mini_plan else 260.0),
+                       "records_per_pair": (ms.local._mini_plan[2] / args.pairs if ms is not None and ms.local._mini_plan else
+                                            table._mini_plan[2] / args.pairs if mini and table._mini_plan else 260.0),
+                       "exchange_bytes_per_rank": ({"sent": ms.bytes_sent, "received": ms.bytes_received} if ms is not None else None),
+                       "local_bucket_slots": (1 << ms.local.log2_bucket if ms is not None else None),
                        "input": "packed reads resident in HBM", "table_load": table_load,
                        "table_buckets": table.n_buckets, "bucket_slots": 1 << table.log2_bucket if table.log2_bucket else None},
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_tag": traffic_tag,
                          "alg_bytes_per_pair": alg[dominant]},
+            "setup_ms": {k: round(v, 2) for k, v in setup.items()},
         }
-        if world == 1 and args.e2e_pairs > 0 and not args.rehearse_dist:
+        if world == 1 and args.e2e_pairs != 0 and not args.rehearse_dist:
             try:
-                out["e2e"] = e2e_leg(stream, cfg, min(args.e2e_pairs, args.pairs), vae, dev)
+                del table                       # (the leg builds its own: two 8.6 GB tables and their workspaces need not coexist)
+                torch.cuda.empty_cache()
+                out["e2e"] = e2e_leg(stream, cfg, args.pairs if args.e2e_pairs < 0 else min(args.e2e_pairs, args.pairs), vae, dev)
             except Exception as e:          # reporting only
                 out["e2e"] = {"value": None, "unit": "pairs/s", "what": f"failed: {e!r}"}
         if world == 1 and not args.no_cpu_baseline:

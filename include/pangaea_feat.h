@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 3   /* 3: PG_TABLE_MINI and the super-k-mer entry points; 2: packed hash slots keyed by pg_key42(code) */
+#define PG_ABI_VERSION 4   /* 4: pg_mini_records_bytes takes the table (per-record hit masks of the merged lookups), status bits;
+                              3: PG_TABLE_MINI and the super-k-mer entry points; 2: packed hash slots keyed by pg_key42(code) */
 #define PG_CHARS_PER_WORD 32
 #define PG_WORD_ALIGN 256 /* stream arrays are padded to a multiple of this many words */
 
@@ -189,8 +190,14 @@ typedef struct {
 } pg_table;
 
 /* Count the k-mers ending in words [word_begin, word_end) of the stream into `t`.
- * status (device uint32_t[2], zeroed by the caller): [0] is set non-zero when the hash table is full
- * (check after synchronising: PG_ETABLEFULL condition), [1] unused.  May be NULL for dense tables. */
+ * status (device uint32_t[2], zeroed by the caller): [0] is a set of PG_STATUS_* bits, non-zero after synchronising when the
+ * count did not complete (PG_STATUS_TABLE_FULL: the PG_ETABLEFULL condition), [1] unused.  May be NULL for dense tables. */
+#define PG_STATUS_TABLE_FULL 1u      /* a bucket (or the table) has no free slot left: enlarge log2_slots and count again */
+#define PG_STATUS_OVERFLOW_LIST 2u   /* the exchange's list of count remainders >= 0xffff ran over its capacity */
+#define PG_STATUS_PLAN_MISMATCH 4u   /* pg_mini_count: the plan describes more records than the record workspace holds (a plan
+                                        of another stream): nothing was counted */
+#define PG_STATUS_BOUNDS 8u          /* checked builds only (libpangaea_feat_checked.so): a kernel was about to store outside
+                                        the buffer it was given; the store was dropped */
 int pg_kmer_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end,
                   const pg_table *t, uint32_t *status, void *stream);
 
@@ -341,13 +348,14 @@ int pg_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int window
  *                  workgroup (slots of a FRESH table are overwritten, no clearing) and, when window > 0, looked up again
  *                  while its counts are still in LDS: the (row, bin) words of count_kmer.cpp:86-96 are left in
  *                  `shuffle_ws` for pg_mini_abundance_from_emitted.  `rows` may be NULL and window = vsize = 0 (table only).
- * plan_ws: pg_mini_plan_bytes; rec_ws: pg_mini_records_bytes(n_records) (two buffers of 12 B per record);
- * shuffle_ws: pg_mini_shuffle_bytes.  All 256-byte aligned device memory.
+ * plan_ws: pg_mini_plan_bytes; rec_ws: pg_mini_records_bytes(n_records, t) (two buffers of 12 B per record, the per-record
+ * hit masks and per-batch word offsets of the merged lookups); shuffle_ws: pg_mini_shuffle_bytes.  All 256-byte aligned
+ * device memory.  A plan that names more records than rec_ws holds sets PG_STATUS_PLAN_MISMATCH and counts nothing.
  * ---------------------------------------------------------------------------------------------- */
 int64_t pg_mini_plan_bytes(int64_t n_words, const pg_table *t);
 int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                  const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *stream);
-int64_t pg_mini_records_bytes(int64_t n_records);
+int64_t pg_mini_records_bytes(int64_t n_records, const pg_table *t);
 int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize);
 int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                   const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
@@ -358,6 +366,39 @@ int pg_mini_wait_first_pass(void *stream);
 int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int vsize, int32_t *abd_out,
                                    const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
                                    void *shuffle_ws, int64_t shuffle_ws_bytes, void *stream);
+
+/* ---- the super-k-mer form on N > 1 ranks (the reference runs ONE jellyfish over all reads: feature.py:94; here every rank
+ * counts its own reads and the counts meet at bucket owners).  A rank's counts are not final until the other ranks' occurrences
+ * of the same k-mers are in, so pg_mini_count is cut in two:
+ *   pg_mini_count_half    as pg_mini_count up to the bucket workgroups, which leave -- instead of the slice and the lookups --
+ *                         their occupied slots (canonical code << 22 | count) as compacted ENTRIES in slot order, the number of
+ *                         them in fill[bucket] (device int64), the occupancy bitmaps and the provisional (row, slot) words.
+ *                         `local` has the UNION's bucket count and, per bucket, slots for this rank's own k-mers; its `data` is
+ *                         never written.
+ *   pg_mini_gather_entries  bucket b's entries -> out[dst_elem[b] ..): the send buffer, bucket ranges in owner order
+ *   (all-to-all: 8 bytes per entry)
+ *   pg_mini_merge_bins    owner side, buckets [bucket_begin, bucket_end) of the union table `t`: part p's entries of owned bucket i
+ *                         lie at recv[p * part_stride + seg[p * (n_owned + 1) + i] .. seg[p * (n_owned + 1) + i + 1]); the parts are
+ *                         summed inside LDS (counts saturate at PG_HASH_COUNT_SAT, as one rank's would), the merged slices are
+ *                         written to `t`, and bins_out (same layout, uint16) receives for EVERY entry the bin of its k-mer in the
+ *                         merged table: count / window + 1, or 0xffff beyond the vector (count_kmer.cpp:86-96)
+ *   (all-to-all back: 2 bytes per entry)
+ *   pg_mini_lookup_half   bins_in[bin_elem[b] ..) = the bins of bucket b's entries, in the order they were sent -> the lookups of
+ *                         the provisional words and the row-group scatter, exactly as pg_mini_count ends;
+ *                         pg_mini_abundance_from_emitted(local, ...) then writes the rows.
+ * half_ws: pg_mini_half_bytes(local), 256-byte aligned device memory. */
+int64_t pg_mini_half_bytes(const pg_table *local);
+int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *local,
+                       const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                       int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *half_ws, int64_t half_ws_bytes,
+                       int64_t *fill, uint32_t *status, void *stream);
+int pg_mini_gather_entries(const pg_table *local, const void *half_ws, int64_t half_ws_bytes, const int64_t *fill,
+                           const int64_t *dst_elem, uint64_t *out, void *stream);
+int pg_mini_merge_bins(const uint64_t *recv, int64_t part_stride, const int64_t *seg, int n_parts, const pg_table *t,
+                       int64_t bucket_begin, int64_t bucket_end, int window, int vsize, uint16_t *bins_out, uint32_t *status, void *stream);
+int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
+                        int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *half_ws, int64_t half_ws_bytes,
+                        const uint16_t *bins_in, const int64_t *bin_elem, uint32_t *status, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Row normalisation of a count matrix (a9: Data.__init__, src/data.py:16-21 -- sklearn normalize(norm="l1") in float64, the

@@ -1498,7 +1498,9 @@ __global__ __launch_bounds__(BLOCK) void group_caps_kernel(const int64_t *__rest
 // S3: one workgroup per row group: LDS histogram [64 rows][vsize] of the group's (row, bin) words, written out as the
 // rows of the abundance matrix (plain stores: every row belongs to exactly one group)
 // WORD = uint16_t: the narrow words of a one-pass shuffle (row inside the group << vbits | bin; 0xffff = none)
-template <typename WORD>
+// COUNTED (4-byte words): (n - 1) << PG_SHUFFLE_COUNT_SHIFT | row << vbits | bin stands for n equal words -- a lookup pass that
+// merges the runs of a record itself (mini.hip) has left hardly any equal neighbours: no run detection here, the count is added
+template <typename WORD, bool COUNTED = false>
 __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restrict__ words, const unsigned long long *__restrict__ goff,
                                                              const unsigned long long *__restrict__ gcnt, int vbits, uint32_t vsize,
                                                              int64_t n_rows, int32_t *__restrict__ abd_out, int64_t g0, int split)
@@ -1549,6 +1551,12 @@ __global__ __launch_bounds__(BIG_BLOCK) void row_hist_kernel(const WORD *__restr
         // and a lookup pass that works on super-k-mers leaves them next to each other -- as single adds they would queue up on
         // one LDS address
         const uint32_t lane = threadIdx.x & 63;
+        if (COUNTED) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (e[j] != NONE)
+                    atomicAdd(&hist[((e[j] >> vbits) & ((1u << GROUP_ROWS_LOG2) - 1u)) * stride + (e[j] & bmask)], (e[j] >> PG_SHUFFLE_COUNT_SHIFT) + 1u);
+        } else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t prev = __shfl_up(e[j], 1);
@@ -2348,8 +2356,10 @@ static int shuffle_prepare(const ShufflePlan &sp, const pg_rows *rows, char *ws,
     return check_launch("pg_abundance_from_records");
 }
 
-static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize, int32_t *abd_out, char *ws, hipStream_t s, bool narrow = false)
+static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize, int32_t *abd_out, char *ws, hipStream_t s, int word_form = PG_SHUFFLE_WORDS_PLAIN)
 {
+    const bool narrow = word_form == PG_SHUFFLE_WORDS_NARROW, counted = word_form == PG_SHUFFLE_WORDS_COUNTED;
+    if (counted && sp.vbits + GROUP_ROWS_LOG2 + sp.gbits > PG_SHUFFLE_COUNT_SHIFT) return pg_fail(PG_EINVAL, "row shuffle: counted words need row bits + bin bits <= %d", PG_SHUFFLE_COUNT_SHIFT);
     int rc;
     auto *goff = (unsigned long long *)(ws + sp.goff_off);
     auto *gcur1 = (unsigned long long *)(ws + sp.gcur1_off);
@@ -2359,6 +2369,7 @@ static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize,
     const size_t hist_lds = ((size_t)4 << GROUP_ROWS_LOG2) * (size_t)(vsize | 1);
     if ((rc = raise_lds_limit((const void *)row_hist_kernel<uint32_t>, hist_lds, "pg_abundance_from_records"))) return rc;
     if ((rc = raise_lds_limit((const void *)row_hist_kernel<uint16_t>, hist_lds, "pg_abundance_from_records"))) return rc;
+    if ((rc = raise_lds_limit((const void *)row_hist_kernel<uint32_t, true>, hist_lds, "pg_abundance_from_records"))) return rc;
     if (narrow && sp.gb2) return pg_fail(PG_EINVAL, "row shuffle: narrow words need a one-pass shuffle");
     const int gshift = sp.vbits + GROUP_ROWS_LOG2;
     const unsigned long long *gcnt = gcur1;
@@ -2393,15 +2404,16 @@ static int shuffle_finish(const ShufflePlan &sp, const pg_rows *rows, int vsize,
         if (row0 < rows->n_rows && hipMemsetAsync(abd_out + row0 * (int64_t)vsize, 0, (size_t)(rows->n_rows - row0) * vsize * sizeof(int32_t), s) != hipSuccess)
             return pg_fail(PG_EHIP, "pg_abundance_from_records: memset failed");
     }
-#define PG_ROW_HIST(WORD_, WORDS_)                                                                                           \
+#define PG_ROW_HIST(WORD_, COUNTED_, WORDS_)                                                                                 \
     do {                                                                                                                    \
-        if (n_main) hipLaunchKernelGGL(row_hist_kernel<WORD_>, dim3((unsigned)n_main), dim3(BIG_BLOCK), hist_lds, s, WORDS_, (const unsigned long long *)goff, \
+        if (n_main) hipLaunchKernelGGL((row_hist_kernel<WORD_, COUNTED_>), dim3((unsigned)n_main), dim3(BIG_BLOCK), hist_lds, s, WORDS_, (const unsigned long long *)goff, \
                                        gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out, (int64_t)0, 1);               \
-        if (n_tail) hipLaunchKernelGGL(row_hist_kernel<WORD_>, dim3((unsigned)(n_tail * split)), dim3(BIG_BLOCK), hist_lds, s, WORDS_,                       \
+        if (n_tail) hipLaunchKernelGGL((row_hist_kernel<WORD_, COUNTED_>), dim3((unsigned)(n_tail * split)), dim3(BIG_BLOCK), hist_lds, s, WORDS_,           \
                                        (const unsigned long long *)goff, gcnt, sp.vbits, (uint32_t)vsize, rows->n_rows, abd_out, n_main, split); \
     } while (0)
-    if (narrow) PG_ROW_HIST(uint16_t, (const uint16_t *)final_words);
-    else PG_ROW_HIST(uint32_t, final_words);
+    if (narrow) PG_ROW_HIST(uint16_t, false, (const uint16_t *)final_words);
+    else if (counted) PG_ROW_HIST(uint32_t, true, final_words);
+    else PG_ROW_HIST(uint32_t, false, final_words);
 #undef PG_ROW_HIST
     return check_launch("pg_abundance_from_records");
 }
@@ -2461,19 +2473,20 @@ int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, voi
     ctx->gb2 = sp.gb2;
     ctx->dshift = sp.vbits + GROUP_ROWS_LOG2 + sp.gb2;
     ctx->narrow = pg_internal_shuffle_is_narrow(cap, rows->n_rows, vsize, one_pass_bits);
+    ctx->words_cap = (unsigned long long)cap;
     if (rows->n_rows == 0) return PG_OK;
     return shuffle_prepare(sp, rows, ws, (hipStream_t)stream);
 }
 
 int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
-                               int narrow, int one_pass_bits)
+                               int word_form, int one_pass_bits)
 {
     ShufflePlan sp;
     int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits);
     if (rc) return rc;
     if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
     if (rows->n_rows == 0) return PG_OK;
-    return shuffle_finish(sp, rows, vsize, abd_out, (char *)workspace, (hipStream_t)stream, narrow != 0);
+    return shuffle_finish(sp, rows, vsize, abd_out, (char *)workspace, (hipStream_t)stream, word_form);
 }
 
 // a9: L1 row normalisation in float64, narrowed to float32, + the sampling weight; one wavefront per row (src/data.py:16-21)

@@ -244,9 +244,11 @@ __global__ __launch_bounds__(BIG_BLOCK) void digit_totals_kernel(const unsigned 
 // records per bucket, from the records the first pass has written: region = blockIdx.x / tiles_x holds [region_off[region],
 // region_off[region + 1]); its workgroups count the second-pass digits of their share of the meta plane and add them to hist
 __global__ __launch_bounds__(BLOCK) void mini_bucket_hist_kernel(const uint32_t *__restrict__ meta, const unsigned long long *__restrict__ region_off,
-                                                                 int bits2, int tiles_x, unsigned long long *__restrict__ hist)
+                                                                 int bits2, int tiles_x, unsigned long long *__restrict__ hist,
+                                                                 const unsigned long long *__restrict__ header, unsigned long long rec_cap, const uint32_t *status)
 {
     __shared__ uint32_t cnt[1 << META_D2_BITS];
+    if (header[0] > rec_cap || (*status & PG_STATUS_PLAN_MISMATCH)) return;      // (a plan of another stream: see mini_count_kernel)
     const int n_dig = 1 << bits2;
     const uint32_t dmask = (uint32_t)n_dig - 1u;
     const int64_t region = blockIdx.x / tiles_x;
@@ -344,10 +346,16 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                                                                  const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
                                                                  const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
                                                                  uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
-                                                                 const unsigned long long *__restrict__ chunk_off, int64_t n_chunks, int64_t chunk_stride)
+                                                                 const unsigned long long *__restrict__ chunk_off, int64_t n_chunks, int64_t chunk_stride,
+                                                                 const unsigned long long *__restrict__ header, const unsigned long long *__restrict__ region_off,
+                                                                 unsigned long long rec_cap, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     static_assert(N1 <= S1_BLOCK, "one lane per region");
+    if (header[0] > rec_cap) {                                      // (a plan of another stream: see mini_count_kernel)
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(status, PG_STATUS_PLAN_MISMATCH);
+        return;
+    }
     Scatter1Lds<N1> &L = *reinterpret_cast<Scatter1Lds<N1> *>(lds_raw);
     const int n_dig = 1 << (bits - bits2);
     const uint32_t d2mask = (1u << bits2) - 1u;
@@ -421,12 +429,22 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
             lds_sync();
             const uint32_t tot = L.start[N1];
             for (uint32_t i = threadIdx.x; i < tot; i += S1_BLOCK) {
+                // (a record beyond the buffers is dropped: cannot happen with the plan of THIS stream -- the offsets are exact --,
+                // and the plan of another one is reported below)
                 const unsigned long long g = L.gbase[L.dig[i]] + i;
-                out_bases[g] = L.bases[i];
-                out_meta[g] = L.meta[i];
+                if (g < rec_cap) {
+                    out_bases[g] = L.bases[i];
+                    out_meta[g] = L.meta[i];
+                }
             }
         }
         lds_sync();
+    }
+    // every region's run of this chunk must end where the plan put the next chunk's: a plan that was computed for other reads
+    // (KmerTable ties its cached plans to the stream; this is the backstop) shows here, and the count is void
+    if ((int)threadIdx.x < n_dig) {
+        const unsigned long long planned = slot + 1 < n_chunks ? chunk_off[(int64_t)threadIdx.x * n_chunks + slot + 1] : region_off[threadIdx.x + 1];
+        if (L.cur[threadIdx.x] != planned) atomicOr(status, PG_STATUS_PLAN_MISMATCH);
     }
 }
 
@@ -449,8 +467,10 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
                                                               const unsigned long long *__restrict__ off, int bits2, int tiles_x, int short_max,
                                                               uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
                                                               unsigned long long *__restrict__ cursor, unsigned long long *__restrict__ cursor_l,
-                                                              unsigned long long *__restrict__ kwords)
+                                                              unsigned long long *__restrict__ kwords,
+                                                              const unsigned long long *__restrict__ header, unsigned long long rec_cap, uint32_t *status)
 {
+    if (header[0] > rec_cap || (*status & PG_STATUS_PLAN_MISMATCH)) return;      // (a plan of another stream: see mini_count_kernel)
     // kwords[b] += the k-mers of bucket b that lie inside a row (= the words its workgroup will emit): they ride in the high
     // half of the tile's rank counters -- a tile has 4096 records of at most 9 k-mers, both halves stay below 2^16
     static_assert(S2_TILE * MINI_MAX_WINDOW < 65536, "two 16-bit halves per rank counter");
@@ -517,8 +537,8 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {     // flat sweep: the digit is in the record
             const uint32_t m = L.meta[i];
             const unsigned long long g = L.gbase[digit_of(m)] + i;
-            out_bases[g] = L.bases[i];
-            out_meta[g] = m;
+            gstore(out_bases, g, rec_cap, L.bases[i], status);
+            gstore(out_meta, g, rec_cap, m, status);
         }
         lds_sync();
     }
@@ -540,6 +560,15 @@ constexpr int RING = 128;                                    // entries per wave
 constexpr int COUNT_WAVES = BIG_BLOCK / 64;
 constexpr uint32_t BIN_NONE = (uint32_t)HASH_CMASK;          // a slot's count field after the counts have become bins: bin + 1, or this
 
+// a value that is the same in every lane (read from LDS, say), moved to scalar registers: addresses built from it are a scalar
+// base + a 32-bit lane offset, comparisons with it are scalar operands -- as vector registers such bases were spilled and
+// reloaded in front of every load of an unrolled group, each reload with a wait for ALL memory operations in flight
+__device__ __forceinline__ uint32_t uniform32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+template <class T> __device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<T *>(((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v));
+}
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 {
@@ -608,6 +637,7 @@ struct ShufArgs {
     uint32_t *words_out;
     int gb1, gb2, dshift;
     int narrow;                                                  // one-pass shuffle: 2-byte words (row inside its group, bin)
+    unsigned long long words_cap;                                // 4-byte elements of words_out (checked builds)
 };
 // LDS of that scatter (bytes from the start of the dynamic area; the table has become 2-byte bins by then)
 template <int BLK, int DIG> struct LookupLds {                 // BLK threads: 1024, or 512 (buckets of at most 2^13 slots: two workgroups per CU);
@@ -617,7 +647,533 @@ template <int BLK, int DIG> struct LookupLds {                 // BLK threads: 1
 };
 constexpr int SHORT_MAX = PG_SHORT_MAX;                                 // a record with at most this many k-mers is "short"
 
-template <int CAP, bool SLOTS, bool WIDE, int BLK, int DIG>
+// ---- the word-wise lookups of the slot form: provisional (row, slot) words -> (row, bin) words, 16 per lane and tile, scattered
+// by the first digit of their row group into the row shuffle's regions (an LDS multisplit per tile, one global cursor add per
+// digit and tile).  Called by a whole workgroup of BLK threads once the bucket's 2-byte bins lie at the start of the dynamic LDS:
+// by the counting kernel while the counts are still there, or by mini_lookup_half_kernel.
+struct WordCtx {
+    unsigned char *lds;
+    uint32_t smask, np;
+    int lb, vbits;
+    ShufArgs sh;
+    uint32_t *status;
+    const uint32_t *prov_b;
+    unsigned long long *dbg;
+};
+template <int BLK, int DIG>
+__device__ __forceinline__ void wordwise_lookup(const WordCtx &c)
+{
+    using FL = LookupLds<BLK, DIG>;
+    constexpr int DPT = DIG / BLK;
+    const uint16_t *bins16 = reinterpret_cast<const uint16_t *>(c.lds);
+    uint32_t *buf = reinterpret_cast<uint32_t *>(c.lds + FL::BUF), *cnt = reinterpret_cast<uint32_t *>(c.lds + FL::CNT);
+    uint32_t *start = reinterpret_cast<uint32_t *>(c.lds + FL::START), *wave_tot = reinterpret_cast<uint32_t *>(c.lds + FL::WAVE);
+    unsigned long long *gbase = reinterpret_cast<unsigned long long *>(c.lds + FL::GBASE);
+    const ShufArgs &sh = c.sh;
+    const uint32_t smask = c.smask, np = c.np;
+    const int lb = c.lb, vbits = c.vbits;
+    uint32_t *const status = c.status;
+    const uint32_t dmask = (1u << sh.gb1) - 1u;
+#ifdef PG_MINI_STAMPS
+    unsigned long long *dbg = c.dbg;
+    unsigned long long tl = __builtin_amdgcn_s_memtime();
+#define PG_LAP(K) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&dbg[K], now_ - tl); tl = now_; } } while (0)
+#else
+#define PG_LAP(K) do { } while (0)
+#endif
+    // Software pipeline.  Every barrier in the loop is an LDS-only one (lds_sync), and there is ONE wait for global memory per
+    // tile, in front of the copy-out: by then the next tile's words (requested at the top of the tile), the cursor adds
+    // (requested as soon as the ranks, and with them the digits' counts, exist: in front of the scan) and the stores of the
+    // previous tile's copy-out have had the whole tile to come back.  (vmcnt counts loads and stores in one queue: a wait
+    // for the next words at the top of a tile would wait for the copy-out stores issued just before it.)
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t i = j * BLK + threadIdx.x;
+        w[j] = i < np ? c.prov_b[i] : 0xffffffffu;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): the first tile's words (no wait for w inside the loop)
+    for (uint32_t t0 = 0; t0 < np; t0 += FL::TILE) {
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) cnt[threadIdx.x * DPT + q] = 0;
+        uint32_t wn[16];                                     // the next tile's words: in flight until the wait in front of the copy-out
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t i = t0 + FL::TILE + j * BLK + threadIdx.x;
+            wn[j] = i < np ? c.prov_b[i] : 0xffffffffu;
+        }
+        lds_sync();                                          // (also: every wavefront is done with the previous tile's buffer)
+        PG_LAP(16);
+        // Every step below is written for all 16 words of the lane at once and without branches around the LDS operations -- 16
+        // reads in flight and one wait, then 16 returning adds in flight and one wait (a word that is not placed adds 0 to some
+        // counter): compiled from a per-word `if`, every word waited twice for a full LDS round trip
+        uint32_t dr[16];
+        uint32_t live = 0;
+        {
+            uint32_t b1[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) b1[j] = bins16[w[j] & smask];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t i = t0 + j * BLK + threadIdx.x;
+                const bool ok = i < np && (uint32_t)(b1[j] - 1u) < 0xfffeu;        // a bin: not 0 (slot never filled), not 0xffff (out of range)
+                w[j] = ((w[j] >> lb) << vbits) | (b1[j] - 1u);
+                const uint32_t d = (w[j] >> sh.dshift) & dmask;
+                dr[j] = (d << 16) | __hip_atomic_fetch_add(&cnt[d], ok ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                live |= ok ? 1u << j : 0u;
+            }
+        }
+        lds_sync();
+        PG_LAP(17);
+        // this lane's digits: their words of the tile go to a range of the digit's region claimed with one global add
+        unsigned long long g_region[DPT], g_claimed[DPT];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const uint32_t d = threadIdx.x * DPT + q, c_mine = cnt[d];
+            g_region[q] = g_claimed[q] = 0;
+            if (c_mine) {
+                g_region[q] = sh.goff[(uint64_t)d << sh.gb2];
+                g_claimed[q] = atomicAdd(&sh.gcur1[d], (unsigned long long)c_mine);
+            }
+        }
+        scan_digits_blk<DIG, BLK, true>(cnt, start, wave_tot);
+        PG_LAP(18);
+        {
+            uint32_t at[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) at[j] = start[dr[j] >> 16] + (dr[j] & 0xffffu);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((live >> j) & 1u) buf[at[j]] = w[j];
+        }
+#pragma unroll
+        for (int q = 0; q < DPT; ++q)                         // (the wait for global memory; unused for an empty digit)
+            gbase[threadIdx.x * DPT + q] = g_region[q] + g_claimed[q] - start[threadIdx.x * DPT + q];
+        lds_sync();
+        PG_LAP(19);
+        const uint32_t total = start[DIG];
+        // copy-out, four words of the lane at a time (their LDS reads in flight together)
+        for (uint32_t i0 = 0; i0 < total; i0 += 4 * BLK) {
+            uint32_t r[4];
+            unsigned long long g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = buf[i0 + u * BLK + threadIdx.x];            // (< FL::TILE: total <= FL::TILE = 16 blocks)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BLK + threadIdx.x;
+#if PG_DIAG_COUNT & 4
+            asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
+            continue;                                        // (diagnostic: everything but the copy-out's stores)
+#endif
+            if (sh.narrow) {                                 // (the group region implies the rows' upper bits)
+                uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * BLK + threadIdx.x < total) gstore(out16, g[u], 2ull * sh.words_cap, r[u] & 0x7fffu, status);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * BLK + threadIdx.x < total) gstore(sh.words_out, g[u], sh.words_cap, r[u], status);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = wn[j];
+        PG_LAP(20);
+    }
+}
+
+// MERGE (SLOTS form only): the k-mers of a record share their row and, being neighbours in a read, mostly their bin.  The lookup
+// phase then works record-wise: a lane takes ONE record of a batch, fetches the provisional words of its k-mers, turns them into
+// bins and lets every run of equal neighbouring bins travel on as ONE word with a count on top,
+//     word = (run length - 1) << MERGE_CSHIFT | row << vbits | bin,
+// so that ranks, region starts, staging and copy-out are paid per record and per run instead of per occurrence (measured on the
+// bench workload: 0.35 runs per first-probe word).  For that the count loop leaves, per record, the mask of its k-mers that were
+// settled by the first probe inside a row (the `hit` plane: one byte per short record, two per long one) and, per batch of 64
+// records, where the batch's words start (`batch_at`); the words of the general insert, which arrive one by one, fill the
+// bucket's word range from its END and are looked up singly.
+#ifndef PG_MERGE_SLOTS
+#define PG_MERGE_SLOTS 24                                         // (k-mer, batch) register slots of a lane per lookup tile: T = slots / k-mers per record
+#endif
+constexpr int MERGE_CSHIFT = PG_SHUFFLE_COUNT_SHIFT;              // needs row bits + vbits <= 28 (mini_merge_form)
+struct MergeArgs {
+    uint8_t *hit;                                                // bucket b: bytes from (2 off[b] + 8 b) & ~3
+    uint32_t *batch_at;                                          // bucket b: entries from off[b] / 64 + 3 b
+};
+// ---- the record-wise lookups of the MERGE form (see MergeArgs): provisional (row, slot) words -> (run, row, bin) words, scattered
+// by the first digit of their row group into the row shuffle's regions.  Called by a whole workgroup of BLK threads once the
+// bucket's 2-byte bins lie at the start of the dynamic LDS (LookupLds layout): inside the counting kernel while the counts are
+// still there (one GPU), or by mini_lookup_half_kernel once the bins of the merged table have come back from their owners.
+struct MergeCtx {
+    unsigned char *lds;                                          // dynamic LDS (bins16 first)
+    uint32_t smask;
+    int lb, vbits;
+    ShufArgs sh;
+    uint32_t *status;
+    const uint32_t *prov_b;                                      // the bucket's words: [0, np_all - n_ring) by batches, then the singles
+    uint32_t np_all, n_ring;
+    const uint8_t *hit_s, *hit_l;                                // hit masks of the short / long records
+    const uint32_t *bat;                                         // word offsets of the batches (short ones first)
+    uint32_t n_short, n_long, n_sb;                              // records of the two classes; batches of the short class
+    unsigned long long *dbg;                                     // PG_MINI_STAMPS builds: cycle sums of the phases (diagnostic)
+};
+
+// LDS of the MERGE form's lookup phase: the 2-byte bins in front, then TWO buffers of WPL words per lane -- the stage the
+// wavefronts append their run words to, and the buffer the stage is sorted INTO (no word has to sit in a register across the
+// scan: the sort reads the stage twice instead)
+#ifndef PG_MERGE_WPL
+#define PG_MERGE_WPL 12
+#endif
+template <int BLK, int DIG> struct MergeLds {
+    static constexpr int WPL = (BLK == 1024 && DIG == 1024) ? PG_MERGE_WPL : (PG_MERGE_WPL < 10 ? PG_MERGE_WPL : 10);   // (144 KiB with 1024 threads, 72 KiB with 512: two workgroups per CU)
+    static constexpr uint32_t TILE = WPL * BLK;
+    static constexpr uint32_t BUF = BLK == 1024 ? 32 * 1024 : 16 * 1024;        // (the 2-byte bins of the table's slots lie in front)
+    static constexpr uint32_t BUF1 = BUF + 4 * TILE;
+    static constexpr uint32_t CNT = BUF1 + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
+};
+
+template <int CAP, int BLK, int DIG>
+__device__ __forceinline__ void merged_lookup(const MergeCtx &c)
+{
+    // Two stages, repeated until the bucket's words are used up (once or twice per bucket).
+    // A (no barrier inside): every wavefront walks over its share of the work in STEPS of up to 16 word slots per lane -- four
+    //   batches of short records (a lane takes one record of each), one batch of long records, or 1024 singles --: fetch the
+    //   words, turn them into bins, merge the runs of a record, append the step's run words to a stage of FL::TILE words in
+    //   LDS (one returning add per step claims the positions).  The words of the NEXT step and the hit masks / word offsets of the
+    //   one after it are in flight meanwhile, and the wavefronts are at different points of the loop at any time: nobody
+    //   stands still for a memory round trip.
+    // B (when the stage is full or the work is done): the staged words are sorted by the first digit of their row group (WPL per
+    //   lane: rank, scan, place) and copied out to the group regions, one global cursor add per digit.
+    using FL = MergeLds<BLK, DIG>;
+    constexpr int DPT = DIG / BLK, WAVES_B = BLK / 64, WPL = FL::WPL;
+    constexpr int CXS = CAP > SHORT_MAX ? SHORT_MAX : CAP;       // k-mers per short record
+#ifndef PG_MERGE_NS
+#define PG_MERGE_NS 8
+#endif
+    constexpr int NS = PG_MERGE_NS < CAP ? CAP : PG_MERGE_NS;      // word slots of a step
+    constexpr int GS = CAP > SHORT_MAX ? NS / CXS : 0;           // batches of short records per step
+    constexpr uint32_t NONE = 0xffffffffu;                       // (never a word: rows stay below 2^20)
+    static_assert(CAP <= NS && GS * CXS <= NS && GS <= 4, "slots of a step");
+    __shared__ uint32_t staged, valid_end, busy;
+    const uint16_t *bins16 = reinterpret_cast<const uint16_t *>(c.lds);
+    uint32_t *buf = reinterpret_cast<uint32_t *>(c.lds + FL::BUF), *sorted = reinterpret_cast<uint32_t *>(c.lds + FL::BUF1), *cnt = reinterpret_cast<uint32_t *>(c.lds + FL::CNT);
+    uint32_t *start = reinterpret_cast<uint32_t *>(c.lds + FL::START), *wave_tot = reinterpret_cast<uint32_t *>(c.lds + FL::WAVE);
+    unsigned long long *gbase = reinterpret_cast<unsigned long long *>(c.lds + FL::GBASE);
+    const ShufArgs &sh = c.sh;
+    const uint32_t smask = c.smask, np_all = uniform32(c.np_all);
+    const int lb = c.lb, vbits = c.vbits;
+    uint32_t *const status = c.status;
+    const uint32_t *const prov_b = c.prov_b;
+    const uint8_t *const hit_s = c.hit_s, *const hit_l = c.hit_l;
+    const uint32_t *const bat = c.bat;
+    const uint32_t n_short = uniform32(c.n_short), n_long = uniform32(c.n_long);
+    const uint32_t lane = lane_id(), wave = uniform32(threadIdx.x >> 6);
+    const uint32_t dmask = (1u << sh.gb1) - 1u;
+    uint32_t *const wout = sh.words_out;
+#ifdef PG_MINI_STAMPS
+    unsigned long long tl_ = __builtin_amdgcn_s_memtime();
+#define PG_MLAP(K) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&c.dbg[48 + K], now_ - tl_); tl_ = now_; } } while (0)
+#else
+#define PG_MLAP(K) do { } while (0)
+#endif
+    const uint32_t n_sb_all = uniform32(c.n_sb);                 // batches of short records as the count loop numbered them
+    const uint32_t n_sb = GS ? n_sb_all : 0u, n_lb = (n_long + 63u) >> 6, n_ring = uniform32(c.n_ring);
+    const uint32_t n_ss = GS ? (n_sb + GS - 1) / (GS ? GS : 1) : 0u;            // steps of short batches, then one step per long batch, then the singles
+    const uint32_t n_steps = n_ss + n_lb + (n_ring + 64u * NS - 1u) / (64u * NS);
+    const uint32_t *const ringw = prov_b + (np_all - n_ring);          // (scalar base: see uniform32)
+    // Every load below is UNCONDITIONAL, at an index clamped into the buffer, and NOTHING is computed from a loaded value where it
+    // is requested: a load under a per-lane condition is compiled as a branch around it (sixteen of those in a row, each with
+    // the base address reloaded and waited for, took the group one memory round trip at a time), and a select or a shift
+    // right behind a load makes the compiler wait for it there -- the prefetch would be gone.  Values are masked / extracted
+    // where they are USED, a step later.
+    // raw hit-mask words and word offsets of the batches of step `st` (slots 0..3: batches of a short step; slot 0: the long batch)
+    auto fetch_heads = [&](uint32_t st, uint32_t (&hw)[4], uint32_t (&at)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { hw[t] = 0; at[t] = 0; }
+        if (st < n_ss) {                                         // (uniform)
+#pragma unroll
+            for (int t = 0; t < (GS ? GS : 1); ++t) {
+                const uint32_t bq = st * GS + t, bc = bq < n_sb ? bq : 0u;
+                // (through the dword that holds them: see row_hist_kernel on narrow loads)
+                hw[t] = reinterpret_cast<const uint32_t *>(hit_s)[bc * 16u + (lane >> 2)];
+                at[t] = bat[bc];
+            }
+        } else if (st < n_ss + n_lb) {
+            const uint32_t bq = st - n_ss;
+            hw[0] = reinterpret_cast<const uint32_t *>(hit_l)[bq * 32u + (lane >> 1)];
+            at[0] = bat[n_sb_all + bq];
+        }
+    };
+    // the hit masks of this lane's records out of the raw words
+    auto extract_heads = [&](uint32_t st, const uint32_t (&hw)[4], uint32_t (&h)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[t] = 0;
+        if (st < n_ss) {
+#pragma unroll
+            for (int t = 0; t < (GS ? GS : 1); ++t) {
+                const uint32_t bq = st * GS + t;
+                h[t] = (bq < n_sb && bq * 64u + lane < n_short) ? (hw[t] >> (8u * (lane & 3u))) & 0xffu : 0u;
+            }
+        } else if (st < n_ss + n_lb) {
+            const uint32_t bq = st - n_ss;
+            h[0] = bq * 64u + lane < n_long ? (hw[0] >> (16u * (lane & 1u))) & 0xffffu : 0u;
+        }
+    };
+    // the words of step `st`, raw (requested here, masked and used a step later); np_all > 0 here
+    auto fetch_words = [&](uint32_t st, const uint32_t (&h)[4], const uint32_t (&at)[4], uint32_t (&w)[NS]) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) w[i] = NONE;
+        if (st < n_ss) {                                         // (uniform)
+            uint32_t idx[GS ? GS * CXS : 1];
+#pragma unroll
+            for (int t = 0; t < GS; ++t) {
+                uint32_t base = at[t];
+#pragma unroll
+                for (int j = 0; j < CXS; ++j) {
+                    const unsigned long long pmj = __builtin_amdgcn_ballot_w64((h[t] >> j) & 1u);
+                    const uint32_t i = base + lanes_below(pmj);
+                    idx[t * CXS + j] = i < np_all ? i : 0u;
+                    base += (uint32_t)__popcll(pmj);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GS * CXS; ++i) w[i] = prov_b[idx[i]];
+        } else if (st < n_ss + n_lb) {
+            uint32_t idx[CAP];
+            uint32_t base = at[0];
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) {
+                const unsigned long long pmj = __builtin_amdgcn_ballot_w64((h[0] >> j) & 1u);
+                const uint32_t i = base + lanes_below(pmj);
+                idx[j] = i < np_all ? i : 0u;
+                base += (uint32_t)__popcll(pmj);
+            }
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) w[j] = prov_b[idx[j]];
+        } else if (st < n_steps) {
+            const uint32_t i0 = (st - n_ss - n_lb) * (64u * NS) + lane;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) w[u] = ringw[i0 + 64u * u < n_ring ? i0 + 64u * u : 0u];
+        }
+    };
+    // raw words -> bins -> the run words of the step, in place (NONE: no run starts in that slot).  A run = equal neighbouring bins
+    // of ONE record; its first k-mer carries (length - 1) << MERGE_CSHIFT | row << vbits | bin
+    auto process = [&](uint32_t st, const uint32_t (&h)[4], uint32_t (&w)[NS]) {
+        // which slots hold a word of this lane
+        uint32_t have = 0;
+        if (st < n_ss) {
+#pragma unroll
+            for (int t = 0; t < GS; ++t) have |= (h[t] & ((1u << CXS) - 1u)) << (t * CXS);
+        } else if (st < n_ss + n_lb) {
+            have = h[0] & ((1u << CAP) - 1u);
+        } else {
+            const uint32_t i0 = (st - n_ss - n_lb) * (64u * NS) + lane;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) have |= i0 + 64u * u < n_ring ? 1u << u : 0u;
+        }
+        if (st < n_ss + n_lb) {
+            // rows first (they sit in the words), then every slot becomes bin + 1 in place (0: no word, slot never filled, bin out
+            // of range): all reads of the bins in flight together, no second register array
+            uint32_t rows_[4] = {0, 0, 0, 0};
+            if (st < n_ss) {
+#pragma unroll
+                for (int t = 0; t < GS; ++t)
+#pragma unroll
+                    for (int j = 0; j < CXS; ++j) rows_[t] = (have >> (t * CXS + j)) & 1u ? w[t * CXS + j] >> lb : rows_[t];
+            } else {
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) rows_[0] = (have >> j) & 1u ? w[j] >> lb : rows_[0];
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) w[i] = bins16[w[i] & smask];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) w[i] = ((have >> i) & 1u) && (uint32_t)(w[i] - 1u) < 0xfffeu ? w[i] : 0u;
+            if (st < n_ss) {
+#pragma unroll
+                for (int t = 0; t < GS; ++t) {
+                    const uint32_t rowbits = rows_[t] << vbits;
+                    uint32_t len = 0;
+#pragma unroll
+                    for (int j = CXS - 1; j >= 0; --j) {
+                        const uint32_t cur = w[t * CXS + j];
+                        const uint32_t before = j > 0 ? w[t * CXS + (j > 0 ? j - 1 : 0)] : 0u;
+                        const bool head = cur != 0u && cur != before;
+                        w[t * CXS + j] = head ? (len << MERGE_CSHIFT) | rowbits | (cur - 1u) : NONE;
+                        len = (cur != 0u && !head) ? len + 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int i = GS * CXS; i < NS; ++i) w[i] = NONE;
+            } else {
+                const uint32_t rowbits = rows_[0] << vbits;
+                uint32_t len = 0;
+#pragma unroll
+                for (int j = CAP - 1; j >= 0; --j) {
+                    const uint32_t cur = w[j];
+                    const uint32_t before = j > 0 ? w[j > 0 ? j - 1 : 0] : 0u;
+                    const bool head = cur != 0u && cur != before;
+                    w[j] = head ? (len << MERGE_CSHIFT) | rowbits | (cur - 1u) : NONE;
+                    len = (cur != 0u && !head) ? len + 1u : 0u;
+                }
+#pragma unroll
+                for (int i = CAP; i < NS; ++i) w[i] = NONE;
+            }
+        } else {
+            uint32_t b1[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) b1[i] = bins16[w[i] & smask];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const bool ok = ((have >> i) & 1u) && (uint32_t)(b1[i] - 1u) < 0xfffeu;
+                w[i] = ok ? ((w[i] >> lb) << vbits) | (b1[i] - 1u) : NONE;
+            }
+        }
+    };
+    // this thread's digits of a tile: claim their ranges in the group regions (one global add per digit and tile), scan
+    auto claim_and_scan = [&]() {
+        unsigned long long g_region[DPT], g_claimed[DPT];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const uint32_t d = threadIdx.x * DPT + q, c_mine = cnt[d];
+            g_region[q] = g_claimed[q] = 0;
+            if (c_mine) {
+                g_region[q] = sh.goff[(uint64_t)d << sh.gb2];
+                g_claimed[q] = atomicAdd(&sh.gcur1[d], (unsigned long long)c_mine);
+            }
+        }
+        scan_digits_blk<DIG, BLK, true>(cnt, start, wave_tot);
+#pragma unroll
+        for (int q = 0; q < DPT; ++q)                             // (the wait for global memory; unused for an empty digit)
+            gbase[threadIdx.x * DPT + q] = g_region[q] + g_claimed[q] - start[threadIdx.x * DPT + q];
+    };
+    if (np_all == 0u) return;                                    // (uniform: a bucket without a k-mer inside a row)
+    if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }
+    uint32_t step = wave;                                        // this wavefront's next step
+    bool pending = false;                                        // pw[] holds run words that did not fit the stage yet (wave-uniform)
+    uint32_t pw[NS];                                             // the run words of the step in hand
+    uint32_t cw[NS];                                             // the raw words of `step`, in flight or here (not kept across stage B)
+    uint32_t ch[4], cat[4];                                      // hit masks and word offsets of `step`
+    uint32_t nhw[4], nat[4];                                     // raw heads of the step after it (not kept across stage B)
+    {
+        uint32_t hw0[4];
+        fetch_heads(step, hw0, cat);
+        extract_heads(step, hw0, ch);
+    }
+    lds_sync();
+    for (;;) {
+        // the words of `step` (their heads are here) and the heads of the step after it: at the start, and again behind every
+        // stage B, which had the registers
+        fetch_words(step, ch, cat, cw);
+        fetch_heads(step + WAVES_B, nhw, nat);
+        // ---- A
+        for (;;) {
+            if (!pending) {
+                if (step >= n_steps) break;                      // (uniform)
+                const uint32_t st = step;
+                uint32_t ph[4];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) pw[i] = cw[i];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ph[t] = ch[t];
+                step += WAVES_B;
+                extract_heads(step, nhw, ch);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cat[t] = nat[t];
+                fetch_words(step, ch, cat, cw);                  // the next step's words and the heads of the one after it: in flight
+                fetch_heads(step + WAVES_B, nhw, nat);           // while this step is worked on
+                process(st, ph, pw);
+                pending = true;
+            }
+            uint32_t n = 0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) n += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pw[j] != NONE));
+            if (n == 0) { pending = false; continue; }           // (uniform)
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&staged, n);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (at + n > FL::TILE) {                             // the stage is full: this step's words wait for the next round
+                if (lane == 0) atomicMin(&valid_end, at);
+                break;
+            }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(pw[j] != NONE);
+                if (hm == 0ull) continue;                        // (uniform)
+                if (pw[j] != NONE) buf[at + lanes_below(hm)] = pw[j];
+                at += (uint32_t)__popcll(hm);
+            }
+            pending = false;
+        }
+        if (lane == 0 && (pending || step < n_steps)) atomicOr(&busy, 1u);
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) cnt[threadIdx.x * DPT + q] = 0;     // (nobody reads the counters between the placement of one round and here)
+        lds_sync();
+        PG_MLAP(0);                                              // (stage A)
+        const uint32_t n_valid = staged < valid_end ? staged : valid_end;
+        const bool more = busy != 0u;
+        // ---- B: the staged words [0, n_valid), WPL per lane: rank, scan, place into the second buffer, copy out
+        uint32_t rk[WPL];
+        {
+            uint32_t w[WPL];
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) w[j] = buf[j * BLK + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) {
+                const uint32_t i = j * BLK + threadIdx.x;
+                rk[j] = __hip_atomic_fetch_add(&cnt[(w[j] >> sh.dshift) & dmask], i < n_valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        lds_sync();
+        if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }     // (everybody has read them: a barrier lies in between)
+        claim_and_scan();
+        {
+            uint32_t w[WPL], at[WPL];
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) w[j] = buf[j * BLK + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) at[j] = start[(w[j] >> sh.dshift) & dmask] + rk[j];
+#pragma unroll
+            for (int j = 0; j < WPL; ++j)
+                if ((uint32_t)(j * BLK) + threadIdx.x < n_valid) sorted[at[j]] = w[j];
+        }
+        lds_sync();                                              // (the stage is free again: the next round's wavefronts may append)
+        PG_MLAP(1);                                              // (ranks, cursor adds, scan, placement)
+        for (uint32_t i0 = 0; i0 < n_valid; i0 += 4 * BLK) {
+            uint32_t r[4];
+            unsigned long long g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * BLK + threadIdx.x;
+                r[u] = sorted[i < FL::TILE ? i : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BLK + threadIdx.x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * BLK + threadIdx.x < n_valid) gstore(wout, g[u], sh.words_cap, r[u], status);
+        }
+#ifdef PG_MINI_STAMPS
+        if (threadIdx.x == 0) { atomicAdd(&c.dbg[48 + 6], 1ull); atomicAdd(&c.dbg[48 + 7], (unsigned long long)n_valid); }
+#endif
+        PG_MLAP(2);                                              // (copy-out)
+        // (no barrier here: the next round appends to the stage, sorts into `sorted` only behind two more barriers, and gbase /
+        // start are rewritten behind the same)
+        if (!more) break;                                        // (uniform)
+    }
+}
+
+// HALF (N > 1 ranks; SLOTS form, packed slots): the COUNT half of the kernel.  The counts of a rank's own reads are not final --
+// the other ranks hold occurrences of the same k-mers --, so instead of the slice and the lookups the bucket leaves
+//   * its occupied slots (code << 22 | count) in slot order, compacted, in its slab of `ent` (the entries that travel to the
+//     bucket's owner: pg_mini_gather_entries), their number in `fill`, and WHICH slots they are as a bitmap in `occ`;
+//   * what the lookup half needs to find the bucket's provisional words again: where they start (`wbeg`) and how many of them
+//     the general insert wrote from the end of the range (`ring_cnt`).
+// mini_lookup_half_kernel finishes the bucket once the owner has answered with the bins of exactly these entries, in order.
+struct HalfArgs {
+    unsigned long long *ent;                                     // bucket b: entries from b << log2 bucket slots
+    unsigned long long *occ;                                     // bucket b: max(1, bucket slots / 64) words from b * that
+    long long *fill;                                             // [buckets]
+    uint32_t *ring_cnt;                                          // [buckets]
+};
+template <int CAP, bool SLOTS, bool WIDE, int BLK, int DIG, bool MERGE = false, bool HALF = false>
 __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
                                                                const unsigned long long *__restrict__ off,
                                                                const unsigned long long *__restrict__ n_short,
@@ -625,12 +1181,18 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                                                                uint32_t window, uint32_t vsize, int vbits, uint32_t *__restrict__ words,
                                                                uint32_t *__restrict__ prov, unsigned long long *__restrict__ word_cursor,
                                                                unsigned long long *__restrict__ wbeg, unsigned long long *__restrict__ emit_end,
-                                                               ShufArgs sh, uint32_t *status)
+                                                               ShufArgs sh, MergeArgs mg, unsigned long long rec_cap, uint32_t *status, HalfArgs hv = HalfArgs{nullptr, nullptr, nullptr, nullptr})
 {
-    using FL = LookupLds<BLK, DIG>;
-    constexpr int DPT = DIG / BLK;                               // row-group digits per thread
+    static_assert(!MERGE || SLOTS, "merged words are a form of the slot lookups");
+    static_assert(!HALF || (SLOTS && !WIDE), "the count half is a form of the slot lookups on packed slots");
+    // (the plan this launch was given describes another stream: its record count does not fit the record buffers -- nothing is
+    // touched, bit 2 of the status word says so; KmerTable ties its cached plans to the stream, this is the backstop)
+    if (word_cursor[-1] > rec_cap || (*status & PG_STATUS_PLAN_MISMATCH)) {     // (... or the first pass found the plan to be another stream's)
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(status, PG_STATUS_PLAN_MISMATCH);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
-    __shared__ uint32_t emitted;
+    __shared__ uint32_t emitted, emitted_ring;
     __shared__ unsigned long long n_lookups, wbase;
     __shared__ unsigned long long wave_words[(BLK / 64)];
     const uint32_t n_slots = 1u << t.log2_bucket;
@@ -656,14 +1218,18 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #define PG_STAMP(K) do { __syncthreads(); if (threadIdx.x == 0) atomicAdd(&dbg[K], (unsigned long long)(__builtin_amdgcn_s_memtime() - st0)); } while (0)
     // per-wave laps inside the count loop: dbg[32 + K] += time since the previous lap (everything in flight is waited for first)
     unsigned long long wl = st0, wacc[5] = {0, 0, 0, 0, 0};
+#if PG_MINI_STAMPS + 0 >= 2              // (-DPG_MINI_STAMPS=2: laps inside the count loop too -- every lap waits for all memory operations, which slows the loop down several times)
 #define PG_WLAP(K) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
                         wacc[K] += now_ - wl; wl = now_; } while (0)
+#else
+#define PG_WLAP(K) do { (void)wl; (void)wacc; } while (0)
+#endif
 #else
 #define PG_STAMP(K) do { } while (0)
 #define PG_WLAP(K) do { } while (0)
 #endif
     for (uint32_t i = threadIdx.x; i < tab_units; i += BLK) tab[i] = 0ull;
-    if (threadIdx.x == 0) { emitted = 0; n_lookups = 0; }
+    if (threadIdx.x == 0) { emitted = 0; emitted_ring = 0; n_lookups = 0; }
     if (emit_slots) {
         // every occurrence that lies in a row leaves exactly one word: the bucket's word range is claimed before the first word is
         // written (one global add).  The total comes with the records (the second scatter pass tallies it per bucket); without that
@@ -693,6 +1259,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     }
     __syncthreads();
     unsigned long long wb = emit_slots ? wbase : 0ull;
+    // (read from LDS, hence a vector register to the compiler; made a scalar so that the words' addresses are a scalar base + a
+    // 32-bit lane offset instead of a 64-bit sum per lane and load)
+    wb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wb);
     uint32_t *const prov_b = prov + wb;                          // the bucket's words (32-bit positions from here on)
     // words are placed by claiming positions on the bucket's LDS counter `emitted`: ONE returning add per batch of 64 records
     // (all its first-probe hits) and one per general insert round, by lane 0
@@ -701,6 +1270,12 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (lane == 0) at = atomicAdd(&emitted, n_words);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
     };
+    // MERGE: where this bucket's per-record hit masks and per-batch word offsets live (see MergeArgs)
+    const uint32_t n_sb = (uint32_t)((rs - r0 + 63) >> 6);        // batches of short records (the long ones follow)
+    uint8_t *const hit_s = MERGE ? mg.hit + (((uint64_t)2 * (uint64_t)r0 + 8ull * blockIdx.x) & ~3ull) : nullptr;
+    uint8_t *const hit_l = MERGE ? hit_s + (((uint64_t)(rs - r0) + 3ull) & ~3ull) : nullptr;        // 2 bytes per long record
+    uint32_t *const bat = MERGE ? mg.batch_at + ((uint64_t)r0 >> 6) + 3ull * blockIdx.x : nullptr;
+    const uint32_t np_all = (uint32_t)n_lookups;                 // (emit_slots: the bucket's words, known before the first is written)
     PG_STAMP(0);
     bool full = false;
     unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
@@ -717,8 +1292,15 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             const bool put = rw != MINI_ROW_NONE;
             const unsigned long long qm = __ballot(put);
             if (qm) {                                            // (uniform)
-                const uint32_t at = claim((uint32_t)__popcll(qm));
-                if (put) prov_b[at + lanes_below(qm)] = (rw << lb) | (sl & smask);
+                if (MERGE) {                                     // singles: from the end of the bucket's range downwards
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&emitted_ring, (uint32_t)__popcll(qm));
+                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                    if (put) gstore(prov_b, (uint64_t)np_all - 1u - (at + lanes_below(qm)), (uint64_t)np_all, (rw << lb) | (sl & smask), status);
+                } else {
+                    const uint32_t at = claim((uint32_t)__popcll(qm));
+                    if (put) gstore(prov_b, (uint64_t)at + lanes_below(qm), (uint64_t)np_all, (rw << lb) | (sl & smask), status);
+                }
             }
         }
     };
@@ -817,13 +1399,24 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             }
             PG_WLAP(3);                                          // (ring pushes, general inserts)
             if (emit_slots) {
+                if (MERGE) {
+                    // which of this lane's k-mers left a word (one byte per short record, two per long one), and where the
+                    // batch's words start
+                    uint32_t hm = 0;
+#pragma unroll
+                    for (int j = 0; j < CX; ++j) hm |= __builtin_amdgcn_inverse_ballot_w64(pm[j]) ? 1u << j : 0u;
+                    const uint32_t rel = (uint32_t)(i0 - ra) + lane;
+                    if (CX <= 8 && CX < CAP) { if (live) hit_s[rel] = (uint8_t)hm; }
+                    else { if (live) reinterpret_cast<uint16_t *>(hit_l)[rel] = (uint16_t)hm; }
+                    if (lane == 0) bat[(CX < CAP ? 0u : n_sb) + (uint32_t)((i0 - ra) >> 6)] = at;
+                }
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
                 // shuffle do not like runs of equal words).  (Deferring these stores to the next iteration's top, behind its
                 // vmcnt wait, changed nothing: 17.33 ms either way.)
 #pragma unroll
                 for (int j = 0; j < CX; ++j) {
 #if !(PG_DIAG_COUNT & 1)
-                    if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) prov_b[at + lanes_below(pm[j])] = (row << lb) | sl[j];
+                    if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) gstore(prov_b, (uint64_t)at + lanes_below(pm[j]), (uint64_t)np_all, (row << lb) | sl[j], status);
 #endif
                     at += (uint32_t)__popcll(pm[j]);
                 }
@@ -854,6 +1447,63 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #if PG_DIAG_COUNT & 2
     if (emit_slots) return;                                      // (diagnostic: the count phase alone, with or without its stores)
 #endif
+    if (HALF) {
+        // the bucket's occupied slots, in slot order: a bitmap of the occupancy (64 consecutive slots = the lanes of one wavefront:
+        // a ballot), ranks from the popcounts of its words, the entries written to consecutive places (coalesced).  The LDS table
+        // stays as it is until every slot has been read (the bitmap and its scan live behind it, where the rings were).
+        unsigned long long *occ_l = tab + tab_units;             // [n_slots / 64] occupancy words, then as many exclusive ranks (uint32)
+        const uint32_t n_occ = n_slots >= 64u ? n_slots >> 6 : 1u;
+        uint32_t *rank_l = reinterpret_cast<uint32_t *>(occ_l + n_occ);
+        __shared__ uint32_t n_entries;
+        unsigned long long v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t i = q * BLK + threadIdx.x;
+            unsigned long long x = i < n_slots ? tab[i] : 0ull;
+            if (x) {                                             // (the count stops at SAT; the overshoot of concurrent adds is clamped here)
+                uint32_t c = (uint32_t)(x & HASH_CMASK);
+                if (c > HASH_SAT) c = HASH_SAT;
+                x = (x & ~(unsigned long long)HASH_CMASK) | c;
+            }
+            v[q] = x;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(x != 0ull);
+            if (lane == 0 && q * BLK + wave * 64u < (n_slots >= 64u ? n_slots : 64u)) occ_l[(q * BLK + wave * 64u) >> 6] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                                  // exclusive ranks of the occupancy words (at most 256 of them), by one wavefront
+            uint32_t run = 0;
+            for (uint32_t w0 = 0; w0 < n_occ; w0 += 64) {
+                const uint32_t wi = w0 + threadIdx.x;
+                const uint32_t c = wi < n_occ ? (uint32_t)__popcll(occ_l[wi]) : 0u;
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d);
+                    if ((int)threadIdx.x >= d) incl += o;
+                }
+                if (wi < n_occ) rank_l[wi] = run + incl - c;
+                run += __shfl(incl, 63);
+            }
+            if (threadIdx.x == 0) n_entries = run;
+        }
+        __syncthreads();
+        unsigned long long *ent = hv.ent + ((uint64_t)blockIdx.x << t.log2_bucket);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t i = q * BLK + threadIdx.x;
+            if (i < n_slots && v[q]) {
+                const unsigned long long m = occ_l[i >> 6];
+                ent[rank_l[i >> 6] + (uint32_t)__popcll(m & ((1ull << (i & 63u)) - 1ull))] = v[q];
+            }
+        }
+        for (uint32_t wi = threadIdx.x; wi < n_occ; wi += BLK) hv.occ[(uint64_t)blockIdx.x * n_occ + wi] = occ_l[wi];
+        if (threadIdx.x == 0) {
+            hv.fill[blockIdx.x] = (long long)n_entries;
+            hv.ring_cnt[blockIdx.x] = emitted_ring;
+            wbeg[blockIdx.x] = wbase;
+        }
+        return;
+    }
     if (emit_slots) {
         // the packed slice (an empty table needs no clearing: every slot is written), and the table shrinks to 2-byte bins:
         // 0 = slot never filled, 0xffff = bin out of range, else bin + 1.  (Every lane first reads all its slots -- the bins
@@ -891,114 +1541,27 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // the row shuffle's regions (an LDS multisplit per tile of 16 Ki words, one global cursor add per digit and tile): the
         // final words never make a trip of their own through HBM
         unsigned char *lds = reinterpret_cast<unsigned char *>(tab);
-        uint32_t *buf = reinterpret_cast<uint32_t *>(lds + FL::BUF), *cnt = reinterpret_cast<uint32_t *>(lds + FL::CNT);
-        uint32_t *start = reinterpret_cast<uint32_t *>(lds + FL::START), *wave_tot = reinterpret_cast<uint32_t *>(lds + FL::WAVE);
-        unsigned long long *gbase = reinterpret_cast<unsigned long long *>(lds + FL::GBASE);
         const uint32_t np = (uint32_t)n_lookups;
-        const uint32_t dmask = (1u << sh.gb1) - 1u;
+        if (MERGE) {
+            MergeCtx mc;
+            mc.lds = lds; mc.smask = smask; mc.lb = lb; mc.vbits = vbits; mc.sh = sh; mc.status = status;
+            mc.prov_b = prov_b; mc.np_all = np_all; mc.n_ring = emitted_ring;
+            mc.hit_s = hit_s; mc.hit_l = hit_l; mc.bat = bat;
+            mc.n_short = (uint32_t)(rs - r0); mc.n_long = (uint32_t)(r1 - rs); mc.n_sb = n_sb;
 #ifdef PG_MINI_STAMPS
-        unsigned long long tl = __builtin_amdgcn_s_memtime();
-#define PG_LAP(K) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&dbg[K], now_ - tl); tl = now_; } } while (0)
-#else
-#define PG_LAP(K) do { } while (0)
+            mc.dbg = dbg;
 #endif
-        // Software pipeline.  Every barrier in the loop is an LDS-only one (lds_sync), and there is ONE wait for global memory per
-        // tile, in front of the copy-out: by then the next tile's words (requested at the top of the tile), the cursor adds
-        // (requested as soon as the ranks, and with them the digits' counts, exist: in front of the scan) and the stores of the
-        // previous tile's copy-out have had the whole tile to come back.  (vmcnt counts loads and stores in one queue: a wait
-        // for the next words at the top of a tile would wait for the copy-out stores issued just before it.)
-        uint32_t w[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t i = j * BLK + threadIdx.x;
-            w[j] = i < np ? prov_b[i] : 0xffffffffu;
+            merged_lookup<CAP, BLK, DIG>(mc);
+            PG_STAMP(3);
+            return;
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): the first tile's words (no wait for w inside the loop)
-        for (uint32_t t0 = 0; t0 < np; t0 += FL::TILE) {
-#pragma unroll
-            for (int q = 0; q < DPT; ++q) cnt[threadIdx.x * DPT + q] = 0;
-            uint32_t wn[16];                                     // the next tile's words: in flight until the wait in front of the copy-out
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t i = t0 + FL::TILE + j * BLK + threadIdx.x;
-                wn[j] = i < np ? prov_b[i] : 0xffffffffu;
-            }
-            lds_sync();                                          // (also: every wavefront is done with the previous tile's buffer)
-            PG_LAP(16);
-            // Every step below is written for all 16 words of the lane at once and without branches around the LDS operations -- 16
-            // reads in flight and one wait, then 16 returning adds in flight and one wait (a word that is not placed adds 0 to some
-            // counter): compiled from a per-word `if`, every word waited twice for a full LDS round trip
-            uint32_t dr[16];
-            uint32_t live = 0;
-            {
-                uint32_t b1[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) b1[j] = bins16[w[j] & smask];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t i = t0 + j * BLK + threadIdx.x;
-                    const bool ok = i < np && (uint32_t)(b1[j] - 1u) < 0xfffeu;        // a bin: not 0 (slot never filled), not 0xffff (out of range)
-                    w[j] = ((w[j] >> lb) << vbits) | (b1[j] - 1u);
-                    const uint32_t d = (w[j] >> sh.dshift) & dmask;
-                    dr[j] = (d << 16) | __hip_atomic_fetch_add(&cnt[d], ok ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    live |= ok ? 1u << j : 0u;
-                }
-            }
-            lds_sync();
-            PG_LAP(17);
-            // this lane's digits: their words of the tile go to a range of the digit's region claimed with one global add
-            unsigned long long g_region[DPT], g_claimed[DPT];
-#pragma unroll
-            for (int q = 0; q < DPT; ++q) {
-                const uint32_t d = threadIdx.x * DPT + q, c_mine = cnt[d];
-                g_region[q] = g_claimed[q] = 0;
-                if (c_mine) {
-                    g_region[q] = sh.goff[(uint64_t)d << sh.gb2];
-                    g_claimed[q] = atomicAdd(&sh.gcur1[d], (unsigned long long)c_mine);
-                }
-            }
-            scan_digits_blk<DIG, BLK, true>(cnt, start, wave_tot);
-            PG_LAP(18);
-            {
-                uint32_t at[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) at[j] = start[dr[j] >> 16] + (dr[j] & 0xffffu);
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if ((live >> j) & 1u) buf[at[j]] = w[j];
-            }
-#pragma unroll
-            for (int q = 0; q < DPT; ++q)                         // (the wait for global memory; unused for an empty digit)
-                gbase[threadIdx.x * DPT + q] = g_region[q] + g_claimed[q] - start[threadIdx.x * DPT + q];
-            lds_sync();
-            PG_LAP(19);
-            const uint32_t total = start[DIG];
-            // copy-out, four words of the lane at a time (their LDS reads in flight together)
-            for (uint32_t i0 = 0; i0 < total; i0 += 4 * BLK) {
-                uint32_t r[4];
-                unsigned long long g[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) r[u] = buf[i0 + u * BLK + threadIdx.x];            // (< FL::TILE: total <= FL::TILE = 16 blocks)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BLK + threadIdx.x;
-#if PG_DIAG_COUNT & 4
-                asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
-                continue;                                        // (diagnostic: everything but the copy-out's stores)
+        {
+            WordCtx wc;
+            wc.lds = lds; wc.smask = smask; wc.np = np; wc.lb = lb; wc.vbits = vbits; wc.sh = sh; wc.status = status; wc.prov_b = prov_b;
+#ifdef PG_MINI_STAMPS
+            wc.dbg = dbg;
 #endif
-                if (sh.narrow) {                                 // (the group region implies the rows' upper bits)
-                    uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i0 + u * BLK + threadIdx.x < total) out16[g[u]] = (uint16_t)(r[u] & 0x7fffu);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i0 + u * BLK + threadIdx.x < total) sh.words_out[g[u]] = r[u];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) w[j] = wn[j];
-            PG_LAP(20);
+            wordwise_lookup<BLK, DIG>(wc);
         }
         PG_STAMP(3);
         return;
@@ -1139,6 +1702,144 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     if (threadIdx.x == 0) emit_end[blockIdx.x] = wb + emitted;
 }
 
+// ---- N > 1 ranks: the other kernels of the super-k-mer form (pangaea_amd/dist.py: features_sharded_mini)
+//
+// rank:   plan -> A1' -> A2' -> mini_count_kernel<..., HALF>     entries + occupancy per bucket, provisional words
+//         mini_gather_entries_kernel                              entries, bucket-ordered, into the send buffer (owner ranges)
+//         ---- all-to-all: every bucket range to its owner (8 bytes per entry)
+// owner:  mini_merge_bins_kernel                                  per owned bucket: the N parts summed inside LDS -> its slice of the
+//                                                                 global table, and for EVERY entry received its bin (2 bytes), in order
+//         ---- all-to-all back (2 bytes per entry)
+// rank:   mini_lookup_half_kernel                                 bins + occupancy -> the bucket's 2-byte bins in LDS -> lookups of the
+//                                                                 provisional words (as the one-GPU kernel does), row-group scatter
+__global__ __launch_bounds__(BLOCK) void mini_gather_entries_kernel(const unsigned long long *__restrict__ ent, int log2_bucket,
+                                                                    const long long *__restrict__ fill, const long long *__restrict__ dst_elem,
+                                                                    unsigned long long *__restrict__ out)
+{
+    const unsigned long long *src = ent + ((uint64_t)blockIdx.x << log2_bucket);
+    const long long n = fill[blockIdx.x], d0 = dst_elem[blockIdx.x];
+    for (long long i = threadIdx.x; i < n; i += BLOCK) out[d0 + i] = src[i];
+}
+
+// one workgroup per OWNED bucket: part p's entries of owned bucket i lie at recv[p * part_stride + seg[p * (n_owned + 1) + i] ..
+// seg[... + i + 1]) (slot format: canonical code << 22 | count, counts <= SAT); bins_out has the same layout in uint16:
+// bin + 1 of the entry's k-mer in the MERGED table, 0xffff when the bin lies beyond the vector
+__global__ __launch_bounds__(BIG_BLOCK) void mini_merge_bins_kernel(const unsigned long long *__restrict__ recv, long long part_stride,
+                                                                    const long long *__restrict__ seg, int n_parts, int n_owned,
+                                                                    MiniView t, long long bucket0, uint32_t window, uint32_t vsize,
+                                                                    uint16_t *__restrict__ bins_out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    const uint32_t n_slots = 1u << t.log2_bucket, smask = n_slots - 1u;
+    const uint32_t limit = n_slots < MAX_PROBE ? n_slots : MAX_PROBE;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = 0ull;
+    __syncthreads();
+    bool full = false;
+    for (int p = 0; p < n_parts; ++p) {
+        const long long a = seg[(long long)p * (n_owned + 1) + blockIdx.x], b = seg[(long long)p * (n_owned + 1) + blockIdx.x + 1];
+        for (long long e = a + threadIdx.x; e < b; e += BIG_BLOCK) {
+            const unsigned long long x = recv[(long long)p * part_stride + e];
+            const uint64_t code = x >> HASH_CBITS;
+            const uint32_t c = (uint32_t)(x & HASH_CMASK);
+            uint32_t s = mini_slot_hash<false>(code) & smask;
+            bool done = false;
+            for (uint32_t i = 0; i < limit && !done; ++i) {
+                unsigned long long cur = tab[s];
+                if (cur == 0ull) {
+                    cur = atomicCAS(&tab[s], 0ull, x);
+                    if (cur == 0ull) { done = true; break; }
+                }
+                if ((cur >> HASH_CBITS) == code) {               // add, saturating: parts of up to SAT each must not carry into the code
+                    for (;;) {
+                        const uint32_t sum = (uint32_t)(cur & HASH_CMASK) + c;
+                        const unsigned long long nv = (cur & ~(unsigned long long)HASH_CMASK) | (sum > HASH_SAT ? HASH_SAT : sum);
+                        const unsigned long long old = atomicCAS(&tab[s], cur, nv);
+                        if (old == cur) break;
+                        cur = old;
+                    }
+                    done = true;
+                    break;
+                }
+                s = (s + 1) & smask;
+            }
+            full |= !done;
+        }
+    }
+    if (full) atomicOr(status, PG_STATUS_TABLE_FULL);
+    __syncthreads();
+    uint64_t *slice = t.slots + ((uint64_t)(bucket0 + blockIdx.x) << t.log2_bucket);
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+    for (int p = 0; p < n_parts; ++p) {
+        const long long a = seg[(long long)p * (n_owned + 1) + blockIdx.x], b = seg[(long long)p * (n_owned + 1) + blockIdx.x + 1];
+        for (long long e = a + threadIdx.x; e < b; e += BIG_BLOCK) {
+            const uint64_t code = recv[(long long)p * part_stride + e] >> HASH_CBITS;
+            uint32_t s = mini_slot_hash<false>(code) & smask;
+            uint32_t out = 0xffffu;                              // (a k-mer that found no place -- the table is full and reported so -- has no bin)
+            for (uint32_t i = 0; i < limit; ++i) {
+                const unsigned long long cur = tab[s];
+                if (cur == 0ull) break;
+                if ((cur >> HASH_CBITS) == code) {
+                    const uint32_t bin = (uint32_t)(cur & HASH_CMASK) / window;
+                    out = bin < vsize ? bin + 1u : 0xffffu;
+                    break;
+                }
+                s = (s + 1) & smask;
+            }
+            bins_out[(long long)p * part_stride + e] = (uint16_t)out;
+        }
+    }
+}
+
+// (the word-wise lookups; the merged form -- merged_lookup with the hit planes of a MERGE count half -- plugs in here once it
+// is the faster one)
+template <int BLK, int DIG>
+__global__ __launch_bounds__(BLK, 4) void mini_lookup_half_kernel(const unsigned long long *__restrict__ kwords, const unsigned long long *__restrict__ wbeg,
+                                                                const unsigned long long *__restrict__ occ,
+                                                                const uint16_t *__restrict__ bins_in, const long long *__restrict__ bin_elem,
+                                                                int log2_bucket, int vbits, const uint32_t *__restrict__ prov, ShufArgs sh, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t n_slots = 1u << log2_bucket, smask = n_slots - 1u;
+    const uint32_t n_occ = n_slots >= 64u ? n_slots >> 6 : 1u;
+    const uint32_t np_all = (uint32_t)kwords[blockIdx.x];
+    if (np_all == 0u) return;                                    // (uniform: no k-mer of this bucket lies inside a row)
+    // the bucket's 2-byte bins: slot i holds the entry of rank (occupied slots below i), whose bin came back in that order.
+    // Occupancy words and their exclusive ranks go to LDS first (behind the bins and the lookup's areas: the tail of the tile
+    // buffer, which the lookups only use later), two barriers in all
+    uint16_t *bins16 = reinterpret_cast<uint16_t *>(lds);
+    const uint16_t *bi = bins_in + bin_elem[blockIdx.x];
+    unsigned long long *occ_l = reinterpret_cast<unsigned long long *>(lds + LookupLds<BLK, DIG>::BUF);          // [n_occ] words, then [n_occ] ranks
+    uint32_t *rank_l = reinterpret_cast<uint32_t *>(occ_l + n_occ);
+    for (uint32_t wi = threadIdx.x; wi < n_occ; wi += BLK) occ_l[wi] = occ[(uint64_t)blockIdx.x * n_occ + wi];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < n_occ; w0 += 64) {
+            const uint32_t wi = w0 + threadIdx.x;
+            const uint32_t c = wi < n_occ ? (uint32_t)__popcll(occ_l[wi]) : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if ((int)threadIdx.x >= d) incl += o;
+            }
+            if (wi < n_occ) rank_l[wi] = run + incl - c;
+            run += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BLK) {
+        const unsigned long long m = occ_l[i >> 6];
+        bins16[i] = (m >> (i & 63u)) & 1ull ? bi[rank_l[i >> 6] + (uint32_t)__popcll(m & ((1ull << (i & 63u)) - 1ull))] : (uint16_t)0;
+    }
+    __syncthreads();
+    WordCtx wc;
+    wc.lds = lds; wc.smask = smask; wc.np = np_all; wc.lb = log2_bucket; wc.vbits = vbits; wc.sh = sh; wc.status = status;
+    wc.prov_b = prov + wbeg[blockIdx.x];
+    wc.dbg = nullptr;
+    wordwise_lookup<BLK, DIG>(wc);
+}
+
 // ---- workspace of the plan: header | region_tot | region_off | off | hist | cur2 | cur2l | kwords | wbeg | round_row | chunk table
 struct MiniPlan {
     int bits, bits1, bits2;
@@ -1228,6 +1929,37 @@ bool mini_slots_form(const pg_table *t, const pg_rows *rows)
     return rows && rows->n_rows > 0 && rows->n_rows < ((int64_t)1 << (32 - t->log2_bucket_slots)) - 1 && !getenv("PG_MINI_PROBE_TWICE");
 }
 
+// merged lookups (mini_count_kernel<..., MERGE>): the slot form, with room for the run length on top of row and bin.
+// Opt-in (PG_MINI_MERGE=1): bit-identical rows, a third of the words for the row histograms (features stage - 1.1 ms at 10 M
+// pairs), but its lookup phase still takes 2.7-3.3 ms longer than the word-wise one -- not the default
+// until it wins.  PG_MINI_NO_MERGE=1 overrides.
+bool mini_merge_form(const pg_table *t, const pg_rows *rows, int vsize)
+{
+    const char *want = getenv("PG_MINI_MERGE");
+    if (!want || atoi(want) == 0 || getenv("PG_MINI_NO_MERGE")) return false;
+    if (!mini_slots_form(t, rows) || vsize < 1 || rows->n_rows >= ((int64_t)1 << 20)) return false;
+    int vbits = 1, gbits = 0;
+    while ((1 << vbits) < vsize) ++vbits;
+    const int64_t n_groups = (rows->n_rows + 63) >> 6;
+    while (((int64_t)1 << gbits) < n_groups) ++gbits;
+    return vbits + 6 + gbits <= MERGE_CSHIFT;
+}
+
+// the record workspace: [bases A | bases B | meta A | meta B] of `cap` records each, then the planes of the merged lookups --
+// one hit mask per record (bucket b's from byte (2 off[b] + 8 b) & ~3: a byte per short record, two per long one) and one
+// word offset per batch of 64 records (bucket b's from entry off[b] / 64 + 3 b)
+struct MiniRecLayout { size_t cap, hit_off, bat_off, total; };
+MiniRecLayout mini_rec_layout(size_t cap, size_t nb)
+{
+    MiniRecLayout l;
+    l.cap = cap;
+    l.hit_off = 24 * cap;
+    const size_t hit_bytes = (2 * cap + 8 * nb + 256 + 255) / 256 * 256;
+    l.bat_off = l.hit_off + hit_bytes;
+    l.total = l.bat_off + (4 * (cap / 64 + 3 * nb + 8) + 255) / 256 * 256;
+    return l;
+}
+
 int check_mini_rows(const pg_rows *rows, const char *who)
 {
     if (!rows) return PG_OK;
@@ -1248,11 +1980,13 @@ extern "C" int64_t pg_mini_plan_bytes(int64_t n_words, const pg_table *t)
     return (int64_t)p.total;
 }
 
-extern "C" int64_t pg_mini_records_bytes(int64_t n_records)
+extern "C" int64_t pg_mini_records_bytes(int64_t n_records, const pg_table *t)
 {
     if (n_records < 0) return pg_fail(PG_EINVAL, "negative record count");
+    int rc = check_mini(t, "pg_mini_records_bytes");
+    if (rc) return rc;
     const size_t n = ((size_t)n_records + 255) / 256 * 256 + 256;
-    return (int64_t)(2 * n * 12);
+    return (int64_t)mini_rec_layout(n, (size_t)1 << (t->log2_slots - t->log2_bucket_slots)).total;
 }
 
 extern "C" int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize)
@@ -1352,9 +2086,12 @@ extern "C" int pg_mini_wait_first_pass(void *stream)
     return PG_OK;
 }
 
-extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
-                             const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
-                             int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream)
+// `half` (N > 1 ranks): the count half only -- no slice, no lookups; the bucket workgroups leave entries, occupancy and what
+// the lookup half needs (HalfArgs).  `t` is then the rank's LOCAL geometry (the union's buckets, slots for the rank's own
+// k-mers); its slots are never written.
+static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                           const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                           int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream, const HalfArgs *half)
 {
     if (!codes || !valid || !plan_ws || !rec_ws || !status) return pg_fail(PG_EINVAL, "pg_mini_count: null argument");
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_mini_count: bad word range");
@@ -1374,7 +2111,15 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_count: plan workspace of %lld bytes, %lld needed", (long long)plan_ws_bytes, (long long)p.total);
     if ((reinterpret_cast<uintptr_t>(plan_ws) & 255) != 0 || (reinterpret_cast<uintptr_t>(rec_ws) & 255) != 0)
         return pg_fail(PG_EINVAL, "pg_mini_count: workspaces must be 256-byte aligned");
-    if (rec_ws_bytes < 24 * 256 || rec_ws_bytes % 24 != 0) return pg_fail(PG_EINVAL, "pg_mini_count: record workspace size %lld", (long long)rec_ws_bytes);
+    // the largest record capacity (a multiple of 256) whose layout fits the workspace
+    const size_t nb_l = (size_t)1 << p.bits;
+    size_t cap = 0;
+    if (rec_ws_bytes > 0) {
+        cap = (size_t)rec_ws_bytes / 24 / 256 * 256;
+        while (cap >= 256 && mini_rec_layout(cap, nb_l).total > (size_t)rec_ws_bytes) cap -= 256;
+    }
+    if (cap < 256) return pg_fail(PG_EINVAL, "pg_mini_count: record workspace of %lld bytes (pg_mini_records_bytes)", (long long)rec_ws_bytes);
+    const MiniRecLayout rl = mini_rec_layout(cap, nb_l);
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)plan_ws;
     auto *header = (unsigned long long *)(ws + p.header_off);
@@ -1389,7 +2134,6 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     auto *chunk_tab = (unsigned long long *)(ws + p.chunk_off);
     const int nb = 1 << p.bits;
     // record buffers: [bases A | bases B | meta A | meta B], cap records each
-    const size_t cap = (size_t)rec_ws_bytes / 24;
     auto *bases_a = (uint64_t *)rec_ws;
     auto *bases_b = bases_a + cap;
     auto *meta_a = (uint32_t *)(bases_b + cap);
@@ -1414,7 +2158,8 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
             hipLaunchKernelGGL((mini_scatter_kernel<W, DELAY, M, N1_>), dim3((unsigned)p.n_chunks), dim3(S1_BLOCK), lds1, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, \
                                p.bits2, mini_cap(t->k), with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr, \
                                with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr, \
-                               (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride))
+                               (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride, \
+                               (const unsigned long long *)header, (const unsigned long long *)region_off, (unsigned long long)cap, status))
         if (p.bits1 > MINI_BITS1) { PG_MINI_LAUNCH_SCATTER(512) } else { PG_MINI_LAUNCH_SCATTER(256) }
 #undef PG_MINI_LAUNCH_SCATTER
     }
@@ -1427,7 +2172,7 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         const int tiles_h = 32;
         if (word_end > word_begin)
             hipLaunchKernelGGL(mini_bucket_hist_kernel, dim3((unsigned)(tiles_h << p.bits1)), dim3(BLOCK), 0, s, (const uint32_t *)meta_a,
-                               (const unsigned long long *)region_off, p.bits2, tiles_h, hist);
+                               (const unsigned long long *)region_off, p.bits2, tiles_h, hist, (const unsigned long long *)header, (unsigned long long)cap, (const uint32_t *)status);
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)hist, (int64_t)nb, off);
     } else {
         off = region_off;                                   // buckets = regions
@@ -1436,7 +2181,8 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
         if (p.bits2) {
             const int tiles_x = 96;
             hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
-                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l, kwords);
+                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l, kwords,
+                               (const unsigned long long *)header, (unsigned long long)cap, status);
         }
     }
     const bool slots_form = window > 0 && mini_slots_form(t, rows);
@@ -1444,44 +2190,60 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     const unsigned long long *n_short = p.bits2 && mini_cap(t->k) > SHORT_MAX ? (const unsigned long long *)cur2 : (const unsigned long long *)nullptr;
     uint32_t *words_e = window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr;
     uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
-    ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0ull};
+    const MergeArgs mg{(uint8_t *)rec_ws + rl.hit_off, (uint32_t *)((char *)rec_ws + rl.bat_off)};
+    const bool merge = window > 0 && !half && mini_merge_form(t, rows, vsize);
+    if (half && (wide || !(window > 0 && mini_slots_form(t, rows))))
+        return pg_fail(PG_EINVAL, "pg_mini_count_half: needs packed slots (k <= %d), rows and fewer than 2^(32 - log2 bucket slots) of them", PG_HASH_MAX_K);
+    if (half && !p.bits2) return pg_fail(PG_EINVAL, "pg_mini_count_half: needs more than 256 buckets");
+    const HalfArgs hv = half ? *half : HalfArgs{nullptr, nullptr, nullptr, nullptr};
     size_t count_lds = slice_lds;
     // Buckets of at most 2^13 8-byte slots (64 KiB): 512-thread workgroups, TWO per CU -- one can be in its count loop (VALU, waits)
     // while the other is in its lookup phase (LDS throughput).  PG_COUNT_BLOCK=1024: the one-workgroup form for such tables too.
     const char *blk_env = getenv("PG_COUNT_BLOCK");
     const bool many_groups = window > 0 && rows && rows->n_rows > ((int64_t)1 << (PG_SHUFFLE_ONE_PASS_BITS + 6));     // more than 2^10 row groups: 2048 digits
-    const bool half_block = !wide && window > 0 && mini_slots_form(t, rows) && t->log2_bucket_slots <= 13 && !many_groups && !(blk_env && atoi(blk_env) == 1024);
+    // (the count half does no lookups: the row-group digits do not matter to its geometry)
+    const bool half_block = !wide && window > 0 && mini_slots_form(t, rows) && t->log2_bucket_slots <= 13 && (!many_groups || half) && !(blk_env && atoi(blk_env) == 1024);
     if (half_block) count_lds = table_lds + (size_t)(512 / 64) * RING * 12;
     if (slots_form) {
         // the count kernel scatters its words into the row shuffle's group regions itself: offsets and cursors must be ready
         pg_shuffle_ctx ctx;
         if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS))) return rc;
-        sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, ctx.narrow};
+        sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, merge ? 0 : ctx.narrow, ctx.words_cap};
         words_a = ctx.words_in;                          // the provisional words wait in the shuffle's input buffer
-        const size_t lookup_lds = half_block ? LookupLds<512, 1024>::END : sh.gb1 > 10 ? LookupLds<BIG_BLOCK, 2048>::END : LookupLds<BIG_BLOCK, 1024>::END;
+        const size_t lookup_lds = merge ? (half_block ? MergeLds<512, 1024>::END : sh.gb1 > 10 ? MergeLds<BIG_BLOCK, 2048>::END : MergeLds<BIG_BLOCK, 1024>::END)
+                                        : half_block ? LookupLds<512, 1024>::END : sh.gb1 > 10 ? LookupLds<BIG_BLOCK, 2048>::END : LookupLds<BIG_BLOCK, 1024>::END;
         if (sh.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_count: %d first-pass digits of the row shuffle", sh.gb1);
-        if (count_lds < lookup_lds) count_lds = lookup_lds;
+        if (count_lds < lookup_lds && !half) count_lds = lookup_lds;
     }
     unsigned long long *emit_end = window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
-#define PG_MINI_LAUNCH_COUNT_(CAP_, SLOTS_, WIDE_, BLK_, DIG_, LDS_)                                                         \
+#define PG_MINI_LAUNCH_COUNT__(CAP_, SLOTS_, WIDE_, BLK_, DIG_, MERGE_, HALF_, LDS_)                                         \
     do {                                                                                                                    \
-        if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_, DIG_>), LDS_, "pg_mini_count"))) return rc; \
-        hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_, DIG_>), dim3(nb), dim3(BLK_), LDS_, s,              \
+        if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_, DIG_, MERGE_, HALF_>), LDS_, "pg_mini_count"))) return rc; \
+        hipLaunchKernelGGL((mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_, DIG_, MERGE_, HALF_>), dim3(nb), dim3(BLK_), LDS_, s, \
                            (const uint64_t *)(p.bits2 ? bases_b : bases_a), (const uint32_t *)(p.bits2 ? meta_b : meta_a),  \
                            (const unsigned long long *)off, n_short, p.bits2 ? (const unsigned long long *)kwords : (const unsigned long long *)nullptr, \
                            mini_view(t), (uint32_t)window, (uint32_t)vsize,                                                 \
-                           sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, status);                             \
+                           sl.vbits, words_e, words_a, header + 1, wbeg, emit_end, sh, mg, (unsigned long long)cap, status, hv); \
+    } while (0)
+#define PG_MINI_LAUNCH_COUNT_(CAP_, SLOTS_, WIDE_, BLK_, DIG_, MERGE_, LDS_) PG_MINI_LAUNCH_COUNT__(CAP_, SLOTS_, WIDE_, BLK_, DIG_, MERGE_, false, LDS_)
+#define PG_MINI_LAUNCH_SLOTS_(CAP_, WIDE_, BLK_, DIG_)                                                                      \
+    do {                                                                                                                    \
+        if (merge) PG_MINI_LAUNCH_COUNT_(CAP_, true, WIDE_, BLK_, DIG_, true, count_lds);                                    \
+        else PG_MINI_LAUNCH_COUNT_(CAP_, true, WIDE_, BLK_, DIG_, false, count_lds);                                         \
     } while (0)
 #define PG_MINI_LAUNCH_SLOTS(CAP_, WIDE_)                                                                                   \
     do {                                                                                                                    \
-        if (sh.gb1 > 10) PG_MINI_LAUNCH_COUNT_(CAP_, true, WIDE_, BIG_BLOCK, 2048, count_lds);                               \
-        else PG_MINI_LAUNCH_COUNT_(CAP_, true, WIDE_, BIG_BLOCK, 1024, count_lds);                                           \
+        if (sh.gb1 > 10) PG_MINI_LAUNCH_SLOTS_(CAP_, WIDE_, BIG_BLOCK, 2048);                                                \
+        else PG_MINI_LAUNCH_SLOTS_(CAP_, WIDE_, BIG_BLOCK, 1024);                                                            \
     } while (0)
 #define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \
     do {                                                                                                                    \
-        if (wide) { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, true); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, BIG_BLOCK, 1024, slice_lds); } \
-        else if (half_block) PG_MINI_LAUNCH_COUNT_(CAP_, true, false, 512, 1024, count_lds);                                 \
-        else { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, false); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, BIG_BLOCK, 1024, slice_lds); } \
+        if (half) { if (half_block) PG_MINI_LAUNCH_COUNT__(CAP_, true, false, 512, 1024, false, true, count_lds);            \
+                    else PG_MINI_LAUNCH_COUNT__(CAP_, true, false, BIG_BLOCK, 1024, false, true, count_lds); }               \
+        else if (wide) { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, true); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, BIG_BLOCK, 1024, false, slice_lds); } \
+        else if (half_block) PG_MINI_LAUNCH_SLOTS_(CAP_, false, 512, 1024);                                                  \
+        else { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, false); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, BIG_BLOCK, 1024, false, slice_lds); } \
     } while (0)
     switch (mini_cap(t->k)) {                                          // k-mers per record at most (as the first pass cuts them)
     case 1: case 2: case 3: case 4: PG_MINI_LAUNCH_COUNT(4); break;
@@ -1491,8 +2253,134 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
     }
 #undef PG_MINI_LAUNCH_COUNT
 #undef PG_MINI_LAUNCH_SLOTS
+#undef PG_MINI_LAUNCH_SLOTS_
 #undef PG_MINI_LAUNCH_COUNT_
+#undef PG_MINI_LAUNCH_COUNT__
     return check_launch("pg_mini_count");
+}
+
+extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                             const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                             int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream)
+{
+    return mini_count_impl(codes, valid, word_begin, word_end, t, rows, plan_ws, plan_ws_bytes, rec_ws, rec_ws_bytes, window, vsize, shuffle_ws,
+                           shuffle_ws_bytes, status, stream, nullptr);
+}
+
+// ---- N > 1 ranks (see the kernels above): workspace of the count half: entry slabs | occupancy bitmaps | ring counts
+namespace {
+struct MiniHalfLayout { size_t ent_off, occ_off, ring_off, total; };
+MiniHalfLayout mini_half_layout(const pg_table *t)
+{
+    const size_t nb = (size_t)1 << (t->log2_slots - t->log2_bucket_slots), n_slots = (size_t)1 << t->log2_bucket_slots;
+    const size_t n_occ = n_slots >= 64 ? n_slots / 64 : 1;
+    MiniHalfLayout l;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    l.ent_off = take(nb * n_slots * 8);
+    l.occ_off = take(nb * n_occ * 8);
+    l.ring_off = take(nb * 4);
+    l.total = o;
+    return l;
+}
+}  // namespace
+
+extern "C" int64_t pg_mini_half_bytes(const pg_table *local)
+{
+    int rc = check_mini(local, "pg_mini_half_bytes");
+    if (rc) return rc;
+    return (int64_t)mini_half_layout(local).total;
+}
+
+extern "C" int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *local,
+                                  const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                                  int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *half_ws, int64_t half_ws_bytes,
+                                  int64_t *fill, uint32_t *status, void *stream)
+{
+    int rc = check_mini(local, "pg_mini_count_half");
+    if (rc) return rc;
+    if (!half_ws || !fill) return pg_fail(PG_EINVAL, "pg_mini_count_half: null argument");
+    const MiniHalfLayout hl = mini_half_layout(local);
+    if ((int64_t)hl.total > half_ws_bytes || (reinterpret_cast<uintptr_t>(half_ws) & 255) != 0)
+        return pg_fail(PG_EINVAL, "pg_mini_count_half: workspace of %lld bytes (256-byte aligned), %lld needed", (long long)half_ws_bytes, (long long)hl.total);
+    char *hw = (char *)half_ws;
+    const HalfArgs hv{(unsigned long long *)(hw + hl.ent_off), (unsigned long long *)(hw + hl.occ_off), (long long *)fill, (uint32_t *)(hw + hl.ring_off)};
+    return mini_count_impl(codes, valid, word_begin, word_end, local, rows, plan_ws, plan_ws_bytes, rec_ws, rec_ws_bytes, window, vsize, shuffle_ws,
+                           shuffle_ws_bytes, status, stream, &hv);
+}
+
+extern "C" int pg_mini_gather_entries(const pg_table *local, const void *half_ws, int64_t half_ws_bytes, const int64_t *fill,
+                                      const int64_t *dst_elem, uint64_t *out, void *stream)
+{
+    int rc = check_mini(local, "pg_mini_gather_entries");
+    if (rc) return rc;
+    if (!half_ws || !fill || !dst_elem || !out) return pg_fail(PG_EINVAL, "pg_mini_gather_entries: null argument");
+    const MiniHalfLayout hl = mini_half_layout(local);
+    if ((int64_t)hl.total > half_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_gather_entries: workspace does not match the table");
+    const unsigned nb = 1u << (local->log2_slots - local->log2_bucket_slots);
+    hipLaunchKernelGGL(mini_gather_entries_kernel, dim3(nb), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const unsigned long long *)((const char *)half_ws + hl.ent_off), local->log2_bucket_slots, (const long long *)fill,
+                       (const long long *)dst_elem, (unsigned long long *)out);
+    return check_launch("pg_mini_gather_entries");
+}
+
+extern "C" int pg_mini_merge_bins(const uint64_t *recv, int64_t part_stride, const int64_t *seg, int n_parts, const pg_table *t,
+                                  int64_t bucket_begin, int64_t bucket_end, int window, int vsize, uint16_t *bins_out, uint32_t *status, void *stream)
+{
+    int rc = check_mini(t, "pg_mini_merge_bins");
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_MINI) return pg_fail(PG_EINVAL, "pg_mini_merge_bins: packed mini tables only");
+    const int64_t nb = (int64_t)1 << (t->log2_slots - t->log2_bucket_slots);
+    if (!recv || !seg || !bins_out || !status || n_parts < 1 || bucket_begin < 0 || bucket_end < bucket_begin || bucket_end > nb || window < 1 || vsize < 1)
+        return pg_fail(PG_EINVAL, "pg_mini_merge_bins: bad arguments");
+    if (bucket_end == bucket_begin) return PG_OK;
+    const size_t lds = (size_t)8 << t->log2_bucket_slots;
+    if ((rc = raise_lds_limit((const void *)mini_merge_bins_kernel, lds, "pg_mini_merge_bins"))) return rc;
+    hipLaunchKernelGGL(mini_merge_bins_kernel, dim3((unsigned)(bucket_end - bucket_begin)), dim3(BIG_BLOCK), lds, (hipStream_t)stream,
+                       (const unsigned long long *)recv, (long long)part_stride, (const long long *)seg, n_parts, (int)(bucket_end - bucket_begin),
+                       mini_view(t), (long long)bucket_begin, (uint32_t)window, (uint32_t)vsize, bins_out, status);
+    return check_launch("pg_mini_merge_bins");
+}
+
+extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
+                                   int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *half_ws, int64_t half_ws_bytes,
+                                   const uint16_t *bins_in, const int64_t *bin_elem, uint32_t *status, void *stream)
+{
+    int rc = check_mini(local, "pg_mini_lookup_half");
+    if (rc) return rc;
+    if (!rows || !plan_ws || !shuffle_ws || !half_ws || !bins_in || !bin_elem || !status) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: null argument");
+    if ((rc = check_mini_rows(rows, "pg_mini_lookup_half"))) return rc;
+    if (local->kind != PG_TABLE_MINI || !mini_slots_form(local, rows)) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: not the slot form");
+    MiniPlan p;
+    plan_mini(local, n_words_counted, &p);
+    if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: plan workspace does not match n_words_counted");
+    const MiniHalfLayout hl = mini_half_layout(local);
+    if ((int64_t)hl.total > half_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: workspace does not match the table");
+    const char *ws = (const char *)plan_ws;
+    const auto *kwords = (const unsigned long long *)(ws + p.kw_off);
+    const auto *wbeg = (const unsigned long long *)(ws + p.wbeg_off);
+    if (!p.bits2) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: needs more than 256 buckets");
+    // the row shuffle's regions: offsets and cursors as the count half's launch prepared them (same layout call)
+    pg_shuffle_ctx ctx;
+    if ((rc = pg_internal_shuffle_prepare(n_words_counted * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS))) return rc;
+    if (ctx.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: %d first-pass digits of the row shuffle", ctx.gb1);
+    const ShufArgs sh{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, ctx.narrow, ctx.words_cap};
+    const unsigned nb = 1u << p.bits;
+    const auto *occ = (const unsigned long long *)((const char *)half_ws + hl.occ_off);
+    const bool half_block = local->log2_bucket_slots <= 13 && ctx.gb1 <= 10;
+    hipStream_t s = (hipStream_t)stream;
+#define PG_LOOKUP_HALF(BLK_, DIG_)                                                                                          \
+    do {                                                                                                                    \
+        const size_t lds_ = LookupLds<BLK_, DIG_>::END;                                                                     \
+        if ((rc = raise_lds_limit((const void *)(mini_lookup_half_kernel<BLK_, DIG_>), lds_, "pg_mini_lookup_half"))) return rc; \
+        hipLaunchKernelGGL((mini_lookup_half_kernel<BLK_, DIG_>), dim3(nb), dim3(BLK_), lds_, s, kwords, wbeg, occ, bins_in, (const long long *)bin_elem, \
+                           local->log2_bucket_slots, ctx.vbits, (const uint32_t *)ctx.words_in, sh, status);                \
+    } while (0)
+    if (half_block) PG_LOOKUP_HALF(512, 1024);
+    else if (ctx.gb1 > 10) PG_LOOKUP_HALF(BIG_BLOCK, 2048);
+    else PG_LOOKUP_HALF(BIG_BLOCK, 1024);
+#undef PG_LOOKUP_HALF
+    return check_launch("pg_mini_lookup_half");
 }
 
 extern "C" int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int vsize, int32_t *abd_out,
@@ -1509,7 +2397,9 @@ extern "C" int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *
     if ((reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_abundance_from_emitted: workspace must be 256-byte aligned");
     if (mini_slots_form(t, rows))        // the count kernel has scattered the words by row group already
         return pg_internal_shuffle_finish(n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream,
-                                          pg_internal_shuffle_is_narrow(n_words_counted * 32, rows->n_rows, vsize, MINI_ONE_PASS_BITS), MINI_ONE_PASS_BITS);
+                                          mini_merge_form(t, rows, vsize) ? PG_SHUFFLE_WORDS_COUNTED
+                                          : pg_internal_shuffle_is_narrow(n_words_counted * 32, rows->n_rows, vsize, MINI_ONE_PASS_BITS) ? PG_SHUFFLE_WORDS_NARROW
+                                          : PG_SHUFFLE_WORDS_PLAIN, MINI_ONE_PASS_BITS);
     const auto *wbeg = (const unsigned long long *)((const char *)plan_ws + p.wbeg_off);
     return pg_internal_shuffle_rows(wbeg, 1 << p.bits, n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
 }

@@ -71,6 +71,18 @@ __device__ __forceinline__ void lds_sync()
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 
+// A global store that names the capacity (in elements) of the buffer it writes into.  Ordinary builds: a plain store.  Checked
+// builds (make CHECKED=1 -> libpangaea_feat_checked.so, PANGAEA_LIB=checked loads it; the GPU suite's super-k-mer cases run
+// through it once): an index outside the buffer is NOT written and sets PG_STATUS_BOUNDS -- a kernel whose indexing is wrong
+// fails a test instead of faulting the GPU (a memory fault of one process can reset every GPU of the host).
+template <class T, class V> __device__ __forceinline__ void gstore(T *p, uint64_t idx, uint64_t cap, V v, uint32_t *status)
+{
+#ifdef PG_CHECKED
+    if (idx >= cap) { atomicOr(status, PG_STATUS_BOUNDS); return; }
+#endif
+    p[idx] = (T)v;
+}
+
 // per-digit exclusive scan of table[d][0..n) in place, plus base[d << base_shift]; totals[d] (may be NULL) = row sum.
 // One workgroup per digit.
 __global__ __launch_bounds__(BIG_BLOCK) void digit_scan_kernel(unsigned long long *__restrict__ table, int64_t n,

@@ -29,12 +29,19 @@ struct pg_shuffle_ctx {
     uint32_t *words_in, *words_out;
     int vbits, gb1, gb2, dshift;
     int narrow;
+    unsigned long long words_cap;                 // elements (4-byte words) of words_in / words_out
 };
+// word forms a lookup pass may leave for finish: plain 4-byte (row << vbits | bin), narrow 2-byte (above), or COUNTED 4-byte:
+// (n - 1) << PG_SHUFFLE_COUNT_SHIFT | row << vbits | bin stands for n equal words (needs row bits + vbits <= the shift)
+#define PG_SHUFFLE_WORDS_PLAIN 0
+#define PG_SHUFFLE_WORDS_NARROW 1
+#define PG_SHUFFLE_WORDS_COUNTED 2
+#define PG_SHUFFLE_COUNT_SHIFT 28
 int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);       // what prepare will put into ctx->narrow
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
                                 pg_shuffle_ctx *ctx, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
 int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
-                               int narrow, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
+                               int word_form, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
 int pg_internal_shuffle_rows(const unsigned long long *in_begin, int nb, int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out,
                              void *workspace, int64_t workspace_bytes, void *stream);
 

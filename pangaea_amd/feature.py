@@ -105,6 +105,17 @@ def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | Non
     return part
 
 
+def _sharded_mini_applies(stream, plan, k, window, vsize, lowercase_is_base) -> bool:
+    """may the multi-rank super-k-mer form (``dist.MiniSharded``) take this input?  Packed slots (13 <= k <= 21), rows the
+    partition records can name, exact bins, no soft-masked / quality-masked planes -- and the SAME answer on every rank."""
+    from . import _lib
+    ok = (_lib.MINI_MIN_K <= k <= _lib.HASH_MAX_K and plan.shuffle_ok and 0 < plan.n_rows < (1 << 17)
+          and 1 <= vsize <= _lib.SHUFFLE_MAX_VSIZE and window >= 1 and window * vsize <= _lib.HASH_COUNT_SAT
+          and stream.table_valid(lowercase_is_base) is stream.valid and stream.rows_inside_table
+          and os.environ.get("PANGAEA_NO_MINI", "0") in ("", "0"))
+    return pdist.everyone(ok)
+
+
 def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window: int, vsize: int, min_len: int,
                      device=None, want_tnf: bool = True, want_abd: bool = True, table: KmerTable | None = None,
                      stream_cache: str | None = None, lowercase_is_base: bool = True, gather: str = "all"):
@@ -122,11 +133,16 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     stream = _ingest(reads1, reads2, world, stream_cache).to(device)
     rows = stream.rows(min_len)
     plan = Plan(rows, device)
-    if want_abd and table is None:
-        table = (pdist.count_kmers_sharded(stream, k, rows=plan, lowercase_is_base=lowercase_is_base) if world > 1
-                 else count_kmers(stream, k, rows=plan, emit=(window, vsize), lowercase_is_base=lowercase_is_base))
-    tnf, abd = features(stream, plan, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
-                        window=window, vsize=vsize)
+    tnf = abd = None
+    if want_abd and table is None and world > 1 and _sharded_mini_applies(stream, plan, k, window, vsize, lowercase_is_base):
+        # several ranks: the super-k-mer pipeline on every rank's own reads, entries to bucket owners, bins back
+        tnf, abd, _ = pdist.features_sharded_mini(stream, plan, k, k_tnf if want_tnf else None, window, vsize)
+    else:
+        if want_abd and table is None:
+            table = (pdist.count_kmers_sharded(stream, k, rows=plan, lowercase_is_base=lowercase_is_base) if world > 1
+                     else count_kmers(stream, k, rows=plan, emit=(window, vsize), lowercase_is_base=lowercase_is_base))
+        tnf, abd = features(stream, plan, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
+                            window=window, vsize=vsize)
     names = list(rows.names)
     host = lambda t: t.cpu().numpy() if t is not None else None
     if world == 1 or gather == "none":

@@ -61,6 +61,8 @@ class KmerTable:
         self._mini_next = None           # (key, plan workspace, event, rows) of a plan computed ahead on a side stream
         self._mini_spare = None          # the plan workspace that is neither in use nor being filled
         self._mini_rec_ws = None
+        self._half = None                # (fill, n_words, rows, window, vsize) between count_half and lookup_half (N > 1 ranks)
+        self._half_ws = None
 
     # ------------------------------------------------------------------ construction
 
@@ -268,7 +270,7 @@ class KmerTable:
         if self.kind in ("mini", "miniw"):
             if deferred_group is not None:
                 raise ValueError("mini tables have no deferred form")
-            return self._count_mini(stream, word_begin, word_end, valid_ptr, rows, rows_arg, emit, lenient, check)
+            return self._count_mini(stream, word_begin, word_end, table_plane, rows, rows_arg, emit, lenient, check)
         if deferred_group is not None:
             if not self.can_defer(word_end - word_begin):
                 raise ValueError("deferred counting needs a fresh bucketed table with more than 256 buckets and a single pass")
@@ -327,9 +329,32 @@ class KmerTable:
             self.check_status()
         return self
 
-    def _count_mini(self, stream, word_begin, word_end, valid_ptr, rows, rows_arg, emit, lenient, check):
+    @staticmethod
+    def _plan_key(codes: torch.Tensor, plane: torch.Tensor, word_begin: int, word_end: int, keep, lenient: bool, log2_slots: int, log2_bucket: int):
+        """what a cached partition plan is valid for.  Addresses alone would not do: after the stream is freed the caching
+        allocator hands the same address to the next stream of that size, and tensors can be rewritten in place -- so the key
+        carries the tensors' version counters, and the cache entry holds the tensors (and the rows) themselves, which keeps
+        their storage from being recycled while the plan is kept.  (pg_mini_count checks the plan's record count against the
+        record workspace as well: PG_STATUS_PLAN_MISMATCH.)"""
+        return (codes.data_ptr(), codes._version, plane.data_ptr(), plane._version, word_begin, word_end, id(keep), bool(lenient),
+                log2_slots, log2_bucket)
+
+    def count_half(self, stream: ReadStream, rows: "Plan", emit: tuple, check: bool = True) -> "KmerTable":
+        """N > 1 ranks (``dist.MiniSharded``): the COUNT half of the super-k-mer pipeline on this rank's reads.  This table object
+        only carries the rank's LOCAL geometry (the union's bucket count, slots for the rank's own k-mers): its slots are never
+        written.  Left behind for ``dist``: the buckets' entries and occupancy (``_half``), the provisional words of the rows."""
+        if self.kind != "mini":
+            raise ValueError("count_half() is for packed mini tables (13 <= k <= 21)")
+        _require_gpu(stream.codes, "the read stream")
+        plane = stream.table_valid(False)
+        if plane is not stream.valid or not stream.rows_inside_table:
+            raise ValueError("count_half() takes plain streams (no soft-masked / quality-masked planes)")
+        return self._count_mini(stream, 0, stream.n_words, plane, rows, lambda plan: C.byref(plan.rows_desc), emit, False, check, half=True)
+
+    def _count_mini(self, stream, word_begin, word_end, table_plane, rows, rows_arg, emit, lenient, check, half=False):
         """the super-k-mer pipeline (pg_mini_plan + pg_mini_count): a fresh table, one piece.  The partition plan depends on
         the stream, the rows and the geometry only and is kept: counting the same range again skips pg_mini_plan."""
+        valid_ptr = table_plane.data_ptr()
         if not self._empty:
             raise ValueError("mini tables are built by ONE count of a fresh (or reset) table")
         L = _lib.load()
@@ -339,16 +364,17 @@ class KmerTable:
             raise ValueError("mini tables need sorted, disjoint, non-empty rows (at most 2^21 - 2 of them)")
         fuse = (emit is not None and keep is not None and n_words > 0 and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1
                 and (self.kind == "miniw" or emit[0] * emit[1] <= _lib.HASH_COUNT_SAT))
-        key = (stream.codes.data_ptr(), valid_ptr, word_begin, word_end, id(keep), bool(lenient), self.log2_slots, self.log2_bucket)
+        key = self._plan_key(stream.codes, table_plane, word_begin, word_end, keep, lenient, self.log2_slots, self.log2_bucket)
+        held = (stream.codes, table_plane)               # (kept with the plan: see _plan_key)
         with torch.cuda.device(self.device):
             if (self._mini_plan is None or self._mini_plan[0] != key) and self._mini_next is not None and self._mini_next[0] == key:
                 # a plan computed ahead (``prefetch_plan``): the count waits for it on the device; its record count is read here
-                _, ws, event, _ = self._mini_next
+                _, ws, event, _ = self._mini_next[:4]
                 torch.cuda.current_stream(self.device).wait_event(event)
                 event.synchronize()
                 if self._mini_plan is not None:
                     self._mini_spare = self._mini_plan[1]
-                self._mini_plan = (key, ws, int(ws[:8].view(torch.int64).item()), keep)
+                self._mini_plan = (key, ws, int(ws[:8].view(torch.int64).item()), keep, held)
                 self._mini_next = None
             if self._mini_plan is None or self._mini_plan[0] != key:
                 need = _lib.check(L.pg_mini_plan_bytes(n_words, self.desc()))
@@ -361,9 +387,9 @@ class KmerTable:
                 n_records = int(ws[:8].view(torch.int64).item())          # (host sync; once per plan)
                 if self._mini_plan is not None:
                     self._mini_spare = self._mini_plan[1]
-                self._mini_plan = (key, ws, n_records, keep)
-            _, plan_ws, n_records, _ = self._mini_plan
-            need = _lib.check(L.pg_mini_records_bytes(n_records))
+                self._mini_plan = (key, ws, n_records, keep, held)
+            _, plan_ws, n_records = self._mini_plan[:3]
+            need = _lib.check(L.pg_mini_records_bytes(n_records, self.desc()))
             if self._mini_rec_ws is None or self._mini_rec_ws.numel() != need:
                 self._mini_rec_ws = None
                 self._mini_rec_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -375,15 +401,45 @@ class KmerTable:
                     self._shuffle_ws = None
                     self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
                 sws_ptr, sws_n = self._shuffle_ws.data_ptr(), self._shuffle_ws.numel()
-            _lib.check(L.pg_mini_count(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
-                                       plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
-                                       window, vsize, sws_ptr, sws_n, self.status.data_ptr(), _stream_ptr(self.device)))
+            if half:
+                if not fuse:
+                    raise ValueError("count_half() needs rows and abundance parameters")
+                need = _lib.check(L.pg_mini_half_bytes(self.desc()))
+                if getattr(self, "_half_ws", None) is None or self._half_ws.numel() != need:
+                    self._half_ws = None
+                    self._half_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                fill = torch.empty(self.n_buckets, dtype=torch.int64, device=self.device)
+                _lib.check(L.pg_mini_count_half(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
+                                                plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
+                                                window, vsize, sws_ptr, sws_n, self._half_ws.data_ptr(), self._half_ws.numel(),
+                                                fill.data_ptr(), self.status.data_ptr(), _stream_ptr(self.device)))
+                self._half = (fill, n_words, keep, window, vsize)
+            else:
+                _lib.check(L.pg_mini_count(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
+                                           plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
+                                           window, vsize, sws_ptr, sws_n, self.status.data_ptr(), _stream_ptr(self.device)))
         self._empty = False
-        self._records = (keep, n_words) if fuse else None
-        self._emitted = (window, vsize) if fuse else None
+        self._records = (keep, n_words) if fuse and not half else None
+        self._emitted = (window, vsize) if fuse and not half else None
         if check:
             self.check_status()
         return self
+
+    def lookup_half(self, bins: torch.Tensor, bin_elem: torch.Tensor) -> None:
+        """N > 1 ranks: finish a ``count_half`` -- ``bins`` (int16 view of what the bucket owners sent back: bin + 1 of every entry in
+        the merged table, in the order the entries were sent), ``bin_elem[b]`` = where bucket b's bins start -- lookups of the
+        provisional words and the row-group scatter; ``features`` then reads the rows from the shuffled words"""
+        fill, n_words, keep, window, vsize = self._half
+        assert bins.dtype == torch.int16 and bin_elem.dtype == torch.int64 and bin_elem.numel() == self.n_buckets
+        L = _lib.load()
+        plan_ws = self._mini_plan[1]
+        with torch.cuda.device(self.device):
+            _lib.check(L.pg_mini_lookup_half(self.desc(), C.byref(keep.rows_desc), plan_ws.data_ptr(), plan_ws.numel(), n_words, vsize,
+                                             self._shuffle_ws.data_ptr(), self._shuffle_ws.numel(), self._half_ws.data_ptr(), self._half_ws.numel(),
+                                             bins.data_ptr(), bin_elem.data_ptr(), self.status.data_ptr(), _stream_ptr(self.device)))
+        self._records = (keep, n_words)
+        self._emitted = (window, vsize)
+        self._half = None
 
     def prefetch_plan(self, stream: ReadStream, rows: "Plan | None", side: "torch.cuda.Stream",
                       after: "torch.cuda.Event | None" = None) -> None:
@@ -398,7 +454,7 @@ class KmerTable:
         L = _lib.load()
         keep = rows if (rows is not None and rows.shuffle_ok and rows.n_rows <= _lib.MINI_MAX_ROWS) else None
         n_words = stream.n_words
-        key = (stream.codes.data_ptr(), stream.valid.data_ptr(), 0, n_words, id(keep), False, self.log2_slots, self.log2_bucket)
+        key = self._plan_key(stream.codes, stream.valid, 0, n_words, keep, False, self.log2_slots, self.log2_bucket)
         need = _lib.check(L.pg_mini_plan_bytes(n_words, self.desc()))
         ws = self._mini_spare if self._mini_spare is not None and self._mini_spare.numel() == need else None
         self._mini_spare = None
@@ -423,7 +479,7 @@ class KmerTable:
             event = torch.cuda.Event()
             event.record(side)
         ws.record_stream(side)
-        self._mini_next = (key, ws, event, keep)
+        self._mini_next = (key, ws, event, keep, (stream.codes, stream.valid))
 
     def can_shuffle(self, plan: "Plan", window: int, vsize: int) -> bool:
         """can ``abundance_from_records`` build the rows of this plan (instead of table lookups)?"""
@@ -460,7 +516,16 @@ class KmerTable:
         return out
 
     def check_status(self) -> None:
-        if self.kind != "dense" and int(self.status[0].item()) != 0:
+        """raise what the kernels reported in the status word (include/pangaea_feat.h: PG_STATUS_*)"""
+        if self.kind == "dense":
+            return
+        st = int(self.status[0].item())
+        if st & _lib.STATUS_BOUNDS:
+            raise RuntimeError("a kernel of the checked build was about to store outside its buffer (PG_STATUS_BOUNDS): the results are incomplete")
+        if st & _lib.STATUS_PLAN_MISMATCH:
+            self._mini_plan = None
+            raise RuntimeError("the partition plan did not describe this stream (PG_STATUS_PLAN_MISMATCH): nothing was counted")
+        if st != 0:
             raise _lib.PangaeaError(_lib.PG_ETABLEFULL, f"hash table with 2^{self.log2_slots} slots is full")
 
     def merge(self, pairs: torch.Tensor, check: bool = True, pending_ok: bool = False) -> "KmerTable":

@@ -243,3 +243,70 @@ def write_fastq(stream: ReadStream, cfg: SynthConfig, path: str, n_pairs: int | 
                 out.append(f"{h1}\n{txt[o:o + L]}\n+\n{qual}\n{h2}\n{txt[o + L + 1:o + 2 * L + 1]}\n+\n{qual}\n")
             f.write("".join(out))
     return n
+
+
+def write_fastq_fast(stream: ReadStream, cfg: SynthConfig, path: str, n_pairs: int | None = None, chunk_pairs: int = 1 << 17) -> int:
+    """``write_fastq(style="10x")`` for files of BASELINE size (10 M pairs = 6.9 GB): the same reads, barcodes and record
+    structure, built as fixed-width byte matrices with tensor operations on the stream's device instead of one formatted
+    string per pair (minutes -> seconds).  The only difference is the read NAME, zero-padded here
+    (``@r00001234 BX:Z:<barcode>-1``): runs, rows and every character of the packed stream come out the same.
+    Fixed pairs-per-barcode mode only; returns pairs written."""
+    if barcode_bounds(cfg) is not None:
+        raise ValueError("write_fastq_fast is for the fixed pairs-per-barcode mode")
+    n = cfg.n_pairs if n_pairs is None else min(n_pairs, cfg.n_pairs)
+    cpp, L, P = cfg.chars_per_pair, cfg.read_len, cfg.pairs_per_barcode
+    dev = stream.device
+    first_bc = cfg.first_pair // P
+    n_bc_used = max(1, min(cfg.n_barcodes, (n + P - 1) // P))
+    # the barcode names of barcode_name(), all at once: 16 bases of a hash + 7 digits
+    b = torch.arange(first_bc, first_bc + n_bc_used, dtype=torch.int64, device=dev)
+    h = _mix(cfg.seed * 7919 + 13 * b + 5)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    names = torch.empty((n_bc_used, 23), dtype=torch.uint8, device=dev)
+    for i in range(16):
+        names[:, i] = acgt[(_lsr(h, 2 * i) & 3)]
+    for i in range(7):
+        names[:, 16 + i] = ((b // 10 ** (6 - i)) % 10 + 48).to(torch.uint8)
+    n_barcoded = min(n, P * cfg.n_barcodes)
+    lut = torch.tensor(list(b"ACTG"), dtype=torch.uint8, device=dev)          # codes A0 C1 T2 G3
+    sh2 = (2 * torch.arange(32, dtype=torch.int64, device=dev))[None, :]
+    sh1 = torch.arange(32, dtype=torch.int64, device=dev)[None, :]
+
+    def chars(c0: int, c1: int) -> torch.Tensor:
+        w0, w1 = c0 // 32, (c1 + 31) // 32
+        c = stream.codes[w0:w1]
+        v = stream.valid[w0:w1].to(torch.int64)
+        txt = lut[((c[:, None] >> sh2) & 3)]
+        txt = torch.where(((v[:, None] >> sh1) & 1).bool(), txt, torch.full_like(txt, ord("N")))
+        return txt.reshape(-1)[c0 - 32 * w0:c1 - 32 * w0]
+
+    def block(p0: int, p1: int, barcoded: bool) -> torch.Tensor:
+        m = p1 - p0
+        txt = chars(p0 * cpp, p1 * cpp).reshape(m, cpp)
+        idx = torch.arange(p0, p1, dtype=torch.int64, device=dev)
+        w = 42 if barcoded else 11
+        hdr = torch.empty((m, w), dtype=torch.uint8, device=dev)
+        hdr[:, 0], hdr[:, 1] = ord("@"), ord("r")
+        for i in range(8):
+            hdr[:, 2 + i] = ((idx // 10 ** (7 - i)) % 10 + 48).to(torch.uint8)
+        if barcoded:
+            hdr[:, 10:16] = torch.tensor(list(b" BX:Z:"), dtype=torch.uint8, device=dev)
+            hdr[:, 16:39] = names[idx // P]
+            hdr[:, 39:41] = torch.tensor(list(b"-1"), dtype=torch.uint8, device=dev)
+        hdr[:, -1] = ord("\n")
+        rec = torch.empty((m, 2 * (w + 2 * L + 4)), dtype=torch.uint8, device=dev)
+        o = 0
+        for r in range(2):
+            rec[:, o:o + w] = hdr; o += w
+            rec[:, o:o + L] = txt[:, r * (L + 1):r * (L + 1) + L]; o += L
+            rec[:, o:o + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=dev); o += 3
+            rec[:, o:o + L] = ord("I"); o += L
+            rec[:, o] = ord("\n"); o += 1
+        return rec
+
+    with open(path, "wb") as f:
+        for p0 in range(0, n_barcoded, chunk_pairs):
+            block(p0, min(n_barcoded, p0 + chunk_pairs), True).cpu().numpy().tofile(f)
+        for p0 in range(n_barcoded, n, chunk_pairs):
+            block(p0, min(n, p0 + chunk_pairs), False).cpu().numpy().tofile(f)
+    return n

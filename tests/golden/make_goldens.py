@@ -335,6 +335,43 @@ def part_b():
     np.savez_compressed(os.path.join(HERE, "vae_g5.npz"), **blob)
     print("part B: data_g4.npz vae_g5.npz")
 
+    # G5b: the network as the reference builds it by default -- VaritionalAutoEncoder(400, 136): hidden_sizes [512, 512],
+    # latent 32 (VAENET.py:193) --, seed 2021, three reference training steps on 128 rows, then eval: the embedding of 64
+    # rows and one full forward with its loss terms.  The whole state is stored (4 MB): the weights of a trained net are
+    # what they are.
+    torch.manual_seed(2021)
+    vn = VAENET(abd_dim=400, tnf_dim=136, latent_size=32, num_classes=30, epochs=1, cuda=False, num_gpus=1,
+                lr=0.005, dropout=0.2, alpha=0.1, w_kl=0.015, weight_decay=0.0001)
+    net = vn.network                                    # the constructor's own network: the default layer sizes
+    assert [m.out_features for m in net.modules() if isinstance(m, torch.nn.Linear)][:2] == [512, 512]
+    rs = np.random.RandomState(55)
+    x_abd = torch.from_numpy(rs.poisson(2.0, size=(128, 400)).astype(np.float32) + 1e-3); x_abd /= x_abd.sum(1, keepdim=True)
+    x_tnf = torch.from_numpy(rs.poisson(30.0, size=(128, 136)).astype(np.float32) + 1e-3); x_tnf /= x_tnf.sum(1, keepdim=True)
+    opt = torch.optim.Adam(net.parameters(), lr=0.005, weight_decay=0.0001)
+    net.train()
+    for _ in range(3):
+        opt.zero_grad()
+        loss = vn.unlabeled_loss(net(x_abd, x_tnf))["total"]
+        loss.backward()
+        opt.step()
+    net.eval()
+    with torch.no_grad():
+        mu = net.emebdding(x_abd[:64], x_tnf[:64]).numpy()
+        torch.manual_seed(78)
+        out = net(x_abd[:64], x_tnf[:64])
+        losses = vn.unlabeled_loss(out)
+    torch.manual_seed(78)
+    eps = torch.randn(64, 32).numpy()
+    blob = {f"state/{k}": v.numpy() for k, v in net.state_dict().items()}
+    blob.update(abd=x_abd[:64].numpy(), tnf=x_tnf[:64].numpy(), mu=mu, epsilon=eps,
+                fwd_mu=out["mu"].numpy(), fwd_logsigma=out["logsigma"].numpy(),
+                fwd_abd_rec=out["abd_rec"].numpy(), fwd_tnf_rec=out["tnf_rec"].numpy(),
+                loss_total=np.float64(losses["total"].item()), loss_abd=np.float64(losses["abd_rec"].item()),
+                loss_tnf=np.float64(losses["tnf_rec"].item()), loss_kl=np.float64(losses["kl_loss"].item()),
+                wa=np.float64(vn.wa), wt=np.float64(vn.wt), w_kl=np.float64(vn.w_kl))
+    np.savez_compressed(os.path.join(HERE, "vae_g5b_512.npz"), **blob)
+    print("part B: vae_g5b_512.npz")
+
 
 def part_c():
     """bin writer: the reference's extract_reads binary on three inputs -> every file it writes"""

@@ -454,3 +454,111 @@ def _control_worker(rank, world, port):
 
 def test_waits_for_rank0_use_the_control_plane():
     _spawn(_control_worker, 2)
+
+
+# ------------------------------------------------------------------ the super-k-mer form on N > 1 ranks (dist.MiniSharded)
+
+
+def _mini_cfg():
+    return synth.SynthConfig(n_pairs=24_000, n_barcodes=150, n_genomes=3, genome_len=40_000, fragment=10_000, sub_rate=0.01, n_rate=0.05, seed=321)
+
+
+def _shard_by_runs(s, rank, world):
+    """this rank's run range of a device stream, as a stream of its own (word aligned; what ``dist.shard_stream`` does on the host)"""
+    return pdist.shard_stream(ReadStream(s.codes.cpu(), s.valid.cpu(), s.n_chars, s.run_off, s.run_names), rank, world).to("cuda:0")
+
+
+def _mini_sharded_worker(rank, world, port, outdir, backend, saturate):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if saturate:
+            # 3.1 M copies of one 21-mer on EVERY rank: every part arrives saturated, the sum must stay at 2^21 and must not carry
+            # into the code; a tandem repeat and random text besides
+            rng = np.random.RandomState(3)
+            rnd = bytes(rng.choice(list(b"ACGT"), size=60_000).astype(np.uint8))
+            s = ReadStream.from_runs([("a", b"A" * 1_600_000 + b"N" + b"T" * 1_500_040 + b"N"), ("b", b"ACG" * 30_000 + b"N"),
+                                      ("c", rnd + b"N")], device="cuda:0")
+            part = s
+        else:
+            s = synth.generate(_mini_cfg(), device="cuda:0")
+            part = _shard_by_runs(s, rank, world)
+        rows = part.rows(2000 if not saturate else 0)
+        plan = kmer.Plan(rows, "cuda:0")
+        tnf, abd, ms = pdist.features_sharded_mini(part, plan, 21, 4, 10, 400)
+        assert ms.local.n_buckets == ms.union.n_buckets >= 512 and ms.local.log2_bucket <= ms.union.log2_bucket
+        c, n = ms.owned_items()
+        np.savez(os.path.join(outdir, f"m{rank}.npz"), c=c, n=n, tnf=tnf.cpu().numpy(), abd=abd.cpu().numpy(),
+                 names=np.array(rows.names), sent=ms.bytes_sent)
+        # counting again with the same object (what every bench step does) gives the same rows
+        ms.count(part, plan)
+        _, abd2 = kmer.features(part, plan, k_tnf=None, table=ms.local, window=10, vsize=400)
+        assert torch.equal(abd2, abd)
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_mini_sharded(tmp_path, world, backend="gloo", saturate=False):
+    _spawn(_mini_sharded_worker, world, str(tmp_path), backend, saturate)
+    parts = [np.load(str(tmp_path / f"m{r}.npz")) for r in range(world)]
+    if saturate:
+        rng = np.random.RandomState(3)
+        rnd = bytes(rng.choice(list(b"ACGT"), size=60_000).astype(np.uint8))
+        s = ReadStream.from_runs([("a", b"A" * 1_600_000 + b"N" + b"T" * 1_500_040 + b"N"), ("b", b"ACG" * 30_000 + b"N"), ("c", rnd + b"N")], device="cuda:0")
+        text = s.decode()
+        otab = oracle.Table(21, threads=4)
+        for _ in range(world):
+            otab.count(text)                                 # every rank holds a copy of the same reads
+    else:
+        s = synth.generate(_mini_cfg(), device="cuda:0")
+        text = s.decode()
+        otab = oracle.Table(21, threads=4).count(text)
+    # the owners' ranges together are the oracle's table (counts saturate at 2^21 exactly as one rank's table would)
+    codes = np.concatenate([p["c"] for p in parts]); counts = np.concatenate([p["n"] for p in parts])
+    order = np.argsort(codes)
+    ocodes, ocounts = otab.items()
+    assert np.array_equal(codes[order], ocodes) and np.array_equal(counts[order], np.minimum(ocounts, 1 << 21))
+    if saturate:
+        assert counts.max() == 1 << 21
+        rows = s.rows(0)
+        for p in parts:                                       # every rank has the rows of the whole text, looked up in the summed table
+            for r in range(len(rows)):
+                assert np.array_equal(p["abd"][r], oracle.abd_row(text[rows.start[r]:rows.end[r]], 21, otab, 10, 400))
+        return
+    # the ranks' rows, in rank order, are the rows of the whole file
+    rows = s.rows(2000)
+    names = [n for p in parts for n in p["names"].tolist()]
+    assert names == list(rows.names)
+    abd = np.concatenate([p["abd"] for p in parts]); tnf = np.concatenate([p["tnf"] for p in parts])
+    plan = kmer.Plan(rows, "cuda:0")
+    one = kmer.count_kmers(s, 21, rows=plan, emit=(10, 400))
+    want_tnf, want_abd = kmer.features(s, plan, k_tnf=4, table=one, window=10, vsize=400)
+    assert np.array_equal(abd, want_abd.cpu().numpy()) and np.array_equal(tnf, want_tnf.cpu().numpy())
+    for r in range(0, len(rows), max(1, len(rows) // 8)):
+        assert np.array_equal(abd[r], oracle.abd_row(text[rows.start[r]:rows.end[r]], 21, otab, 10, 400))
+    assert world == 1 or all(int(p["sent"]) > 0 for p in parts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_super_kmer_form_on_several_ranks(tmp_path, world):
+    """every rank counts ITS runs with the one-GPU pipeline up to the provisional words, entries go to bucket-range owners (8 bytes per
+    distinct k-mer), merged bins come back (2 bytes), the lookup half finishes: rows == the one-process rows == the oracle's, the
+    owners' table ranges together == the oracle's table (3 ranks: uneven ranges)"""
+    _check_mini_sharded(tmp_path, world)
+
+
+@pytest.mark.gpu
+def test_super_kmer_form_saturating_counts_on_two_ranks(tmp_path):
+    _check_mini_sharded(tmp_path, 2, saturate=True)
+
+
+@pytest.mark.gpu
+def test_super_kmer_form_over_a_one_rank_rccl_group(tmp_path):
+    """the same exchange with RCCL's collectives (a one-GPU box holds a one-rank group): all-gather of the fills, both all-to-alls"""
+    _check_mini_sharded(tmp_path, 1, backend="nccl")

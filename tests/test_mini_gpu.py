@@ -375,3 +375,87 @@ def test_row_histograms_shared_among_workgroups_give_the_same_rows(force, monkey
     assert int(ref.sum()) > 1_000_000
     for v in got.values():
         assert torch.equal(v[0], ref) and torch.equal(v[1], ref)
+
+
+# ------------------------------------------------------------------ merged (row, bin) runs, the checked build, stale plans
+
+
+@pytest.mark.parametrize("sub_rate,coverage_genomes,window", [(0.001, 2, 10), (0.05, 2, 1), (0.05, 40, 1)])
+def test_merged_runs_equal_the_word_wise_lookups(sub_rate, coverage_genomes, window, monkeypatch):
+    """the lookup phase lets runs of equal neighbouring bins of a record travel as one word with a count (MERGE form).  High
+    coverage and few errors: nearly every record is one run; window 1 with 5 % substitutions and uneven coverage: neighbours
+    rarely share a bin, a tile's runs overflow the LDS stage and are laid out in several windows.  Same rows as the word-wise
+    form (the default), as the lookup kernel, and as the oracle; both workgroup sizes."""
+    cfg = synth.SynthConfig(n_pairs=120_000, n_barcodes=900, n_genomes=coverage_genomes, genome_len=60_000, fragment=20_000,
+                            sub_rate=sub_rate, n_rate=0.05, seed=1234)
+    s = synth.generate(cfg, device=DEV)
+    rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    got = {}
+    for lb in (14, 13):
+        for merged in (True, False):
+            monkeypatch.setenv("PG_MINI_MERGE", "1" if merged else "0")
+            t = kmer.KmerTable.mini_with_slots(21, DEV, 26, lb).count(s, rows=plan, emit=(window, 400))
+            _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=window, vsize=400)
+            got[(lb, merged)] = abd
+    monkeypatch.delenv("PG_MINI_MERGE", raising=False)
+    ref = got[(14, True)]
+    assert all(torch.equal(v, ref) for v in got.values()) and int(ref.sum()) > 10_000_000
+    _, want = kmer.features(s, rows, k_tnf=None, table=t, window=window, vsize=400)
+    assert torch.equal(ref, want)
+    text = s.decode()
+    otab = oracle.Table(21, threads=4).count(text)
+    for r in range(0, len(rows), max(1, len(rows) // 10)):
+        assert np.array_equal(ref[r].cpu().numpy(), oracle.abd_row(text[rows.start[r]:rows.end[r]], 21, otab, window, 400))
+
+
+def test_super_kmer_kernels_through_the_checked_build():
+    """the same library built with -DPG_CHECKED (every global store of the super-k-mer kernels checks its index against the
+    capacity of the buffer it writes into; PG_STATUS_BOUNDS instead of a memory fault): the oracle cases of this file run
+    through it in a process of their own.  New kernel code is run this way first -- see DESIGN.md section 4, 'the abort'."""
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    if os.environ.get("PANGAEA_LIB") == "checked":
+        pytest.skip("already inside the checked pass")
+    for merge in ("0", "1"):                   # word-wise lookups (the default) and the merged form
+        _checked_pass(merge)
+
+
+def _checked_pass(merge):
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    env = dict(os.environ, PANGAEA_LIB="checked", PG_MINI_MERGE=merge)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_mini_gpu.py"),
+                        "-k", "against_oracle or merged_runs or general_lookup or its_own_record or one_pass_row_shuffle or low_complexity"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_a_plan_of_another_stream_is_not_reused_and_a_forced_one_is_refused(monkeypatch):
+    """the cached partition plan is tied to the stream's tensors (their addresses AND versions; the cache holds the tensors, so
+    the addresses cannot be recycled) -- a stream rewritten in place gets a new plan; a plan forced onto a stream with more
+    records than the record workspace holds sets PG_STATUS_PLAN_MISMATCH and counts nothing"""
+    a = synth.generate(synth.SynthConfig(n_pairs=2000, n_barcodes=20, n_genomes=2, genome_len=30_000, fragment=8_000, seed=1), device=DEV)
+    b = synth.generate(synth.SynthConfig(n_pairs=2000, n_barcodes=20, n_genomes=2, genome_len=30_000, fragment=8_000, seed=2), device=DEV)
+    assert a.n_words == b.n_words
+    t = kmer.KmerTable.mini_with_slots(21, DEV, 20, 10).count(a)
+    plan_a = t._mini_plan[1]
+    a.codes.copy_(b.codes); a.valid.copy_(b.valid)                       # same addresses, other reads
+    t.reset().count(a)
+    assert t._mini_plan[1] is not plan_a or t._mini_plan[0][1] != 0       # planned again (the version moved on)
+    assert _same_items(t.items(), oracle.Table(21, threads=2).count(b.decode()).items())
+    # a plan of a small stream forced onto a large one: refused by the kernels
+    small = synth.generate(synth.SynthConfig(n_pairs=256, n_barcodes=4, n_genomes=1, genome_len=30_000, fragment=8_000, seed=3), device=DEV)
+    pad = torch.zeros(a.n_words - small.n_words, dtype=small.codes.dtype, device=DEV)
+    padv = torch.zeros(a.n_words - small.n_words, dtype=small.valid.dtype, device=DEV)
+    small_padded = ReadStream(torch.cat([small.codes, pad]), torch.cat([small.valid, padv]), small.n_chars, small.run_off, small.run_names)
+    u = kmer.KmerTable.mini_with_slots(21, DEV, 20, 10).count(small_padded)
+    monkeypatch.setattr(kmer.KmerTable, "_plan_key", staticmethod(lambda *a_, **k_: "always the same"))
+    u.reset()
+    u._mini_plan = ("always the same",) + tuple(u._mini_plan[1:])
+    with pytest.raises(RuntimeError, match="PLAN_MISMATCH"):
+        u.count(a)

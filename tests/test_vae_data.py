@@ -17,9 +17,14 @@ from .conftest import GOLDEN
 DEVICES = ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)]
 
 
-def _g5():
-    g = np.load(os.path.join(GOLDEN, "vae_g5.npz"))
+def _g5(name="vae_g5.npz"):
+    g = np.load(os.path.join(GOLDEN, name))
     return g, {k[len("state/"):]: g[k] for k in g.files if k.startswith("state/")}
+
+
+# the reference's own modules produced both: a [48, 40] net (small fixture) and the net its constructor builds by default --
+# hidden sizes [512, 512] (VAENET.py:193), the sizes every real run has
+FIXTURES = [("vae_g5.npz", [48, 40], 5), ("vae_g5b_512.npz", None, 30)]
 
 
 @pytest.mark.parametrize("device", DEVICES)
@@ -59,10 +64,13 @@ def test_fused_row_normalisation_is_bit_identical():
             assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
+@pytest.mark.parametrize("fixture,hidden,n_classes", FIXTURES)
 @pytest.mark.parametrize("device", DEVICES)
-def test_network_matches_reference_vectors(device):
-    g, state = _g5()
-    net = VaritionalAutoEncoder(400, 136, hidden_sizes=[48, 40]).to(device)
+def test_network_matches_reference_vectors(device, fixture, hidden, n_classes):
+    g, state = _g5(fixture)
+    net = (VaritionalAutoEncoder(400, 136, hidden_sizes=hidden) if hidden else VaritionalAutoEncoder(400, 136)).to(device)
+    if hidden is None:
+        assert tuple(state["encoder.0.weight"].shape) == (512, 536) and tuple(state["encoder.4.weight"].shape) == (512, 512)
     assert set(net.state_dict()) == set(state)                       # the reference's state_dict keys
     net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     net.eval()
@@ -75,7 +83,7 @@ def test_network_matches_reference_vectors(device):
     assert np.abs(mu - oracle.vae_embedding(state, g["abd"], g["tnf"])).max() <= 1e-5 * scale
     for key, ref in (("mu", "fwd_mu"), ("logsigma", "fwd_logsigma"), ("abd_rec", "fwd_abd_rec"), ("tnf_rec", "fwd_tnf_rec")):
         assert np.abs(out[key].cpu().numpy() - g[ref]).max() <= 1e-5 * max(1e-3, np.abs(g[ref]).max()), key
-    vn = VAENET(400, 136, 32, 5, 1, device != "cpu", 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
+    vn = VAENET(400, 136, 32, n_classes, 1, device != "cpu", 1, 0.005, 0.2, 0.1, 0.015, 0.0001)
     assert np.isclose(vn.wa, float(g["wa"])) and np.isclose(vn.wt, float(g["wt"])) and np.isclose(vn.w_kl, float(g["w_kl"]))
     losses = vn.unlabeled_loss(out)
     for key, ref in (("total", "loss_total"), ("abd_rec", "loss_abd"), ("tnf_rec", "loss_tnf"), ("kl_loss", "loss_kl")):
