@@ -142,9 +142,11 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
         s = host.to(dev)
         torch.cuda.synchronize()
         lap["h2d"] = time.perf_counter() - t; t = time.perf_counter()
+        regs = kmer.distinct_sketch(s, K_ABD)                 # (the sizing pass runs on the GPU while the host builds the rows)
         rows = s.rows(MIN_LEN)
         plan = kmer.Plan(rows, dev)
-        table = kmer.count_kmers(s, K_ABD, rows=plan, emit=(WINDOW, VSIZE))          # (HyperLogLog sizing, allocation, partition plan, count + lookups)
+        hint = max(1 << 13, int(1.1 * kmer.sketch_estimate(regs)))
+        table = kmer.count_kmers(s, K_ABD, rows=plan, emit=(WINDOW, VSIZE), distinct_hint=hint, load=0.4)      # (allocation, partition plan, count + lookups)
         tnf, abd = kmer.features(s, plan, k_tnf=K_TNF, table=table, window=WINDOW, vsize=VSIZE)
         torch.cuda.synchronize()
         lap["table+rows"] = time.perf_counter() - t; t = time.perf_counter()
@@ -303,10 +305,10 @@ def main():
             ms.local._mini_plan = None
         ms.count_half(stream, plan)
         e[1].record()
-        if args.plan == "ahead":
-            ms.local.prefetch_plan(stream, plan, side)
         ms.exchange()
         e[2].record()
+        if args.plan == "ahead":            # the next batch's plan: beside the lookup half (LDS-bound) and the row histograms
+            ms.local.prefetch_plan(stream, plan, side)
         ms.lookup_half()
         kmer.features(stream, plan, k_tnf=K_TNF, table=ms.local, window=WINDOW, vsize=VSIZE, out_tnf=tnf, out_abd=abd)
         e[3].record()

@@ -2367,7 +2367,10 @@ extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, c
     const ShufArgs sh{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, ctx.narrow, ctx.words_cap};
     const unsigned nb = 1u << p.bits;
     const auto *occ = (const unsigned long long *)((const char *)half_ws + hl.occ_off);
-    const bool half_block = local->log2_bucket_slots <= 13 && ctx.gb1 <= 10;
+    // 1024-thread workgroups whatever the bucket size: tiles of 16 Ki words keep the runs per row group at 32 bytes -- with
+    // 512 threads (8 Ki-word tiles, two workgroups per CU) this kernel took 14.1 ms where the one-GPU kernel's lookup phase
+    // takes 8.5 (PG_LOOKUP_HALF_512=1: that form, for comparison)
+    const bool half_block = local->log2_bucket_slots <= 13 && ctx.gb1 <= 10 && getenv("PG_LOOKUP_HALF_512");
     hipStream_t s = (hipStream_t)stream;
 #define PG_LOOKUP_HALF(BLK_, DIG_)                                                                                          \
     do {                                                                                                                    \

@@ -131,6 +131,12 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
         device = torch.device("cuda", torch.cuda.current_device())
     world = torch.distributed.get_world_size() if pdist.is_distributed() else 1
     stream = _ingest(reads1, reads2, world, stream_cache).to(device)
+    # one rank: the table's sizing pass (a HyperLogLog sketch of the distinct k-mers) is launched first and runs on the GPU while
+    # the host assembles the rows
+    from . import kmer as _kmer
+    sketch = None
+    if world == 1 and want_abd and table is None and _kmer.KmerTable.default_kind(k) != "dense":
+        sketch = _kmer.distinct_sketch(stream, k, lowercase_is_base=lowercase_is_base)
     rows = stream.rows(min_len)
     plan = Plan(rows, device)
     tnf = abd = None
@@ -140,7 +146,9 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     else:
         if want_abd and table is None:
             table = (pdist.count_kmers_sharded(stream, k, rows=plan, lowercase_is_base=lowercase_is_base) if world > 1
-                     else count_kmers(stream, k, rows=plan, emit=(window, vsize), lowercase_is_base=lowercase_is_base))
+                     else count_kmers(stream, k, rows=plan, emit=(window, vsize), lowercase_is_base=lowercase_is_base,
+                                      distinct_hint=None if sketch is None else max(1 << 13, int(1.1 * _kmer.sketch_estimate(sketch))),
+                                      load=None if sketch is None else 0.4))
         tnf, abd = features(stream, plan, k_tnf=k_tnf if want_tnf else None, table=table if want_abd else None,
                             window=window, vsize=vsize)
     names = list(rows.names)

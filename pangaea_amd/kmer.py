@@ -813,7 +813,7 @@ def estimate_distinct(stream: ReadStream, k: int, word_begin: int = 0, word_end:
 
 def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hint: int | None = None,
                 max_log2_slots: int = 36, log2_bucket: int | None = None, rows: "Plan | None" = None,
-                emit: tuple | None = None, lowercase_is_base: bool = False) -> KmerTable:
+                emit: tuple | None = None, lowercase_is_base: bool = False, load: float | None = None) -> KmerTable:
     """build the table of one stream; a full hash table is re-built with four times the slots.  ``emit`` = (window,
     vector_size) fuses the lookup pass of the abundance rows into the count where that applies (``KmerTable.count``)."""
     resolved = kind or KmerTable.default_kind(k)
@@ -825,8 +825,8 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
         # size from a HyperLogLog pass (as cheap as the bucket histogram) instead of guessing the coverage; +10 % covers
         # the estimator's error, load 0.4 leaves room for per-bucket variance
         distinct_hint = max(1 << 13, int(1.1 * estimate_distinct(stream, k, lowercase_is_base=lowercase_is_base)))
-        load = 0.4
-    else:
+        load = 0.4 if load is None else load
+    elif load is None:
         load = 0.5
     if auto_mini and log2_bucket is None:
         # one GPU, rows and abundance parameters known: the super-k-mer pipeline (table by minimizer buckets) where its geometry

@@ -30,7 +30,8 @@ def test_bench_line_honours_the_contract(extra):
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert "traffic" in r and r["kernel"] in j["kernel_ms"]
+    assert "traffic" in r and "traffic_tag" in r and r["kernel"] in j["kernel_ms"]
+    assert {"distinct_sketch", "table_alloc", "rows+plan_segments", "first_step_incl_allocations"} <= set(j["setup_ms"])     # what `value` leaves out
     if not extra:
         c = j["cpu_baseline"]
         assert c["unit"] == "pairs/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
@@ -39,6 +40,9 @@ def test_bench_line_honours_the_contract(extra):
         e = j["e2e"]                                    # the FASTQ -> mu leg, reported beside the device-resident value
         assert e["unit"] == "pairs/s" and e["value"] > 0 and e["pairs"] == 200000 and e["host_threads"] >= 1
         assert set(e["seconds"]) == {"ingest", "h2d", "table+rows", "normalise+encode"} and e["value"] < j["value"]
+        assert 0 < e["first_pass"] <= e["value"] * 1.0000001
+    if extra == ["--rehearse-dist", "4"]:
+        assert "exchange" in j["kernel_ms"] and "lookup half" in j["config"]["pipeline"] or "lookups of the provisional words" in j["config"]["pipeline"]
 
 
 def test_bench_starts_its_own_ranks():
