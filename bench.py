@@ -297,10 +297,25 @@ def main():
 
     side = torch.cuda.Stream(device=dev)
 
+    tnf_side = torch.cuda.Stream(device=dev)
+
+    def tnf_beside(cur):
+        """K1 (TNF rows) depends on the reads alone and could run on a stream of its own beside the table kernels (PG_TNF_BESIDE=1).
+        Measured on one GPU: the first scatter pass, which is bound by VALU issue, slows down by more than K1 takes -- stage + 1.8 ms,
+        features - 0.8 ms, step 35.1 instead of 34.1 ms -- so the default keeps K1 behind the row histograms."""
+        tnf_side.wait_stream(cur)
+        with torch.cuda.stream(tnf_side):
+            kmer.features(stream, plan, k_tnf=K_TNF, table=None, out_tnf=tnf)
+
+    beside = os.environ.get("PG_TNF_BESIDE", "0") not in ("", "0")
+
     def step_sharded(timed: bool):
         """N > 1 ranks, super-k-mer form: count half | entries to owners, merged bins back | lookup half + rows + TNF"""
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
+        cur = torch.cuda.current_stream(dev)
+        if beside:
+            tnf_beside(cur)
         if args.plan != "once":
             ms.local._mini_plan = None
         ms.count_half(stream, plan)
@@ -310,7 +325,9 @@ def main():
         if args.plan == "ahead":            # the next batch's plan: beside the lookup half (LDS-bound) and the row histograms
             ms.local.prefetch_plan(stream, plan, side)
         ms.lookup_half()
-        kmer.features(stream, plan, k_tnf=K_TNF, table=ms.local, window=WINDOW, vsize=VSIZE, out_tnf=tnf, out_abd=abd)
+        kmer.features(stream, plan, k_tnf=None if beside else K_TNF, table=ms.local, window=WINDOW, vsize=VSIZE, out_tnf=None if beside else tnf, out_abd=abd)
+        if beside:
+            cur.wait_stream(tnf_side)
         e[3].record()
         mu = vae.encode(Data(names, abd, tnf, device=dev))
         if timed:
@@ -324,6 +341,9 @@ def main():
             return step_sharded(timed)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
+        cur = torch.cuda.current_stream(dev)
+        if beside:
+            tnf_beside(cur)
         table.reset()                   # bucketed tables are overwritten slice by slice: no 4 GB clear
         if mini and args.plan != "once":
             table._mini_plan = None         # every step plans its batch: in front of the count, or ahead (prefetched by the step before)
@@ -344,7 +364,9 @@ def main():
         elif multi:
             pdist._exchange_bucketed(table)         # rehearsal: the same launches and collectives in a one-rank group
         e[2].record()
-        kmer.features(stream, plan, k_tnf=K_TNF, table=table, window=WINDOW, vsize=VSIZE, out_tnf=tnf, out_abd=abd)
+        kmer.features(stream, plan, k_tnf=None if beside else K_TNF, table=table, window=WINDOW, vsize=VSIZE, out_tnf=None if beside else tnf, out_abd=abd)
+        if beside:
+            cur.wait_stream(tnf_side)
         e[3].record()
         d = Data(names, abd, tnf, device=dev)
         mu = vae.encode(d)
@@ -429,6 +451,7 @@ def main():
                                             table._mini_plan[2] / args.pairs if mini and table._mini_plan else 260.0),
                        "exchange_bytes_per_rank": ({"sent": ms.bytes_sent, "received": ms.bytes_received} if ms is not None else None),
                        "local_bucket_slots": (1 << ms.local.log2_bucket if ms is not None else None),
+                       "tnf_rows": ("on a stream of their own beside the table kernels" if beside else "behind the row histograms"),
                        "input": "packed reads resident in HBM", "table_load": table_load,
                        "table_buckets": table.n_buckets, "bucket_slots": 1 << table.log2_bucket if table.log2_bucket else None},
             "kernel_ms": kern_ms,

@@ -31,6 +31,8 @@ KERNELS = [
     ("mini_total_kernel", "plan (every step, for the next batch, side stream)", 1.0), ("distinct_sketch_kernel", "plan (every step, for the next batch, side stream)", 2.0),
     ("mini_scatter_kernel", "kmer_count+lookup", 2.0), ("mini_scatter2_kernel", "kmer_count+lookup", 2.0),
     ("mini_count_kernel", "kmer_count+lookup", 2.0),
+    # N > 1 ranks (bench.py --rehearse-dist N): the count half keeps the stage name of the count, the rest is the exchange / features
+    ("mini_lookup_half_kernel", "features", 2.0), ("mini_merge_bins_kernel", "exchange", 2.0), ("mini_gather_entries_kernel", "exchange", 2.0),
     ("bucket_hist_kernel", "kmer_count", 2.0), ("scan_kernel", "kmer_count", 1.0), ("digit_scan_kernel", "kmer_count", 1.0),
     ("tile_rows_kernel", "kmer_count", 1.0), ("scatter_stream_kernel", "kmer_count", 1.0),
     ("scatter_records_kernel<unsigned long", "kmer_count", 2.0), ("bucket_count_kernel", "kmer_count", 2.0),
@@ -58,7 +60,21 @@ def info(key):
     raise KeyError(key)
 
 
+def rehearse(tag, stats_dir):
+    """kernel statistics of `bench.py --rehearse-dist 8` -> profiles/<tag>_rehearse_n8_kernel_stats.csv (our kernels only)"""
+    rows = list(csv.DictReader(open(sorted(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")))[-1])))
+    rows = [r for r in rows if short(r["Name"])]
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    with open(os.path.join(ROOT, "profiles", f"{tag}_rehearse_n8_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs"])
+        for r in rows:
+            w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"]])
+
+
 def main():
+    if sys.argv[1] == "rehearse":
+        return rehearse(sys.argv[2], sys.argv[3])
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
     pairs = int(sys.argv[5]) if len(sys.argv) > 5 else 10_000_000
     pipeline = sys.argv[6] if len(sys.argv) > 6 else "mini"
