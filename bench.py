@@ -314,19 +314,24 @@ def main():
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         cur = torch.cuda.current_stream(dev)
-        if beside:
-            tnf_beside(cur)
         if args.plan != "once":
             ms.local._mini_plan = None
         ms.count_half(stream, plan)
         e[1].record()
+        # work that needs nothing from the other ranks goes beside the exchange, whose collectives and host-side sizing leave the GPU
+        # idle in between: the TNF rows (they depend on the reads alone) and the next batch's partition plan
+        in_gaps = os.environ.get("PG_EXCHANGE_GAPS", "1") not in ("", "0")
+        if in_gaps:
+            tnf_beside(cur)
+            if args.plan == "ahead":
+                ms.local.prefetch_plan(stream, plan, side)
         ms.exchange()
         e[2].record()
-        if args.plan == "ahead":            # the next batch's plan: beside the lookup half (LDS-bound) and the row histograms
+        if args.plan == "ahead" and not in_gaps:      # the next batch's plan: beside the lookup half (LDS-bound) and the row histograms
             ms.local.prefetch_plan(stream, plan, side)
         ms.lookup_half()
-        kmer.features(stream, plan, k_tnf=None if beside else K_TNF, table=ms.local, window=WINDOW, vsize=VSIZE, out_tnf=None if beside else tnf, out_abd=abd)
-        if beside:
+        kmer.features(stream, plan, k_tnf=None if in_gaps else K_TNF, table=ms.local, window=WINDOW, vsize=VSIZE, out_tnf=None if in_gaps else tnf, out_abd=abd)
+        if in_gaps:
             cur.wait_stream(tnf_side)
         e[3].record()
         mu = vae.encode(Data(names, abd, tnf, device=dev))
