@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 4   /* 4: pg_mini_records_bytes takes the table (per-record hit masks of the merged lookups), status bits;
+#define PG_ABI_VERSION 5   /* 5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
+                              4: pg_mini_records_bytes takes the table, status bits;
                               3: PG_TABLE_MINI and the super-k-mer entry points; 2: packed hash slots keyed by pg_key42(code) */
 #define PG_CHARS_PER_WORD 32
 #define PG_WORD_ALIGN 256 /* stream arrays are padded to a multiple of this many words */
@@ -348,8 +349,8 @@ int pg_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int window
  *                  workgroup (slots of a FRESH table are overwritten, no clearing) and, when window > 0, looked up again
  *                  while its counts are still in LDS: the (row, bin) words of count_kmer.cpp:86-96 are left in
  *                  `shuffle_ws` for pg_mini_abundance_from_emitted.  `rows` may be NULL and window = vsize = 0 (table only).
- * plan_ws: pg_mini_plan_bytes; rec_ws: pg_mini_records_bytes(n_records, t) (two buffers of 12 B per record, the per-record
- * hit masks and per-batch word offsets of the merged lookups); shuffle_ws: pg_mini_shuffle_bytes.  All 256-byte aligned
+ * plan_ws: pg_mini_plan_bytes; rec_ws: pg_mini_records_bytes(n_records, t) (two buffers of 12 B per record);
+ * shuffle_ws: pg_mini_shuffle_bytes.  All 256-byte aligned
  * device memory.  A plan that names more records than rec_ws holds sets PG_STATUS_PLAN_MISMATCH and counts nothing.
  * ---------------------------------------------------------------------------------------------- */
 int64_t pg_mini_plan_bytes(int64_t n_words, const pg_table *t);
@@ -357,9 +358,15 @@ int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_t word_begi
                  const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *stream);
 int64_t pg_mini_records_bytes(int64_t n_records, const pg_table *t);
 int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize);
+/* merge_ws (may be NULL: the word-wise lookups): pg_mini_merge_words() 4-byte words of device memory for the MERGED form of the
+ * lookups -- the k-mers of a record that share row and bin travel as one word with a count; provisional words in fixed slots
+ * per record, sized from the plan's record counts (the plan workspace's first 8-byte word: records; third: records of more
+ * than 4 k-mers).  Opt-in besides: PG_MINI_MERGE=1 in the environment. */
+int64_t pg_mini_merge_words(int64_t n_words, int64_t n_records, int64_t n_long_records, const pg_table *t);
 int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                   const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
-                  int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream);
+                  int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *merge_ws, int64_t merge_ws_words,
+                  uint32_t *status, void *stream);
 /* `stream` waits for the first scatter pass of the calling thread's latest pg_mini_count (an event recorded there): the next
  * batch's pg_mini_plan, enqueued on that stream afterwards, runs beside the memory-bound second pass. */
 int pg_mini_wait_first_pass(void *stream);

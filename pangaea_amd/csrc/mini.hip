@@ -39,6 +39,10 @@ constexpr uint32_t MINI_ROW_NONE = (1u << (32 - META_ROW_SHIFT)) - 1u;
 constexpr int MINI_MAX_LEN = 1 << META_LEN_BITS;       // k-mers per record
 constexpr int MINI_BITS1 = 8;                          // first-pass digits (regions): 8, or 9 for a table of 2^16 buckets
 constexpr int MINI_MAX_BITS1 = 9;
+#ifndef PG_SHORT_MAX
+#define PG_SHORT_MAX 4
+#endif
+constexpr int PG_SHORT_MAX_ = PG_SHORT_MAX;                       // a record with at most this many k-mers is "short" (see mini_count_kernel)
 static_assert(PG_MINI_MAX_ROWS == (int)MINI_ROW_NONE - 1, "row field of the record");
 static_assert(PG_MINI_MAX_LOG2_BUCKETS == MINI_MAX_BITS1 + META_D2_BITS, "bucket id = region digit + second-pass digit");
 
@@ -196,12 +200,15 @@ __global__ __launch_bounds__(BLOCK) void mini_plan_kernel(const uint64_t *__rest
                                                           int64_t word_begin, int64_t word_end, int k, int woff, int bits, int bits2, int cap,
                                                           const int64_t *__restrict__ row_start, const int64_t *__restrict__ row_end, int64_t n_rows,
                                                           const uint32_t *__restrict__ strict, const int32_t *__restrict__ round_row,
-                                                          unsigned long long *__restrict__ chunk_hist, int64_t n_chunks, int64_t chunk_stride)
+                                                          unsigned long long *__restrict__ chunk_hist, int64_t n_chunks, int64_t chunk_stride,
+                                                          unsigned long long *__restrict__ class_totals)
 {
     __shared__ uint32_t coarse[1 << MINI_MAX_BITS1];
+    __shared__ uint32_t n_long_here;                             // records of more than SHORT_MAX k-mers in this chunk
     const int n_dig = 1 << (bits - bits2);
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         for (int i = threadIdx.x; i < (1 << MINI_MAX_BITS1); i += BLOCK) coarse[i] = 0;
+        if (threadIdx.x == 0) n_long_here = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < MINI_CHUNK_WORDS; i += BLOCK) {
             const int64_t wi = chunk * MINI_CHUNK_WORDS + i;        // word index inside the range
@@ -211,11 +218,15 @@ __global__ __launch_bounds__(BLOCK) void mini_plan_kernel(const uint64_t *__rest
             if (lw.ok == 0) continue;
             RowBits rb;
             rb.init(row_start, row_end, n_rows, row_start ? round_row[wi / ROUND_WORDS] : 0, w << 5);
-            mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int, int, uint32_t b) {
+            uint32_t longs = 0;
+            mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int, int n, uint32_t b) {
                 atomicAdd(&coarse[b >> bits2], 1u);
+                longs += n > PG_SHORT_MAX_ ? 1u : 0u;
             });
+            if (longs) atomicAdd(&n_long_here, longs);
         }
         __syncthreads();
+        if (threadIdx.x == 0 && n_long_here) atomicAdd(class_totals, (unsigned long long)n_long_here);     // header[2]: long records of the stream
         for (int d = threadIdx.x; d < n_dig; d += BLOCK)
             chunk_hist[(int64_t)d * n_chunks + (int64_t)(((__int128)chunk * chunk_stride) % n_chunks)] = coarse[d];
         __syncthreads();
@@ -783,36 +794,35 @@ __device__ __forceinline__ void wordwise_lookup(const WordCtx &c)
 
 // MERGE (SLOTS form only): the k-mers of a record share their row and, being neighbours in a read, mostly their bin.  The lookup
 // phase then works record-wise: a lane takes ONE record of a batch, fetches the provisional words of its k-mers, turns them into
-// bins and lets every run of equal neighbouring bins travel on as ONE word with a count on top,
+// bins and lets every run of equal neighbouring (row, bin) words travel on as ONE word with a count on top,
 //     word = (run length - 1) << MERGE_CSHIFT | row << vbits | bin,
 // so that ranks, region starts, staging and copy-out are paid per record and per run instead of per occurrence (measured on the
-// bench workload: 0.35 runs per first-probe word).  For that the count loop leaves, per record, the mask of its k-mers that were
-// settled by the first probe inside a row (the `hit` plane: one byte per short record, two per long one) and, per batch of 64
-// records, where the batch's words start (`batch_at`); the words of the general insert, which arrive one by one, fill the
-// bucket's word range from its END and are looked up singly.
-#ifndef PG_MERGE_SLOTS
-#define PG_MERGE_SLOTS 24                                         // (k-mer, batch) register slots of a lane per lookup tile: T = slots / k-mers per record
-#endif
+// bench workload: 0.28 words left per provisional word).
+// The provisional words of this form lie in FIXED slots, so that the lookup phase can fetch them without reading anything else
+// first: the bucket's word range is
+//     [ batches of short records: 64 x CXS words each | batches of long records: 64 x CAP words each | singles ]
+// and word j of the record that lane l treated in batch b of its class sits at class_base + b x 64 x CX + j x 64 + l -- a
+// k-mer that left no word there (outside every row, not settled by the first probe) leaves NONE.  Every store of the count loop
+// is a whole aligned 256-byte row of a wavefront, there is no position to claim per batch, and the words of the general
+// insert ("singles", which arrive one by one) are appended behind the batches.  The range is sized from the classes' record
+// counts, which the plan tallies (header[2]): 17 % more provisional bytes than the compacted layout of the word-wise form.
 constexpr int MERGE_CSHIFT = PG_SHUFFLE_COUNT_SHIFT;              // needs row bits + vbits <= 28 (mini_merge_form)
+constexpr uint32_t WORD_NONE = 0xffffffffu;                       // (never a provisional word: rows stay below 2^20 in this form)
 struct MergeArgs {
-    uint8_t *hit;                                                // bucket b: bytes from (2 off[b] + 8 b) & ~3
-    uint32_t *batch_at;                                          // bucket b: entries from off[b] / 64 + 3 b
+    uint32_t *prov;                                              // the provisional words of the MERGE form
+    unsigned long long cap;                                      // its capacity, in words (the buckets claim their ranges on the word cursor)
 };
-// ---- the record-wise lookups of the MERGE form (see MergeArgs): provisional (row, slot) words -> (run, row, bin) words, scattered
-// by the first digit of their row group into the row shuffle's regions.  Called by a whole workgroup of BLK threads once the
-// bucket's 2-byte bins lie at the start of the dynamic LDS (LookupLds layout): inside the counting kernel while the counts are
-// still there (one GPU), or by mini_lookup_half_kernel once the bins of the merged table have come back from their owners.
+// ---- the record-wise lookups of the MERGE form: provisional (row, slot) words -> (run, row, bin) words, scattered by the first
+// digit of their row group into the row shuffle's regions.  Called by a whole workgroup of BLK threads once the bucket's
+// 2-byte bins lie at the start of the dynamic LDS (MergeLds layout).
 struct MergeCtx {
     unsigned char *lds;                                          // dynamic LDS (bins16 first)
     uint32_t smask;
     int lb, vbits;
     ShufArgs sh;
     uint32_t *status;
-    const uint32_t *prov_b;                                      // the bucket's words: [0, np_all - n_ring) by batches, then the singles
-    uint32_t np_all, n_ring;
-    const uint8_t *hit_s, *hit_l;                                // hit masks of the short / long records
-    const uint32_t *bat;                                         // word offsets of the batches (short ones first)
-    uint32_t n_short, n_long, n_sb;                              // records of the two classes; batches of the short class
+    const uint32_t *prov_b;                                      // the bucket's word range
+    uint32_t n_sb, n_lb, n_ring;                                 // batches of short / long records, singles
     unsigned long long *dbg;                                     // PG_MINI_STAMPS builds: cycle sums of the phases (diagnostic)
 };
 
@@ -822,6 +832,9 @@ struct MergeCtx {
 #ifndef PG_MERGE_WPL
 #define PG_MERGE_WPL 12
 #endif
+#ifndef PG_MERGE_NS
+#define PG_MERGE_NS 12
+#endif
 template <int BLK, int DIG> struct MergeLds {
     static constexpr int WPL = (BLK == 1024 && DIG == 1024) ? PG_MERGE_WPL : (PG_MERGE_WPL < 10 ? PG_MERGE_WPL : 10);   // (144 KiB with 1024 threads, 72 KiB with 512: two workgroups per CU)
     static constexpr uint32_t TILE = WPL * BLK;
@@ -829,42 +842,41 @@ template <int BLK, int DIG> struct MergeLds {
     static constexpr uint32_t BUF1 = BUF + 4 * TILE;
     static constexpr uint32_t CNT = BUF1 + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
 };
+// slots of a step of the lookup phase (and the slack the word buffer needs behind its last bucket: a step reads whole rows)
+template <int CAP> struct MergeStep {
+    static constexpr int CXS = CAP > PG_SHORT_MAX_ ? PG_SHORT_MAX_ : CAP;
+    static constexpr int NS = PG_MERGE_NS < CAP ? CAP : PG_MERGE_NS;
+    static constexpr int GS = CAP > PG_SHORT_MAX_ ? NS / CXS : 0;               // batches of short records per step
+};
 
 template <int CAP, int BLK, int DIG>
 __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 {
     // Two stages, repeated until the bucket's words are used up (once or twice per bucket).
-    // A (no barrier inside): every wavefront walks over its share of the work in STEPS of up to 16 word slots per lane -- four
-    //   batches of short records (a lane takes one record of each), one batch of long records, or 1024 singles --: fetch the
-    //   words, turn them into bins, merge the runs of a record, append the step's run words to a stage of FL::TILE words in
-    //   LDS (one returning add per step claims the positions).  The words of the NEXT step and the hit masks / word offsets of the
-    //   one after it are in flight meanwhile, and the wavefronts are at different points of the loop at any time: nobody
-    //   stands still for a memory round trip.
-    // B (when the stage is full or the work is done): the staged words are sorted by the first digit of their row group (WPL per
-    //   lane: rank, scan, place) and copied out to the group regions, one global cursor add per digit.
+    // A (no barrier inside): every wavefront walks over its share of the work in STEPS of NS rows of 64 words -- GS batches of
+    //   short records (a lane takes one record of each), one batch of long records, or NS x 64 singles --: fetch the rows (they
+    //   lie at A0 + 64 i + lane: one scalar base, constant offsets, nothing to read first), turn the words into bins, merge equal
+    //   neighbouring (row, bin) words of a record into one word with a count, append the step's words to a stage of FL::TILE words
+    //   in LDS (one returning add per step claims the positions).  The rows of the NEXT step are in flight meanwhile, and the
+    //   wavefronts are at different points of the loop at any time.
+    // B (when the stage is full or the work is done): the staged words are sorted by the first digit of their row group into a
+    //   second buffer (WPL per lane: rank, scan, place) and copied out to the group regions, one global cursor add per digit.
     using FL = MergeLds<BLK, DIG>;
+    using ST = MergeStep<CAP>;
     constexpr int DPT = DIG / BLK, WAVES_B = BLK / 64, WPL = FL::WPL;
-    constexpr int CXS = CAP > SHORT_MAX ? SHORT_MAX : CAP;       // k-mers per short record
-#ifndef PG_MERGE_NS
-#define PG_MERGE_NS 8
-#endif
-    constexpr int NS = PG_MERGE_NS < CAP ? CAP : PG_MERGE_NS;      // word slots of a step
-    constexpr int GS = CAP > SHORT_MAX ? NS / CXS : 0;           // batches of short records per step
-    constexpr uint32_t NONE = 0xffffffffu;                       // (never a word: rows stay below 2^20)
-    static_assert(CAP <= NS && GS * CXS <= NS && GS <= 4, "slots of a step");
+    constexpr int CXS = ST::CXS, NS = ST::NS, GS = ST::GS;
+    constexpr uint32_t NONE = WORD_NONE;
+    static_assert(CAP <= NS && GS * CXS <= NS, "slots of a step");
     __shared__ uint32_t staged, valid_end, busy;
     const uint16_t *bins16 = reinterpret_cast<const uint16_t *>(c.lds);
     uint32_t *buf = reinterpret_cast<uint32_t *>(c.lds + FL::BUF), *sorted = reinterpret_cast<uint32_t *>(c.lds + FL::BUF1), *cnt = reinterpret_cast<uint32_t *>(c.lds + FL::CNT);
     uint32_t *start = reinterpret_cast<uint32_t *>(c.lds + FL::START), *wave_tot = reinterpret_cast<uint32_t *>(c.lds + FL::WAVE);
     unsigned long long *gbase = reinterpret_cast<unsigned long long *>(c.lds + FL::GBASE);
     const ShufArgs &sh = c.sh;
-    const uint32_t smask = c.smask, np_all = uniform32(c.np_all);
+    const uint32_t smask = c.smask;
     const int lb = c.lb, vbits = c.vbits;
     uint32_t *const status = c.status;
     const uint32_t *const prov_b = c.prov_b;
-    const uint8_t *const hit_s = c.hit_s, *const hit_l = c.hit_l;
-    const uint32_t *const bat = c.bat;
-    const uint32_t n_short = uniform32(c.n_short), n_long = uniform32(c.n_long);
     const uint32_t lane = lane_id(), wave = uniform32(threadIdx.x >> 6);
     const uint32_t dmask = (1u << sh.gb1) - 1u;
     uint32_t *const wout = sh.words_out;
@@ -874,157 +886,53 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 #else
 #define PG_MLAP(K) do { } while (0)
 #endif
-    const uint32_t n_sb_all = uniform32(c.n_sb);                 // batches of short records as the count loop numbered them
-    const uint32_t n_sb = GS ? n_sb_all : 0u, n_lb = (n_long + 63u) >> 6, n_ring = uniform32(c.n_ring);
-    const uint32_t n_ss = GS ? (n_sb + GS - 1) / (GS ? GS : 1) : 0u;            // steps of short batches, then one step per long batch, then the singles
+    const uint32_t n_sb = GS ? uniform32(c.n_sb) : 0u, n_lb = uniform32(c.n_lb), n_ring = uniform32(c.n_ring);
+    const uint32_t long_base = uniform32(c.n_sb) * 64u * CXS, single_base = long_base + n_lb * 64u * CAP;
+    const uint32_t n_ss = GS ? (n_sb + GS - 1) / (GS ? GS : 1) : 0u;            // steps of short batches, then one per long batch, then the singles
     const uint32_t n_steps = n_ss + n_lb + (n_ring + 64u * NS - 1u) / (64u * NS);
-    const uint32_t *const ringw = prov_b + (np_all - n_ring);          // (scalar base: see uniform32)
-    // Every load below is UNCONDITIONAL, at an index clamped into the buffer, and NOTHING is computed from a loaded value where it
-    // is requested: a load under a per-lane condition is compiled as a branch around it (sixteen of those in a row, each with
-    // the base address reloaded and waited for, took the group one memory round trip at a time), and a select or a shift
-    // right behind a load makes the compiler wait for it there -- the prefetch would be gone.  Values are masked / extracted
-    // where they are USED, a step later.
-    // raw hit-mask words and word offsets of the batches of step `st` (slots 0..3: batches of a short step; slot 0: the long batch)
-    auto fetch_heads = [&](uint32_t st, uint32_t (&hw)[4], uint32_t (&at)[4]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { hw[t] = 0; at[t] = 0; }
-        if (st < n_ss) {                                         // (uniform)
-#pragma unroll
-            for (int t = 0; t < (GS ? GS : 1); ++t) {
-                const uint32_t bq = st * GS + t, bc = bq < n_sb ? bq : 0u;
-                // (through the dword that holds them: see row_hist_kernel on narrow loads)
-                hw[t] = reinterpret_cast<const uint32_t *>(hit_s)[bc * 16u + (lane >> 2)];
-                at[t] = bat[bc];
-            }
-        } else if (st < n_ss + n_lb) {
-            const uint32_t bq = st - n_ss;
-            hw[0] = reinterpret_cast<const uint32_t *>(hit_l)[bq * 32u + (lane >> 1)];
-            at[0] = bat[n_sb_all + bq];
-        }
-    };
-    // the hit masks of this lane's records out of the raw words
-    auto extract_heads = [&](uint32_t st, const uint32_t (&hw)[4], uint32_t (&h)[4]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) h[t] = 0;
+    if (n_steps == 0u) return;                                   // (uniform)
+    // a step's rows: first word of row 0 (A0), rows that belong to it (NV), words of its class (LIM), first slots of its records (GST)
+    struct StepGeo { uint32_t a0, nv, lim, gst; };
+    auto geometry = [&](uint32_t st) -> StepGeo {
+        StepGeo g;
         if (st < n_ss) {
+            const uint32_t left = n_sb - st * GS;
+            g.a0 = st * (64u * CXS * GS); g.nv = (left < (uint32_t)GS ? left : (uint32_t)GS) * CXS; g.lim = long_base;
+            g.gst = 0;
 #pragma unroll
-            for (int t = 0; t < (GS ? GS : 1); ++t) {
-                const uint32_t bq = st * GS + t;
-                h[t] = (bq < n_sb && bq * 64u + lane < n_short) ? (hw[t] >> (8u * (lane & 3u))) & 0xffu : 0u;
-            }
+            for (int t = 0; t < (GS ? GS : 1); ++t) g.gst |= 1u << (t * CXS);
         } else if (st < n_ss + n_lb) {
-            const uint32_t bq = st - n_ss;
-            h[0] = bq * 64u + lane < n_long ? (hw[0] >> (16u * (lane & 1u))) & 0xffffu : 0u;
-        }
-    };
-    // the words of step `st`, raw (requested here, masked and used a step later); np_all > 0 here
-    auto fetch_words = [&](uint32_t st, const uint32_t (&h)[4], const uint32_t (&at)[4], uint32_t (&w)[NS]) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) w[i] = NONE;
-        if (st < n_ss) {                                         // (uniform)
-            uint32_t idx[GS ? GS * CXS : 1];
-#pragma unroll
-            for (int t = 0; t < GS; ++t) {
-                uint32_t base = at[t];
-#pragma unroll
-                for (int j = 0; j < CXS; ++j) {
-                    const unsigned long long pmj = __builtin_amdgcn_ballot_w64((h[t] >> j) & 1u);
-                    const uint32_t i = base + lanes_below(pmj);
-                    idx[t * CXS + j] = i < np_all ? i : 0u;
-                    base += (uint32_t)__popcll(pmj);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < GS * CXS; ++i) w[i] = prov_b[idx[i]];
-        } else if (st < n_ss + n_lb) {
-            uint32_t idx[CAP];
-            uint32_t base = at[0];
-#pragma unroll
-            for (int j = 0; j < CAP; ++j) {
-                const unsigned long long pmj = __builtin_amdgcn_ballot_w64((h[0] >> j) & 1u);
-                const uint32_t i = base + lanes_below(pmj);
-                idx[j] = i < np_all ? i : 0u;
-                base += (uint32_t)__popcll(pmj);
-            }
-#pragma unroll
-            for (int j = 0; j < CAP; ++j) w[j] = prov_b[idx[j]];
-        } else if (st < n_steps) {
-            const uint32_t i0 = (st - n_ss - n_lb) * (64u * NS) + lane;
-#pragma unroll
-            for (int u = 0; u < NS; ++u) w[u] = ringw[i0 + 64u * u < n_ring ? i0 + 64u * u : 0u];
-        }
-    };
-    // raw words -> bins -> the run words of the step, in place (NONE: no run starts in that slot).  A run = equal neighbouring bins
-    // of ONE record; its first k-mer carries (length - 1) << MERGE_CSHIFT | row << vbits | bin
-    auto process = [&](uint32_t st, const uint32_t (&h)[4], uint32_t (&w)[NS]) {
-        // which slots hold a word of this lane
-        uint32_t have = 0;
-        if (st < n_ss) {
-#pragma unroll
-            for (int t = 0; t < GS; ++t) have |= (h[t] & ((1u << CXS) - 1u)) << (t * CXS);
-        } else if (st < n_ss + n_lb) {
-            have = h[0] & ((1u << CAP) - 1u);
+            g.a0 = long_base + (st - n_ss) * (64u * CAP); g.nv = CAP; g.lim = single_base; g.gst = 1u;
         } else {
-            const uint32_t i0 = (st - n_ss - n_lb) * (64u * NS) + lane;
-#pragma unroll
-            for (int u = 0; u < NS; ++u) have |= i0 + 64u * u < n_ring ? 1u << u : 0u;
+            g.a0 = single_base + (st - n_ss - n_lb) * (64u * NS); g.nv = NS; g.lim = single_base + n_ring; g.gst = (1u << NS) - 1u;
         }
-        if (st < n_ss + n_lb) {
-            // rows first (they sit in the words), then every slot becomes bin + 1 in place (0: no word, slot never filled, bin out
-            // of range): all reads of the bins in flight together, no second register array
-            uint32_t rows_[4] = {0, 0, 0, 0};
-            if (st < n_ss) {
+        return g;
+    };
+    // the loads of a step: a scalar base and constant offsets (whole rows; rows beyond the step's own are read and ignored: the
+    // buffer has slack for them).  Nothing is computed from the values here.
+    auto fetch_rows = [&](const StepGeo &g, uint32_t (&w)[NS]) {
+        const uint32_t *row0 = prov_b + g.a0;
 #pragma unroll
-                for (int t = 0; t < GS; ++t)
+        for (int i = 0; i < NS; ++i) w[i] = row0[64 * i + lane];
+    };
+    // raw words -> bins -> (row, bin) words; equal neighbours inside a record become ONE word with the run length on top
+    auto process = [&](const StepGeo &g, uint32_t (&w)[NS]) {
+        uint32_t b1[NS];
 #pragma unroll
-                    for (int j = 0; j < CXS; ++j) rows_[t] = (have >> (t * CXS + j)) & 1u ? w[t * CXS + j] >> lb : rows_[t];
-            } else {
+        for (int i = 0; i < NS; ++i) b1[i] = bins16[w[i] & smask];
 #pragma unroll
-                for (int j = 0; j < CAP; ++j) rows_[0] = (have >> j) & 1u ? w[j] >> lb : rows_[0];
-            }
+        for (int i = 0; i < NS; ++i) {
+            const bool ok = (uint32_t)i < g.nv && g.a0 + 64u * i + lane < g.lim && w[i] != NONE && (uint32_t)(b1[i] - 1u) < 0xfffeu;
+            w[i] = ok ? ((w[i] >> lb) << vbits) | (b1[i] - 1u) : NONE;
+        }
+        uint32_t len = 0;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) w[i] = bins16[w[i] & smask];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) w[i] = ((have >> i) & 1u) && (uint32_t)(w[i] - 1u) < 0xfffeu ? w[i] : 0u;
-            if (st < n_ss) {
-#pragma unroll
-                for (int t = 0; t < GS; ++t) {
-                    const uint32_t rowbits = rows_[t] << vbits;
-                    uint32_t len = 0;
-#pragma unroll
-                    for (int j = CXS - 1; j >= 0; --j) {
-                        const uint32_t cur = w[t * CXS + j];
-                        const uint32_t before = j > 0 ? w[t * CXS + (j > 0 ? j - 1 : 0)] : 0u;
-                        const bool head = cur != 0u && cur != before;
-                        w[t * CXS + j] = head ? (len << MERGE_CSHIFT) | rowbits | (cur - 1u) : NONE;
-                        len = (cur != 0u && !head) ? len + 1u : 0u;
-                    }
-                }
-#pragma unroll
-                for (int i = GS * CXS; i < NS; ++i) w[i] = NONE;
-            } else {
-                const uint32_t rowbits = rows_[0] << vbits;
-                uint32_t len = 0;
-#pragma unroll
-                for (int j = CAP - 1; j >= 0; --j) {
-                    const uint32_t cur = w[j];
-                    const uint32_t before = j > 0 ? w[j > 0 ? j - 1 : 0] : 0u;
-                    const bool head = cur != 0u && cur != before;
-                    w[j] = head ? (len << MERGE_CSHIFT) | rowbits | (cur - 1u) : NONE;
-                    len = (cur != 0u && !head) ? len + 1u : 0u;
-                }
-#pragma unroll
-                for (int i = CAP; i < NS; ++i) w[i] = NONE;
-            }
-        } else {
-            uint32_t b1[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) b1[i] = bins16[w[i] & smask];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const bool ok = ((have >> i) & 1u) && (uint32_t)(b1[i] - 1u) < 0xfffeu;
-                w[i] = ok ? ((w[i] >> lb) << vbits) | (b1[i] - 1u) : NONE;
-            }
+        for (int i = NS - 1; i >= 0; --i) {
+            const uint32_t cur = w[i];
+            const uint32_t before = (i == 0 || ((g.gst >> i) & 1u)) ? NONE : w[i > 0 ? i - 1 : 0];
+            const bool head = cur != NONE && cur != before;
+            w[i] = head ? (len << MERGE_CSHIFT) | cur : NONE;
+            len = (cur != NONE && !head) ? len + 1u : 0u;
         }
     };
     // this thread's digits of a tile: claim their ranges in the group regions (one global add per digit and tile), scan
@@ -1044,42 +952,29 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         for (int q = 0; q < DPT; ++q)                             // (the wait for global memory; unused for an empty digit)
             gbase[threadIdx.x * DPT + q] = g_region[q] + g_claimed[q] - start[threadIdx.x * DPT + q];
     };
-    if (np_all == 0u) return;                                    // (uniform: a bucket without a k-mer inside a row)
     if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }
     uint32_t step = wave;                                        // this wavefront's next step
-    bool pending = false;                                        // pw[] holds run words that did not fit the stage yet (wave-uniform)
-    uint32_t pw[NS];                                             // the run words of the step in hand
-    uint32_t cw[NS];                                             // the raw words of `step`, in flight or here (not kept across stage B)
-    uint32_t ch[4], cat[4];                                      // hit masks and word offsets of `step`
-    uint32_t nhw[4], nat[4];                                     // raw heads of the step after it (not kept across stage B)
-    {
-        uint32_t hw0[4];
-        fetch_heads(step, hw0, cat);
-        extract_heads(step, hw0, ch);
-    }
+    bool pending = false;                                        // pw[] holds words that did not fit the stage yet (wave-uniform)
+    uint32_t pw[NS];                                             // the words of the step in hand
+    uint32_t cw[NS];                                             // the raw rows of `step`, in flight or here (not kept across stage B)
     lds_sync();
     for (;;) {
-        // the words of `step` (their heads are here) and the heads of the step after it: at the start, and again behind every
-        // stage B, which had the registers
-        fetch_words(step, ch, cat, cw);
-        fetch_heads(step + WAVES_B, nhw, nat);
+        // the rows of `step`: at the start, and again behind every stage B, which had the registers
+        fetch_rows(geometry(step < n_steps ? step : 0u), cw);
         // ---- A
         for (;;) {
             if (!pending) {
                 if (step >= n_steps) break;                      // (uniform)
-                const uint32_t st = step;
-                uint32_t ph[4];
+                const StepGeo g = geometry(step);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) pw[i] = cw[i];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) ph[t] = ch[t];
                 step += WAVES_B;
-                extract_heads(step, nhw, ch);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) cat[t] = nat[t];
-                fetch_words(step, ch, cat, cw);                  // the next step's words and the heads of the one after it: in flight
-                fetch_heads(step + WAVES_B, nhw, nat);           // while this step is worked on
-                process(st, ph, pw);
+                // (scheduling barriers: the compiler must neither sink these requests below the work on the step in hand nor pull
+                // that work -- and with it the wait for what was just requested -- up in front of them)
+                __builtin_amdgcn_sched_barrier(0);
+                fetch_rows(geometry(step < n_steps ? step : 0u), cw);      // the next step's rows: in flight while this one is worked on
+                __builtin_amdgcn_sched_barrier(0);
+                process(g, pw);
                 pending = true;
             }
             uint32_t n = 0;
@@ -1234,10 +1129,13 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // every occurrence that lies in a row leaves exactly one word: the bucket's word range is claimed before the first word is
         // written (one global add).  The total comes with the records (the second scatter pass tallies it per bucket); without that
         // pass -- at most 256 buckets -- a pre-pass over the meta plane counts it.
+        // (MERGE: fixed slots for the words of every batch, then room for the singles -- see MergeArgs)
+        const unsigned long long fixed_words = MERGE ? 64ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
+                                                       + 64ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP : 0ull;
         if (kwords) {
             if (threadIdx.x == 0) {
                 n_lookups = kwords[blockIdx.x];
-                wbase = atomicAdd(word_cursor, n_lookups);
+                wbase = atomicAdd(word_cursor, n_lookups + fixed_words);
             }
         } else {
             unsigned long long mine = 0;
@@ -1253,16 +1151,26 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 unsigned long long run = 0;
                 for (int w = 0; w < (BLK / 64); ++w) run += wave_words[w];
                 n_lookups = run;
-                wbase = atomicAdd(word_cursor, run);
+                wbase = atomicAdd(word_cursor, run + fixed_words);
             }
         }
     }
     __syncthreads();
+    if (MERGE && emit_slots) {
+        // (the word buffer was sized from the plan's record counts; a range that does not fit it -- a plan of other reads -- is
+        // not written: bit 2 of the status word, as for the record buffers)
+        const unsigned long long need = n_lookups + 64ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
+                                        + 64ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP + 64ull * MergeStep<CAP>::NS;
+        if (wbase + need > mg.cap) {                             // (uniform)
+            if (threadIdx.x == 0) atomicOr(status, PG_STATUS_PLAN_MISMATCH);
+            return;
+        }
+    }
     unsigned long long wb = emit_slots ? wbase : 0ull;
     // (read from LDS, hence a vector register to the compiler; made a scalar so that the words' addresses are a scalar base + a
     // 32-bit lane offset instead of a 64-bit sum per lane and load)
     wb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wb);
-    uint32_t *const prov_b = prov + wb;                          // the bucket's words (32-bit positions from here on)
+    uint32_t *const prov_b = (MERGE ? mg.prov : prov) + wb;      // the bucket's words (32-bit positions from here on)
     // words are placed by claiming positions on the bucket's LDS counter `emitted`: ONE returning add per batch of 64 records
     // (all its first-probe hits) and one per general insert round, by lane 0
     auto claim = [&](uint32_t n_words) -> uint32_t {
@@ -1270,11 +1178,10 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (lane == 0) at = atomicAdd(&emitted, n_words);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
     };
-    // MERGE: where this bucket's per-record hit masks and per-batch word offsets live (see MergeArgs)
-    const uint32_t n_sb = (uint32_t)((rs - r0 + 63) >> 6);        // batches of short records (the long ones follow)
-    uint8_t *const hit_s = MERGE ? mg.hit + (((uint64_t)2 * (uint64_t)r0 + 8ull * blockIdx.x) & ~3ull) : nullptr;
-    uint8_t *const hit_l = MERGE ? hit_s + (((uint64_t)(rs - r0) + 3ull) & ~3ull) : nullptr;        // 2 bytes per long record
-    uint32_t *const bat = MERGE ? mg.batch_at + ((uint64_t)r0 >> 6) + 3ull * blockIdx.x : nullptr;
+    // MERGE: the bucket's word range = batches of short records | batches of long records | singles (see MergeArgs)
+    constexpr uint32_t CXS_ = CAP > SHORT_MAX ? SHORT_MAX : CAP;
+    const uint32_t n_sb = (uint32_t)((rs - r0 + 63) >> 6), n_lb = (uint32_t)((r1 - rs + 63) >> 6);
+    const uint32_t long_base = n_sb * 64u * CXS_, single_base = long_base + n_lb * 64u * CAP;
     const uint32_t np_all = (uint32_t)n_lookups;                 // (emit_slots: the bucket's words, known before the first is written)
     PG_STAMP(0);
     bool full = false;
@@ -1292,11 +1199,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             const bool put = rw != MINI_ROW_NONE;
             const unsigned long long qm = __ballot(put);
             if (qm) {                                            // (uniform)
-                if (MERGE) {                                     // singles: from the end of the bucket's range downwards
+                if (MERGE) {                                     // singles: behind the batches' fixed slots
                     uint32_t at = 0;
                     if (lane == 0) at = atomicAdd(&emitted_ring, (uint32_t)__popcll(qm));
                     at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-                    if (put) gstore(prov_b, (uint64_t)np_all - 1u - (at + lanes_below(qm)), (uint64_t)np_all, (rw << lb) | (sl & smask), status);
+                    if (put) gstore(prov_b, (uint64_t)single_base + at + lanes_below(qm), (uint64_t)single_base + np_all, (rw << lb) | (sl & smask), status);
                 } else {
                     const uint32_t at = claim((uint32_t)__popcll(qm));
                     if (put) gstore(prov_b, (uint64_t)at + lanes_below(qm), (uint64_t)np_all, (rw << lb) | (sl & smask), status);
@@ -1372,7 +1279,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 uint32_t total = 0;
 #pragma unroll
                 for (int j = 0; j < CX; ++j) total += (uint32_t)__popcll(pm[j]);
-                if (total) at = claim(total);                    // (uniform)
+                if (total && !MERGE) at = claim(total);          // (uniform; the MERGE form's words have fixed places)
             }
             PG_WLAP(2);                                          // (hits added, positions claimed)
 #pragma unroll
@@ -1400,25 +1307,23 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             PG_WLAP(3);                                          // (ring pushes, general inserts)
             if (emit_slots) {
                 if (MERGE) {
-                    // which of this lane's k-mers left a word (one byte per short record, two per long one), and where the
-                    // batch's words start
-                    uint32_t hm = 0;
+                    // fixed slots: row j of the batch = the j-th k-mers of its 64 records, whole rows, NONE where a k-mer left no word
+                    uint32_t *rowp = prov_b + (CX < CAP ? 0u : long_base) + (uint32_t)((i0 - ra) >> 6) * (64u * CX) + lane;
 #pragma unroll
-                    for (int j = 0; j < CX; ++j) hm |= __builtin_amdgcn_inverse_ballot_w64(pm[j]) ? 1u << j : 0u;
-                    const uint32_t rel = (uint32_t)(i0 - ra) + lane;
-                    if (CX <= 8 && CX < CAP) { if (live) hit_s[rel] = (uint8_t)hm; }
-                    else { if (live) reinterpret_cast<uint16_t *>(hit_l)[rel] = (uint16_t)hm; }
-                    if (lane == 0) bat[(CX < CAP ? 0u : n_sb) + (uint32_t)((i0 - ra) >> 6)] = at;
-                }
+                    for (int j = 0; j < CX; ++j)
+                        rowp[64 * j] = __builtin_amdgcn_inverse_ballot_w64(pm[j]) ? (row << lb) | sl[j] : WORD_NONE;
+                } else
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
                 // shuffle do not like runs of equal words).  (Deferring these stores to the next iteration's top, behind its
                 // vmcnt wait, changed nothing: 17.33 ms either way.)
+                {
 #pragma unroll
                 for (int j = 0; j < CX; ++j) {
 #if !(PG_DIAG_COUNT & 1)
                     if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) gstore(prov_b, (uint64_t)at + lanes_below(pm[j]), (uint64_t)np_all, (row << lb) | sl[j], status);
 #endif
                     at += (uint32_t)__popcll(pm[j]);
+                }
                 }
             }
             PG_WLAP(4);                                          // (the words' stores, waited for)
@@ -1545,9 +1450,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (MERGE) {
             MergeCtx mc;
             mc.lds = lds; mc.smask = smask; mc.lb = lb; mc.vbits = vbits; mc.sh = sh; mc.status = status;
-            mc.prov_b = prov_b; mc.np_all = np_all; mc.n_ring = emitted_ring;
-            mc.hit_s = hit_s; mc.hit_l = hit_l; mc.bat = bat;
-            mc.n_short = (uint32_t)(rs - r0); mc.n_long = (uint32_t)(r1 - rs); mc.n_sb = n_sb;
+            mc.prov_b = prov_b; mc.n_sb = n_sb; mc.n_lb = n_lb; mc.n_ring = emitted_ring;
 #ifdef PG_MINI_STAMPS
             mc.dbg = dbg;
 #endif
@@ -1945,19 +1848,11 @@ bool mini_merge_form(const pg_table *t, const pg_rows *rows, int vsize)
     return vbits + 6 + gbits <= MERGE_CSHIFT;
 }
 
-// the record workspace: [bases A | bases B | meta A | meta B] of `cap` records each, then the planes of the merged lookups --
-// one hit mask per record (bucket b's from byte (2 off[b] + 8 b) & ~3: a byte per short record, two per long one) and one
-// word offset per batch of 64 records (bucket b's from entry off[b] / 64 + 3 b)
-struct MiniRecLayout { size_t cap, hit_off, bat_off, total; };
-MiniRecLayout mini_rec_layout(size_t cap, size_t nb)
+// the record workspace: [bases A | bases B | meta A | meta B] of `cap` records each
+struct MiniRecLayout { size_t cap, total; };
+MiniRecLayout mini_rec_layout(size_t cap, size_t)
 {
-    MiniRecLayout l;
-    l.cap = cap;
-    l.hit_off = 24 * cap;
-    const size_t hit_bytes = (2 * cap + 8 * nb + 256 + 255) / 256 * 256;
-    l.bat_off = l.hit_off + hit_bytes;
-    l.total = l.bat_off + (4 * (cap / 64 + 3 * nb + 8) + 255) / 256 * 256;
-    return l;
+    return MiniRecLayout{cap, 24 * cap};
 }
 
 int check_mini_rows(const pg_rows *rows, const char *who)
@@ -2064,7 +1959,7 @@ extern "C" int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_
             hipLaunchKernelGGL((mini_plan_kernel<W, DELAY, M>), dim3(grid), dim3(BLOCK), 0, s, codes, valid, word_begin, word_end, t->k, woff, p.bits, p.bits2, mini_cap(t->k),
                                with_rows ? rows->row_start : (const int64_t *)nullptr, with_rows ? rows->row_end : (const int64_t *)nullptr,
                                with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr,
-                               (const int32_t *)round_row, chunk_tab, p.n_chunks, p.chunk_stride))
+                               (const int32_t *)round_row, chunk_tab, p.n_chunks, p.chunk_stride, header + 2))
     }
     // records per region -> where the regions start -> exact offset of every (chunk, region) run; total -> header[0]
     hipLaunchKernelGGL(digit_totals_kernel, dim3((unsigned)n_regions), dim3(BIG_BLOCK), 0, s, (const unsigned long long *)chunk_tab, p.n_chunks, region_tot);
@@ -2091,7 +1986,8 @@ extern "C" int pg_mini_wait_first_pass(void *stream)
 // k-mers); its slots are never written.
 static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                            const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
-                           int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream, const HalfArgs *half)
+                           int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream, const HalfArgs *half,
+                           void *merge_ws = nullptr, int64_t merge_ws_words = 0)
 {
     if (!codes || !valid || !plan_ws || !rec_ws || !status) return pg_fail(PG_EINVAL, "pg_mini_count: null argument");
     if (word_begin < 0 || word_end < word_begin) return pg_fail(PG_EINVAL, "pg_mini_count: bad word range");
@@ -2119,7 +2015,6 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
         while (cap >= 256 && mini_rec_layout(cap, nb_l).total > (size_t)rec_ws_bytes) cap -= 256;
     }
     if (cap < 256) return pg_fail(PG_EINVAL, "pg_mini_count: record workspace of %lld bytes (pg_mini_records_bytes)", (long long)rec_ws_bytes);
-    const MiniRecLayout rl = mini_rec_layout(cap, nb_l);
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)plan_ws;
     auto *header = (unsigned long long *)(ws + p.header_off);
@@ -2191,8 +2086,9 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     uint32_t *words_e = window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr;
     uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
     ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0ull};
-    const MergeArgs mg{(uint8_t *)rec_ws + rl.hit_off, (uint32_t *)((char *)rec_ws + rl.bat_off)};
-    const bool merge = window > 0 && !half && mini_merge_form(t, rows, vsize);
+    const MergeArgs mg{(uint32_t *)merge_ws, (unsigned long long)(merge_ws ? merge_ws_words : 0)};
+    const bool merge = window > 0 && !half && merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize);
+    if (merge_ws && (reinterpret_cast<uintptr_t>(merge_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_count: workspaces must be 256-byte aligned");
     if (half && (wide || !(window > 0 && mini_slots_form(t, rows))))
         return pg_fail(PG_EINVAL, "pg_mini_count_half: needs packed slots (k <= %d), rows and fewer than 2^(32 - log2 bucket slots) of them", PG_HASH_MAX_K);
     if (half && !p.bits2) return pg_fail(PG_EINVAL, "pg_mini_count_half: needs more than 256 buckets");
@@ -2261,10 +2157,30 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
 
 extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                              const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
-                             int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, uint32_t *status, void *stream)
+                             int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *merge_ws, int64_t merge_ws_words,
+                             uint32_t *status, void *stream)
 {
     return mini_count_impl(codes, valid, word_begin, word_end, t, rows, plan_ws, plan_ws_bytes, rec_ws, rec_ws_bytes, window, vsize, shuffle_ws,
-                           shuffle_ws_bytes, status, stream, nullptr);
+                           shuffle_ws_bytes, status, stream, nullptr, merge_ws, merge_ws_words);
+}
+
+// words of the merged form's provisional-word buffer (pg_mini_count's merge_ws): fixed slots for every batch of 64 records of
+// either class, room for the singles (at most one per character), a step's slack.  n_records / n_long_records: the first and
+// third 8-byte word of the plan workspace.
+extern "C" int64_t pg_mini_merge_words(int64_t n_words, int64_t n_records, int64_t n_long_records, const pg_table *t)
+{
+    int rc = check_mini(t, "pg_mini_merge_words");
+    if (rc) return rc;
+    if (n_words < 0 || n_records < 0 || n_long_records < 0 || n_long_records > n_records) return pg_fail(PG_EINVAL, "pg_mini_merge_words: bad counts");
+    const int64_t nb = (int64_t)1 << (t->log2_slots - t->log2_bucket_slots);
+    const int cap = mini_cap(t->k);
+    const int cap_t = cap <= 4 ? 4 : cap <= 6 ? 6 : cap <= 8 ? 8 : 9;           // (the kernels' instantiations)
+    MiniPlan p;
+    plan_mini(t, n_words, &p);
+    const bool two = cap_t > SHORT_MAX && p.bits2 > 0;               // (without a second scatter pass the classes are not sorted apart: all "long")
+    const int64_t n_long = two ? n_long_records : n_records, n_short = two ? n_records - n_long_records : 0;
+    const int64_t fixed = 64 * (int64_t)(two ? SHORT_MAX : cap_t) * (n_short / 64 + nb) + 64 * (int64_t)cap_t * (n_long / 64 + nb);
+    return (fixed + n_words * 32 + 64 * 16 + 255) / 256 * 256;
 }
 
 // ---- N > 1 ranks (see the kernels above): workspace of the count half: entry slabs | occupancy bitmaps | ring counts

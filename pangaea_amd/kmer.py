@@ -374,7 +374,8 @@ class KmerTable:
                 event.synchronize()
                 if self._mini_plan is not None:
                     self._mini_spare = self._mini_plan[1]
-                self._mini_plan = (key, ws, int(ws[:8].view(torch.int64).item()), keep, held)
+                head = ws[:24].view(torch.int64).cpu()                     # (records, -, records of more than four k-mers)
+                self._mini_plan = (key, ws, int(head[0]), keep, held, int(head[2]))
                 self._mini_next = None
             if self._mini_plan is None or self._mini_plan[0] != key:
                 need = _lib.check(L.pg_mini_plan_bytes(n_words, self.desc()))
@@ -384,10 +385,11 @@ class KmerTable:
                     ws = torch.empty(need, dtype=torch.uint8, device=self.device)
                 _lib.check(L.pg_mini_plan(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
                                           ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
-                n_records = int(ws[:8].view(torch.int64).item())          # (host sync; once per plan)
+                head = ws[:24].view(torch.int64).cpu()                     # (host sync; once per plan: records, -, long records)
+                n_records = int(head[0])
                 if self._mini_plan is not None:
                     self._mini_spare = self._mini_plan[1]
-                self._mini_plan = (key, ws, n_records, keep, held)
+                self._mini_plan = (key, ws, n_records, keep, held, int(head[2]))
             _, plan_ws, n_records = self._mini_plan[:3]
             need = _lib.check(L.pg_mini_records_bytes(n_records, self.desc()))
             if self._mini_rec_ws is None or self._mini_rec_ws.numel() != need:
@@ -415,9 +417,19 @@ class KmerTable:
                                                 fill.data_ptr(), self.status.data_ptr(), _stream_ptr(self.device)))
                 self._half = (fill, n_words, keep, window, vsize)
             else:
+                mws_ptr, mws_n = None, 0
+                if fuse and os.environ.get("PG_MINI_MERGE", "0") not in ("", "0"):
+                    # the merged form of the lookups (opt-in): its provisional words lie in fixed slots per record, sized from the
+                    # plan's record counts (records, and records of more than four k-mers: 1st and 3rd word of the plan workspace)
+                    n_long = self._mini_plan[5]
+                    need = _lib.check(L.pg_mini_merge_words(n_words, n_records, n_long, self.desc()))
+                    if getattr(self, "_merge_ws", None) is None or self._merge_ws.numel() < need:
+                        self._merge_ws = None
+                        self._merge_ws = torch.empty(need, dtype=torch.int32, device=self.device)
+                    mws_ptr, mws_n = self._merge_ws.data_ptr(), self._merge_ws.numel()
                 _lib.check(L.pg_mini_count(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
                                            plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
-                                           window, vsize, sws_ptr, sws_n, self.status.data_ptr(), _stream_ptr(self.device)))
+                                           window, vsize, sws_ptr, sws_n, mws_ptr, mws_n, self.status.data_ptr(), _stream_ptr(self.device)))
         self._empty = False
         self._records = (keep, n_words) if fuse and not half else None
         self._emitted = (window, vsize) if fuse and not half else None
