@@ -418,9 +418,10 @@ class KmerTable:
                 self._half = (fill, n_words, keep, window, vsize)
             else:
                 mws_ptr, mws_n = None, 0
-                if fuse and os.environ.get("PG_MINI_MERGE", "0") not in ("", "0"):
-                    # the merged form of the lookups (opt-in): its provisional words lie in fixed slots per record, sized from the
-                    # plan's record counts (records, and records of more than four k-mers: 1st and 3rd word of the plan workspace)
+                if fuse and os.environ.get("PG_MINI_MERGE", "1") not in ("", "0"):
+                    # the merged form of the lookups (PG_MINI_MERGE=0: word-wise): its provisional words lie in fixed slots per record,
+                    # sized from the plan's record counts (records, and records of more than four k-mers: 1st and 3rd word of the plan
+                    # workspace); the library falls back to the word-wise form where the merged one does not apply
                     n_long = self._mini_plan[5]
                     need = _lib.check(L.pg_mini_merge_words(n_words, n_records, n_long, self.desc()))
                     if getattr(self, "_merge_ws", None) is None or self._merge_ws.numel() < need:

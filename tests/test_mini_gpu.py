@@ -385,7 +385,7 @@ def test_merged_runs_equal_the_word_wise_lookups(sub_rate, coverage_genomes, win
     """the lookup phase lets runs of equal neighbouring bins of a record travel as one word with a count (MERGE form).  High
     coverage and few errors: nearly every record is one run; window 1 with 5 % substitutions and uneven coverage: neighbours
     rarely share a bin, a tile's runs overflow the LDS stage and are laid out in several windows.  Same rows as the word-wise
-    form (the default), as the lookup kernel, and as the oracle; both workgroup sizes."""
+    form (PG_MINI_MERGE=0), as the lookup kernel, and as the oracle; both workgroup sizes."""
     cfg = synth.SynthConfig(n_pairs=120_000, n_barcodes=900, n_genomes=coverage_genomes, genome_len=60_000, fragment=20_000,
                             sub_rate=sub_rate, n_rate=0.05, seed=1234)
     s = synth.generate(cfg, device=DEV)
@@ -419,7 +419,7 @@ def test_super_kmer_kernels_through_the_checked_build():
     from .conftest import ROOT
     if os.environ.get("PANGAEA_LIB") == "checked":
         pytest.skip("already inside the checked pass")
-    for merge in ("0", "1"):                   # word-wise lookups (the default) and the merged form
+    for merge in ("1", "0"):                   # the merged lookups (the default) and the word-wise form
         _checked_pass(merge)
 
 
