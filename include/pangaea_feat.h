@@ -393,18 +393,19 @@ int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int v
  *   pg_mini_lookup_half   bins_in[bin_elem[b] ..) = the bins of bucket b's entries, in the order they were sent -> the lookups of
  *                         the provisional words and the row-group scatter, exactly as pg_mini_count ends;
  *                         pg_mini_abundance_from_emitted(local, ...) then writes the rows.
- * half_ws: pg_mini_half_bytes(local), 256-byte aligned device memory. */
+ * half_ws: pg_mini_half_bytes(local), 256-byte aligned device memory; merge_ws as for pg_mini_count (the same buffer in both calls). */
 int64_t pg_mini_half_bytes(const pg_table *local);
 int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *local,
                        const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
-                       int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *half_ws, int64_t half_ws_bytes,
-                       int64_t *fill, uint32_t *status, void *stream);
+                       int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *merge_ws, int64_t merge_ws_words,
+                       void *half_ws, int64_t half_ws_bytes, int64_t *fill, uint32_t *status, void *stream);
 int pg_mini_gather_entries(const pg_table *local, const void *half_ws, int64_t half_ws_bytes, const int64_t *fill,
                            const int64_t *dst_elem, uint64_t *out, void *stream);
 int pg_mini_merge_bins(const uint64_t *recv, int64_t part_stride, const int64_t *seg, int n_parts, const pg_table *t,
                        int64_t bucket_begin, int64_t bucket_end, int window, int vsize, uint16_t *bins_out, uint32_t *status, void *stream);
 int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
-                        int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *half_ws, int64_t half_ws_bytes,
+                        int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *merge_ws, int64_t merge_ws_words,
+                        const void *half_ws, int64_t half_ws_bytes,
                         const uint16_t *bins_in, const int64_t *bin_elem, uint32_t *status, void *stream);
 
 /* ----------------------------------------------------------------------------------------------

@@ -1743,6 +1743,54 @@ __global__ __launch_bounds__(BLK, 4) void mini_lookup_half_kernel(const unsigned
     wordwise_lookup<BLK, DIG>(wc);
 }
 
+// the merged form of the lookup half: the count half left its provisional words in fixed slots (MergeArgs)
+template <int CAP, int BLK, int DIG>
+__global__ __launch_bounds__(BLK, 4) void mini_lookup_half_merge_kernel(const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ n_short,
+                                                                      const unsigned long long *__restrict__ wbeg, const uint32_t *__restrict__ ring_cnt,
+                                                                      const unsigned long long *__restrict__ occ,
+                                                                      const uint16_t *__restrict__ bins_in, const long long *__restrict__ bin_elem,
+                                                                      int log2_bucket, int vbits, const uint32_t *__restrict__ mprov, ShufArgs sh, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t n_slots = 1u << log2_bucket, smask = n_slots - 1u;
+    const uint32_t n_occ = n_slots >= 64u ? n_slots >> 6 : 1u;
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    const int64_t rs = n_short && CAP > SHORT_MAX ? r0 + (int64_t)n_short[blockIdx.x] : r0;
+    uint16_t *bins16 = reinterpret_cast<uint16_t *>(lds);
+    const uint16_t *bi = bins_in + bin_elem[blockIdx.x];
+    unsigned long long *occ_l = reinterpret_cast<unsigned long long *>(lds + MergeLds<BLK, DIG>::BUF);          // [n_occ] words, then [n_occ] ranks
+    uint32_t *rank_l = reinterpret_cast<uint32_t *>(occ_l + n_occ);
+    for (uint32_t wi = threadIdx.x; wi < n_occ; wi += BLK) occ_l[wi] = occ[(uint64_t)blockIdx.x * n_occ + wi];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < n_occ; w0 += 64) {
+            const uint32_t wi = w0 + threadIdx.x;
+            const uint32_t c = wi < n_occ ? (uint32_t)__popcll(occ_l[wi]) : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if ((int)threadIdx.x >= d) incl += o;
+            }
+            if (wi < n_occ) rank_l[wi] = run + incl - c;
+            run += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BLK) {
+        const unsigned long long m = occ_l[i >> 6];
+        bins16[i] = (m >> (i & 63u)) & 1ull ? bi[rank_l[i >> 6] + (uint32_t)__popcll(m & ((1ull << (i & 63u)) - 1ull))] : (uint16_t)0;
+    }
+    __syncthreads();
+    MergeCtx mc;
+    mc.lds = lds; mc.smask = smask; mc.lb = log2_bucket; mc.vbits = vbits; mc.sh = sh; mc.status = status;
+    mc.prov_b = mprov + wbeg[blockIdx.x];
+    mc.n_sb = (uint32_t)((rs - r0 + 63) >> 6); mc.n_lb = (uint32_t)((r1 - rs + 63) >> 6); mc.n_ring = ring_cnt[blockIdx.x];
+    mc.dbg = nullptr;
+    merged_lookup<CAP, BLK, DIG>(mc);
+}
+
 // ---- workspace of the plan: header | region_tot | region_off | off | hist | cur2 | cur2l | kwords | wbeg | round_row | chunk table
 struct MiniPlan {
     int bits, bits1, bits2;
@@ -2086,7 +2134,7 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
     ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0ull};
     const MergeArgs mg{(uint32_t *)merge_ws, (unsigned long long)(merge_ws ? merge_ws_words : 0)};
-    const bool merge = window > 0 && !half && merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize);
+    const bool merge = window > 0 && merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize);
     if (merge_ws && (reinterpret_cast<uintptr_t>(merge_ws) & 255) != 0) return pg_fail(PG_EINVAL, "pg_mini_count: workspaces must be 256-byte aligned");
     if (half && (wide || !(window > 0 && mini_slots_form(t, rows))))
         return pg_fail(PG_EINVAL, "pg_mini_count_half: needs packed slots (k <= %d), rows and fewer than 2^(32 - log2 bucket slots) of them", PG_HASH_MAX_K);
@@ -2134,8 +2182,10 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     } while (0)
 #define PG_MINI_LAUNCH_COUNT(CAP_)                                                                                          \
     do {                                                                                                                    \
-        if (half) { if (half_block) PG_MINI_LAUNCH_COUNT__(CAP_, true, false, 512, 1024, false, true, count_lds);            \
-                    else PG_MINI_LAUNCH_COUNT__(CAP_, true, false, BIG_BLOCK, 1024, false, true, count_lds); }               \
+        if (half) { if (half_block) { if (merge) PG_MINI_LAUNCH_COUNT__(CAP_, true, false, 512, 1024, true, true, count_lds);  \
+                                      else PG_MINI_LAUNCH_COUNT__(CAP_, true, false, 512, 1024, false, true, count_lds); }   \
+                    else { if (merge) PG_MINI_LAUNCH_COUNT__(CAP_, true, false, BIG_BLOCK, 1024, true, true, count_lds);     \
+                           else PG_MINI_LAUNCH_COUNT__(CAP_, true, false, BIG_BLOCK, 1024, false, true, count_lds); } }      \
         else if (wide) { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, true); else PG_MINI_LAUNCH_COUNT_(CAP_, false, true, BIG_BLOCK, 1024, false, slice_lds); } \
         else if (half_block) PG_MINI_LAUNCH_SLOTS_(CAP_, false, 512, 1024);                                                  \
         else { if (slots_form) PG_MINI_LAUNCH_SLOTS(CAP_, false); else PG_MINI_LAUNCH_COUNT_(CAP_, false, false, BIG_BLOCK, 1024, false, slice_lds); } \
@@ -2209,8 +2259,8 @@ extern "C" int64_t pg_mini_half_bytes(const pg_table *local)
 
 extern "C" int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *local,
                                   const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
-                                  int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *half_ws, int64_t half_ws_bytes,
-                                  int64_t *fill, uint32_t *status, void *stream)
+                                  int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *merge_ws, int64_t merge_ws_words,
+                                  void *half_ws, int64_t half_ws_bytes, int64_t *fill, uint32_t *status, void *stream)
 {
     int rc = check_mini(local, "pg_mini_count_half");
     if (rc) return rc;
@@ -2221,7 +2271,7 @@ extern "C" int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, 
     char *hw = (char *)half_ws;
     const HalfArgs hv{(unsigned long long *)(hw + hl.ent_off), (unsigned long long *)(hw + hl.occ_off), (long long *)fill, (uint32_t *)(hw + hl.ring_off)};
     return mini_count_impl(codes, valid, word_begin, word_end, local, rows, plan_ws, plan_ws_bytes, rec_ws, rec_ws_bytes, window, vsize, shuffle_ws,
-                           shuffle_ws_bytes, status, stream, &hv);
+                           shuffle_ws_bytes, status, stream, &hv, merge_ws, merge_ws_words);
 }
 
 extern "C" int pg_mini_gather_entries(const pg_table *local, const void *half_ws, int64_t half_ws_bytes, const int64_t *fill,
@@ -2258,7 +2308,8 @@ extern "C" int pg_mini_merge_bins(const uint64_t *recv, int64_t part_stride, con
 }
 
 extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
-                                   int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *half_ws, int64_t half_ws_bytes,
+                                   int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *merge_ws, int64_t merge_ws_words,
+                                   const void *half_ws, int64_t half_ws_bytes,
                                    const uint16_t *bins_in, const int64_t *bin_elem, uint32_t *status, void *stream)
 {
     int rc = check_mini(local, "pg_mini_lookup_half");
@@ -2279,9 +2330,35 @@ extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, c
     pg_shuffle_ctx ctx;
     if ((rc = pg_internal_shuffle_prepare(n_words_counted * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS))) return rc;
     if (ctx.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: %d first-pass digits of the row shuffle", ctx.gb1);
-    const ShufArgs sh{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, ctx.narrow, ctx.words_cap};
+    const bool merge = merge_ws && merge_ws_words > 0 && mini_merge_form(local, rows, vsize);         // (as the count half decided)
+    const ShufArgs sh{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, merge ? 0 : ctx.narrow, ctx.words_cap};
     const unsigned nb = 1u << p.bits;
     const auto *occ = (const unsigned long long *)((const char *)half_ws + hl.occ_off);
+    if (merge) {
+        const auto *off = (const unsigned long long *)(ws + p.off_off);
+        const auto *cur2 = (const unsigned long long *)(ws + p.cur2_off);
+        const auto *ring = (const uint32_t *)((const char *)half_ws + hl.ring_off);
+        const int cap_k = mini_cap(local->k);
+        const unsigned long long *n_short = cap_k > SHORT_MAX ? cur2 : (const unsigned long long *)nullptr;
+        hipStream_t s2 = (hipStream_t)stream;
+#define PG_LOOKUP_HALF_M(CAP_, DIG_)                                                                                        \
+        do {                                                                                                                \
+            const size_t lds_ = MergeLds<BIG_BLOCK, DIG_>::END;                                                             \
+            if ((rc = raise_lds_limit((const void *)(mini_lookup_half_merge_kernel<CAP_, BIG_BLOCK, DIG_>), lds_, "pg_mini_lookup_half"))) return rc; \
+            hipLaunchKernelGGL((mini_lookup_half_merge_kernel<CAP_, BIG_BLOCK, DIG_>), dim3(nb), dim3(BIG_BLOCK), lds_, s2, off, n_short, wbeg, ring, occ, \
+                               bins_in, (const long long *)bin_elem, local->log2_bucket_slots, ctx.vbits, (const uint32_t *)merge_ws, sh, status); \
+        } while (0)
+#define PG_LOOKUP_HALF_MC(CAP_) do { if (ctx.gb1 > 10) PG_LOOKUP_HALF_M(CAP_, 2048); else PG_LOOKUP_HALF_M(CAP_, 1024); } while (0)
+        switch (cap_k) {
+        case 1: case 2: case 3: case 4: PG_LOOKUP_HALF_MC(4); break;
+        case 5: case 6: PG_LOOKUP_HALF_MC(6); break;
+        case 7: case 8: PG_LOOKUP_HALF_MC(8); break;
+        default: PG_LOOKUP_HALF_MC(9); break;
+        }
+#undef PG_LOOKUP_HALF_MC
+#undef PG_LOOKUP_HALF_M
+        return check_launch("pg_mini_lookup_half");
+    }
     // 1024-thread workgroups whatever the bucket size: tiles of 16 Ki words keep the runs per row group at 32 bytes -- with
     // 512 threads (8 Ki-word tiles, two workgroups per CU) this kernel took 14.1 ms where the one-GPU kernel's lookup phase
     // takes 8.5 (PG_LOOKUP_HALF_512=1: that form, for comparison)

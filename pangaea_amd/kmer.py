@@ -63,6 +63,7 @@ class KmerTable:
         self._mini_rec_ws = None
         self._half = None                # (fill, n_words, rows, window, vsize) between count_half and lookup_half (N > 1 ranks)
         self._half_ws = None
+        self._merge_ws = None            # the provisional words of the merged lookups (fixed slots per record)
 
     # ------------------------------------------------------------------ construction
 
@@ -403,6 +404,16 @@ class KmerTable:
                     self._shuffle_ws = None
                     self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
                 sws_ptr, sws_n = self._shuffle_ws.data_ptr(), self._shuffle_ws.numel()
+            mws_ptr, mws_n = None, 0
+            if fuse and os.environ.get("PG_MINI_MERGE", "1") not in ("", "0"):
+                # the merged form of the lookups (PG_MINI_MERGE=0: word-wise): its provisional words lie in fixed slots per record,
+                # sized from the plan's record counts (records, and records of more than four k-mers: 1st and 3rd word of the plan
+                # workspace); the library falls back to the word-wise form where the merged one does not apply
+                need = _lib.check(L.pg_mini_merge_words(n_words, n_records, self._mini_plan[5], self.desc()))
+                if getattr(self, "_merge_ws", None) is None or self._merge_ws.numel() < need:
+                    self._merge_ws = None
+                    self._merge_ws = torch.empty(need, dtype=torch.int32, device=self.device)
+                mws_ptr, mws_n = self._merge_ws.data_ptr(), self._merge_ws.numel()
             if half:
                 if not fuse:
                     raise ValueError("count_half() needs rows and abundance parameters")
@@ -413,21 +424,10 @@ class KmerTable:
                 fill = torch.empty(self.n_buckets, dtype=torch.int64, device=self.device)
                 _lib.check(L.pg_mini_count_half(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
                                                 plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
-                                                window, vsize, sws_ptr, sws_n, self._half_ws.data_ptr(), self._half_ws.numel(),
+                                                window, vsize, sws_ptr, sws_n, mws_ptr, mws_n, self._half_ws.data_ptr(), self._half_ws.numel(),
                                                 fill.data_ptr(), self.status.data_ptr(), _stream_ptr(self.device)))
                 self._half = (fill, n_words, keep, window, vsize)
             else:
-                mws_ptr, mws_n = None, 0
-                if fuse and os.environ.get("PG_MINI_MERGE", "1") not in ("", "0"):
-                    # the merged form of the lookups (PG_MINI_MERGE=0: word-wise): its provisional words lie in fixed slots per record,
-                    # sized from the plan's record counts (records, and records of more than four k-mers: 1st and 3rd word of the plan
-                    # workspace); the library falls back to the word-wise form where the merged one does not apply
-                    n_long = self._mini_plan[5]
-                    need = _lib.check(L.pg_mini_merge_words(n_words, n_records, n_long, self.desc()))
-                    if getattr(self, "_merge_ws", None) is None or self._merge_ws.numel() < need:
-                        self._merge_ws = None
-                        self._merge_ws = torch.empty(need, dtype=torch.int32, device=self.device)
-                    mws_ptr, mws_n = self._merge_ws.data_ptr(), self._merge_ws.numel()
                 _lib.check(L.pg_mini_count(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
                                            plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
                                            window, vsize, sws_ptr, sws_n, mws_ptr, mws_n, self.status.data_ptr(), _stream_ptr(self.device)))
@@ -448,7 +448,10 @@ class KmerTable:
         plan_ws = self._mini_plan[1]
         with torch.cuda.device(self.device):
             _lib.check(L.pg_mini_lookup_half(self.desc(), C.byref(keep.rows_desc), plan_ws.data_ptr(), plan_ws.numel(), n_words, vsize,
-                                             self._shuffle_ws.data_ptr(), self._shuffle_ws.numel(), self._half_ws.data_ptr(), self._half_ws.numel(),
+                                             self._shuffle_ws.data_ptr(), self._shuffle_ws.numel(),
+                                             self._merge_ws.data_ptr() if getattr(self, "_merge_ws", None) is not None else None,
+                                             self._merge_ws.numel() if getattr(self, "_merge_ws", None) is not None else 0,
+                                             self._half_ws.data_ptr(), self._half_ws.numel(),
                                              bins.data_ptr(), bin_elem.data_ptr(), self.status.data_ptr(), _stream_ptr(self.device)))
         self._records = (keep, n_words)
         self._emitted = (window, vsize)
@@ -527,6 +530,16 @@ class KmerTable:
                           self._workspace.data_ptr(), self._workspace.numel(), n_words, sws.data_ptr(), sws.numel(), _stream_ptr(self.device)))
         self._emitted = None            # the row shuffle reuses the emitted words' buffer: they are gone now
         return out
+
+    def release_workspaces(self) -> None:
+        """give the scratch of the counting pipelines back (record buffers, word buffers, plans: tens of GB at BASELINE sizes); the
+        table keeps its counts, the next count allocates again"""
+        self._workspace = self._shuffle_ws = self._mini_rec_ws = self._mini_spare = None
+        self._merge_ws = self._half_ws = None
+        self._mini_plan = self._mini_next = None
+        self._records = self._emitted = self._half = None
+        if self.data.is_cuda:
+            torch.cuda.empty_cache()
 
     def check_status(self) -> None:
         """raise what the kernels reported in the status word (include/pangaea_feat.h: PG_STATUS_*)"""

@@ -132,6 +132,7 @@ def test_config3_one_gpu_share_two_pass_row_shuffle():
     tnf, abd = kmer.features(s, plan, k_tnf=4, table=t, window=10, vsize=400)
     n21 = _kmer_ends(s.valid, 21)
     assert int((t.compact() & ((1 << 22) - 1)).sum().item()) == n21
+    t.release_workspaces()                 # (two tables' scratch -- 150 GB each at this size -- need not coexist)
     m = kmer.KmerTable.mini_with_slots(21, DEV, 29, 14).count(s, rows=plan, emit=(10, 400))
     _, abd_m = kmer.features(s, plan, k_tnf=None, table=m, window=10, vsize=400)
     assert torch.equal(abd_m, abd)
