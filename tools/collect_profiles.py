@@ -32,7 +32,7 @@ KERNELS = [
     ("mini_scatter_kernel", "kmer_count+lookup", 2.0), ("mini_scatter2_kernel", "kmer_count+lookup", 2.0),
     ("mini_count_kernel", "kmer_count+lookup", 2.0),
     # N > 1 ranks (bench.py --rehearse-dist N): the count half keeps the stage name of the count, the rest is the exchange / features
-    ("mini_lookup_half_kernel", "features", 2.0), ("mini_merge_bins_kernel", "exchange", 2.0), ("mini_gather_entries_kernel", "exchange", 2.0),
+    ("mini_lookup_half_kernel", "features", 2.0), ("mini_lookup_half_merge_kernel", "features", 2.0), ("mini_merge_bins_kernel", "exchange", 2.0), ("mini_gather_entries_kernel", "exchange", 2.0),
     ("bucket_hist_kernel", "kmer_count", 2.0), ("scan_kernel", "kmer_count", 1.0), ("digit_scan_kernel", "kmer_count", 1.0),
     ("tile_rows_kernel", "kmer_count", 1.0), ("scatter_stream_kernel", "kmer_count", 1.0),
     ("scatter_records_kernel<unsigned long", "kmer_count", 2.0), ("bucket_count_kernel", "kmer_count", 2.0),
