@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 5   /* 5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
+#define PG_ABI_VERSION 6   /* 6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
+                              5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
                               4: pg_mini_records_bytes takes the table, status bits;
                               3: PG_TABLE_MINI and the super-k-mer entry points; 2: packed hash slots keyed by pg_key42(code) */
 #define PG_CHARS_PER_WORD 32
@@ -80,6 +81,22 @@ void pg_set_ingest_threads(int n);
  * fails with PG_EFORMAT (callers fall back to pg_ingest_fastq on every rank). */
 int pg_fastq_count_newlines(const char *path, int part, int n_parts, int64_t *n_newlines);
 int pg_ingest_fastq_shard(const char *path, int part, int n_parts, const int64_t *newlines_before, pg_reads **out);
+/* The same two ingests with the copy to the GPU inside (ingest_dev.hip; replaces count_tnf.cpp:234-283 + the device copy for
+ * uncompressed interleaved input): the byte range is cut into pieces (PG_INGEST_PIECE bytes, default 16 MiB) that the parser
+ * threads take from a queue; a thread copies the packed characters of a piece it has finished into the device STAGING arrays
+ * while the other threads go on parsing, so the PCIe copy hides under the parse, and the last host phase -- shifting every
+ * piece to its bit offset in the stream -- becomes one kernel: pg_ingest_place writes codes[n_words] / valid[n_words]
+ * (n_words = pg_reads_n_words) from the staging arrays.  No host copy of the stream exists: pg_reads_codes / pg_reads_valid
+ * of such a handle are NULL; runs, names, counts and the (host, rare) lower-case plane are as for pg_ingest_fastq.
+ * part / n_parts / newlines_before as for pg_ingest_fastq_shard (0 / 1 / NULL: the whole file).  staging_codes
+ * (uint64) and staging_valid (uint32) are DEVICE arrays of staging_words >= pg_ingest_staging_words(file size) elements, free
+ * again after pg_ingest_place.  *out stays NULL with status PG_OK when the input is not an uncompressed file: the caller then
+ * uses pg_ingest_fastq and copies the arrays itself.  The stream is identical to pg_ingest_fastq's for every piece size. */
+int64_t pg_ingest_staging_words(int64_t file_bytes);
+int pg_ingest_fastq_device(const char *path, int part, int n_parts, const int64_t *newlines_before, int64_t file_bytes,
+                           uint64_t *staging_codes, uint32_t *staging_valid, int64_t staging_words, pg_reads **out);
+int pg_ingest_place(const pg_reads *r, uint64_t *staging_codes, const uint32_t *staging_valid, int64_t staging_words,
+                    uint64_t *codes, uint32_t *valid, int64_t n_words, void *stream);
 void pg_reads_free(pg_reads *r);
 int64_t pg_reads_n_chars(const pg_reads *r);
 int64_t pg_reads_n_words(const pg_reads *r); /* padded word count of codes[] and valid[] */

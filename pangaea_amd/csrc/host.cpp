@@ -281,6 +281,9 @@ struct pg_reads {
     std::vector<std::string> run_name;
     int64_t n_pairs = 0, n_unpaired = 0;
     int mode = MODE_UNSET;
+    // pg_ingest_fastq_device: no host arrays; piece p's packed characters lie at word piece_soff[p] of the staging arrays and
+    // belong at characters [piece_cstart[p], piece_cstart[p + 1]) of the stream
+    std::vector<int64_t> piece_soff, piece_cstart;
 
     pg_reads() = default;
     pg_reads(const pg_reads &) = delete;
@@ -294,11 +297,16 @@ struct pg_reads {
         lowq_w = st.any_lowq ? st.lowq.data() : nullptr;
         n_words = (int64_t)st.codes.size(); n_chars = st.n;
     }
-    bool alloc_stream(int64_t total_chars)
+    static size_t padded_words(int64_t total_chars)
     {
         size_t words = (size_t)((total_chars + 31) / 32);
         size_t padded = (words + PG_WORD_ALIGN - 1) / PG_WORD_ALIGN * PG_WORD_ALIGN;
-        if (padded == 0) padded = PG_WORD_ALIGN;
+        return padded ? padded : PG_WORD_ALIGN;
+    }
+    void set_stream_size(int64_t total_chars) { n_words = (int64_t)padded_words(total_chars); n_chars = total_chars; }
+    bool alloc_stream(int64_t total_chars)
+    {
+        size_t padded = padded_words(total_chars);
         auto grab = [](size_t bytes) -> void * {
             const size_t align = bytes >= ((size_t)4 << 20) ? (size_t)2 << 20 : 64;
             void *q = nullptr;
@@ -623,12 +631,15 @@ struct LocalStream {          // one thread's characters, packed from bit 0
         if (lb) lower.push_back(LowerMask{n, lb});
     }
     void finish() { if (n & 31) { codes.push_back(cw); valid.push_back(vw); if (with_q) lowq.push_back(qw); cw = 0; vw = 0; qw = 0; } }
+    void reset() { codes.clear(); valid.clear(); lower.clear(); lowq.clear(); any_q = false; n = 0; cw = 0; vw = 0; qw = 0; }     // (capacity stays)
 };
 
 struct Change { int64_t end_pos; std::string prev; };       // a run ends at end_pos (thread-local); it carries `prev`
 
-struct ThreadOut {
-    LocalStream st;
+struct ThreadOut {                // what a piece (a byte range of the file) leaves behind besides its packed characters
+    int64_t n = 0;                // its characters
+    int64_t soff = 0;             // (sink form) word offset of its local stream in the staging arrays
+    std::vector<LowerMask> lower;
     std::vector<Change> changes;
     bool any = false;             // saw a complete pair
     std::string first, last;      // barcodes of the first and the last complete pair
@@ -638,102 +649,147 @@ struct ThreadOut {
     bool io_error = false;
 };
 
-// bytes [A, B) of the open file: A is the start of a unit, B the start of a unit or the end of the file
-int ingest_interleaved_range(int fd, size_t A, size_t B, const char *path, pg_reads *R, int T, const Latch &L, const ShardCtx &ctx)
+// bytes [A, B) of the open file: A is the start of a unit, B the start of a unit or the end of the file.
+// Without a sink the range is cut into T pieces, one per thread, whose local streams are shifted into place in host arrays
+// (phase C).  With a sink (pg_ingest_fastq_device) it is cut into pieces of PG_INGEST_PIECE bytes that the threads take from a
+// queue; a thread hands the local stream of a finished piece to the sink (a copy to the GPU) while the others go on parsing,
+// phase C is left to the device (pg_ingest_place) and R keeps the pieces' offsets instead of the arrays.
+int ingest_interleaved_range(int fd, size_t A, size_t B, const char *path, pg_reads *R, int T, const Latch &L, const ShardCtx &ctx,
+                             const pg_piece_sink *sink = nullptr)
 {
     PhaseTimer tm;
     const size_t n = B - A;
     const size_t block = reader_block((size_t)1 << 20);
-    std::vector<size_t> rb(T + 1);
-    for (int t = 0; t <= T; ++t) rb[t] = A + (size_t)((unsigned __int128)n * (unsigned)t / (unsigned)T);
-    // ---- A. newlines per range; does the range start at the start of a line?
-    std::vector<uint64_t> nl(T, 0);
-    std::vector<char> at_line_start(T, 1), io_bad(T, 0);
-    run_threads(T, [&](int t) {
+    int P = T;
+    if (sink) {
+        size_t piece = (size_t)16 << 20;
+        if (const char *e = getenv("PG_INGEST_PIECE")) { long v = atol(e); if (v >= 64) piece = (size_t)v; }
+        P = (int)std::max<size_t>(1, std::min<size_t>((n + piece - 1) / piece, (size_t)1 << 20));
+    }
+    std::vector<size_t> rb(P + 1);
+    for (int t = 0; t <= P; ++t) rb[t] = A + (size_t)((unsigned __int128)n * (unsigned)t / (unsigned)P);
+    std::atomic<int> next_piece{0};
+    // every thread its own piece (P == T), or pieces from the queue
+    auto for_pieces = [&](auto &&body) {
+        next_piece = 0;
+        run_threads(T, [&](int worker) {
+            if (!sink) { body(worker, worker); return; }
+            for (int p; (p = next_piece.fetch_add(1, std::memory_order_relaxed)) < P;) body(p, worker);
+        });
+    };
+    // ---- A. newlines per piece; does the piece start at the start of a line?
+    std::vector<uint64_t> nl(P, 0);
+    std::vector<char> at_line_start(P, 1), io_bad(P, 0);
+    for_pieces([&](int t, int) {
         if (t > 0 && rb[t] > A) { char c = 0; if (pread(fd, &c, 1, (off_t)(rb[t] - 1)) != 1) io_bad[t] = 1; at_line_start[t] = c == '\n'; }
         UnitReader rd(fd, rb[t], rb[t + 1], block);
         nl[t] = rd.count_newlines();
         if (rd.io_error()) io_bad[t] = 1;
     });
     for (char x : io_bad) if (x) return pg_fail(PG_EIO, "read error in %s", path);
-    std::vector<uint64_t> nl_before(T + 1, 0);
-    for (int t = 0; t < T; ++t) nl_before[t + 1] = nl_before[t] + nl[t];
+    std::vector<uint64_t> nl_before(P + 1, 0);
+    for (int t = 0; t < P; ++t) nl_before[t + 1] = nl_before[t] + nl[t];
     tm.lap("lines");
-    // ---- B. parse + pack into thread-local streams
-    std::vector<ThreadOut> out(T);
-    run_threads(T, [&](int t) {
+    // ---- B. parse + pack into local streams
+    std::vector<ThreadOut> out(P);
+    std::vector<LocalStream> local(sink ? T : P);            // one per piece, or (sink) one per thread, reused
+    std::atomic<int64_t> staged{0};
+    std::atomic<int> sink_rc{0};
+    for_pieces([&](int t, int worker) {
         ThreadOut &o = out[t];
+        LocalStream &st = local[sink ? worker : t];
         if (rb[t] >= rb[t + 1]) return;
+        st.reset();
         UnitReader rd(fd, rb[t], B, block);
         uint64_t line = nl_before[t];                      // index (from A) of the first line that starts in this range
         if (!at_line_start[t]) { if (!rd.skip_line()) { o.io_error = rd.io_error(); return; } ++line; }
         for (uint64_t skip = (8 - line % 8) % 8; skip; --skip, ++line)
             if (!rd.skip_line()) { o.io_error = rd.io_error(); return; }
         uint64_t unit = ctx.unit_base + line / 8;
-        o.st.codes.reserve((rb[t + 1] - rb[t]) / 64 + 64);
-        o.st.valid.reserve((rb[t + 1] - rb[t]) / 64 + 64);
+        st.codes.reserve((rb[t + 1] - rb[t]) / 64 + 64);
+        st.valid.reserve((rb[t + 1] - rb[t]) / 64 + 64);
         UnitLines u;
         while (rd.offset() < rb[t + 1] && rd.next(u)) {
             int mode = mode_of(L, unit);
             Span nm, bc;
             if (!header_fields(u.p[0], u.n[0], mode, nm, bc)) { o.bad_unit = unit; return; }
-            if (u.count >= 2) o.st.put_line(u.p[1], u.n[1]);
+            if (u.count >= 2) st.put_line(u.p[1], u.n[1]);
             if (u.count >= 6) {
-                o.st.put_line(u.p[5], u.n[5]);
+                st.put_line(u.p[5], u.n[5]);
                 ++o.pairs;
                 const char *b = u.p[0] + bc.b;
-                if (!o.any) { o.any = true; o.first.assign(b, bc.n); o.first_end = o.st.n; o.last = o.first; }
+                if (!o.any) { o.any = true; o.first.assign(b, bc.n); o.first_end = st.n; o.last = o.first; }
                 else if (bc.n != o.last.size() || (bc.n && memcmp(b, o.last.data(), bc.n) != 0)) {
-                    o.changes.push_back(Change{o.st.n, o.last});
+                    o.changes.push_back(Change{st.n, o.last});
                     o.last.assign(b, bc.n);
                 }
             }
             ++unit;
         }
         o.io_error = rd.io_error();
-        o.st.finish();
+        st.finish();
+        o.n = st.n;
+        o.lower = std::move(st.lower);
+        st.lower.clear();
+        if (sink && !o.io_error) {
+            const int64_t nw = (int64_t)st.codes.size();
+            o.soff = staged.fetch_add(nw, std::memory_order_relaxed);
+            if (nw == 0) return;
+            int rc = o.soff + nw <= sink->capacity_words ? sink->copy(sink->ctx, worker, o.soff, st.codes.data(), st.valid.data(), nw) : PG_EINVAL;
+            if (rc) { int zero = 0; sink_rc.compare_exchange_strong(zero, rc); }
+        }
     });
     uint64_t first_bad = UINT64_MAX;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < P; ++t) {
         if (out[t].io_error) return pg_fail(PG_EIO, "read error in %s", path);
         first_bad = std::min(first_bad, out[t].bad_unit);
     }
     if (first_bad != UINT64_MAX)
         return pg_fail(PG_EFORMAT, "%s line %llu: header ends inside its BX:Z tag (the reference aborts here)", path, (unsigned long long)(first_bad * 8 + 1));
-    tm.lap("parse+pack");
+    if (sink_rc.load() == PG_EINVAL && staged.load() > sink->capacity_words)
+        return pg_fail(PG_EINVAL, "staging arrays of %lld words are too small for %s (pg_ingest_staging_words)", (long long)sink->capacity_words, path);
+    if (sink_rc.load()) return sink_rc.load();                 // (the sink recorded its message)
+    tm.lap(sink ? "parse+copy" : "parse+pack");
     // ---- C. place the local streams
-    std::vector<int64_t> cstart(T + 1, 0);
-    for (int t = 0; t < T; ++t) cstart[t + 1] = cstart[t] + out[t].st.n;
-    const int64_t total = cstart[T];
-    if (!R->alloc_stream(total)) return pg_fail(PG_ENOMEM, "out of memory while ingesting %s", path);
-    uint64_t *gc = R->codes_w; uint32_t *gv = R->valid_w;
-    for (int64_t w = (total + 31) >> 5; w < R->n_words; ++w) { gc[w] = 0; gv[w] = 0; }
-    for (int t = 0; t < T; ++t)
-        if (out[t].st.n) {
-            const int64_t a = cstart[t] >> 5, b = (cstart[t + 1] - 1) >> 5;
-            gc[a] = 0; gv[a] = 0; gc[b] = 0; gv[b] = 0;
-        }
-    run_threads(T, [&](int t) {
-        const LocalStream &ls = out[t].st;
-        if (ls.n == 0) return;
-        const int64_t w0 = cstart[t] >> 5, w1 = (cstart[t + 1] - 1) >> 5;
-        const int sh = (int)(cstart[t] & 31);
-        const int64_t nw = (int64_t)ls.codes.size();
-        for (int64_t g = w0; g <= w1; ++g) {
-            const int64_t i = g - w0;
-            uint64_t c = i < nw ? ls.codes[i] << (2 * sh) : 0;
-            uint32_t v = i < nw ? ls.valid[i] << sh : 0;
-            if (sh && i > 0) { c |= ls.codes[i - 1] >> (64 - 2 * sh); v |= ls.valid[i - 1] >> (32 - sh); }
-            if (g == w0 || g == w1) { __atomic_fetch_or(&gc[g], c, __ATOMIC_RELAXED); __atomic_fetch_or(&gv[g], v, __ATOMIC_RELAXED); }
-            else { gc[g] = c; gv[g] = v; }
-        }
-    });
+    std::vector<int64_t> cstart(P + 1, 0);
+    for (int t = 0; t < P; ++t) cstart[t + 1] = cstart[t] + out[t].n;
+    const int64_t total = cstart[P];
+    if (sink) {                                       // the device does it: pg_ingest_place
+        R->set_stream_size(total);
+        R->piece_soff.resize(P);
+        for (int t = 0; t < P; ++t) R->piece_soff[t] = out[t].soff;
+        R->piece_cstart = cstart;
+    } else {
+        if (!R->alloc_stream(total)) return pg_fail(PG_ENOMEM, "out of memory while ingesting %s", path);
+        uint64_t *gc = R->codes_w; uint32_t *gv = R->valid_w;
+        for (int64_t w = (total + 31) >> 5; w < R->n_words; ++w) { gc[w] = 0; gv[w] = 0; }
+        for (int t = 0; t < P; ++t)
+            if (out[t].n) {
+                const int64_t a = cstart[t] >> 5, b = (cstart[t + 1] - 1) >> 5;
+                gc[a] = 0; gv[a] = 0; gc[b] = 0; gv[b] = 0;
+            }
+        run_threads(T, [&](int t) {
+            const LocalStream &ls = local[t];
+            if (out[t].n == 0) return;
+            const int64_t w0 = cstart[t] >> 5, w1 = (cstart[t + 1] - 1) >> 5;
+            const int sh = (int)(cstart[t] & 31);
+            const int64_t nw = (int64_t)ls.codes.size();
+            for (int64_t g = w0; g <= w1; ++g) {
+                const int64_t i = g - w0;
+                uint64_t c = i < nw ? ls.codes[i] << (2 * sh) : 0;
+                uint32_t v = i < nw ? ls.valid[i] << sh : 0;
+                if (sh && i > 0) { c |= ls.codes[i - 1] >> (64 - 2 * sh); v |= ls.valid[i - 1] >> (32 - sh); }
+                if (g == w0 || g == w1) { __atomic_fetch_or(&gc[g], c, __ATOMIC_RELAXED); __atomic_fetch_or(&gv[g], v, __ATOMIC_RELAXED); }
+                else { gc[g] = c; gv[g] = v; }
+            }
+        });
+    }
     bool any_lower = false;
-    for (int t = 0; t < T; ++t) any_lower |= !out[t].st.lower.empty();
-    if (any_lower) {                                  // rare: a dense plane, bits set from the threads' sparse lists
+    for (int t = 0; t < P; ++t) any_lower |= !out[t].lower.empty();
+    if (any_lower) {                                  // rare: a dense plane, bits set from the pieces' sparse lists
         R->lower_plane.assign((size_t)R->n_words, 0u);
-        for (int t = 0; t < T; ++t)
-            for (const LowerMask &m : out[t].st.lower) {
+        for (int t = 0; t < P; ++t)
+            for (const LowerMask &m : out[t].lower) {
                 const int64_t pos = cstart[t] + m.pos;
                 const int sh = (int)(pos & 31);
                 R->lower_plane[(size_t)(pos >> 5)] |= m.mask << sh;
@@ -742,11 +798,11 @@ int ingest_interleaved_range(int fd, size_t A, size_t B, const char *path, pg_re
         R->lower_w = R->lower_plane.data();
     }
     tm.lap("place");
-    // ---- D. runs: the first complete pair of a thread is compared with the last one of the threads before it
+    // ---- D. runs: the first complete pair of a piece is compared with the last one of the pieces before it
     R->mode = L.mode;
     R->run_off.push_back(0);
     const std::string *last = &ctx.last;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < P; ++t) {
         R->n_pairs += out[t].pairs;
         if (!out[t].any) continue;
         if (out[t].first != *last) { R->run_off.push_back(cstart[t] + out[t].first_end); R->run_name.push_back(*last); }
@@ -1406,9 +1462,9 @@ extern "C" int pg_fastq_count_newlines(const char *path, int part, int n_parts, 
     return PG_OK;
 }
 
-extern "C" int pg_ingest_fastq_shard(const char *path, int part, int n_parts, const int64_t *newlines_before, pg_reads **out)
+namespace {
+int ingest_shard_impl(const char *path, int part, int n_parts, const int64_t *newlines_before, const pg_piece_sink *sink, pg_reads **out)
 {
-    if (!path || !out || !newlines_before || n_parts < 1 || part < 0 || part >= n_parts) return pg_fail(PG_EINVAL, "pg_ingest_fastq_shard: bad argument");
     *out = nullptr;
     int fd; size_t size = 0;
     int rc = open_for_shards(path, fd, size);
@@ -1428,6 +1484,7 @@ extern "C" int pg_ingest_fastq_shard(const char *path, int part, int n_parts, co
             R->mode = L.mode;
             R->run_off.push_back(0);
             R->seal_serial();
+            if (sink) R->piece_cstart.assign(1, 0);
         } else if (!rc) {
             ShardCtx ctx;
             ctx.unit_base = lo.unit;
@@ -1435,7 +1492,7 @@ extern "C" int pg_ingest_fastq_shard(const char *path, int part, int n_parts, co
             ctx.trailing = !hi.found;
             const size_t a = lo.pos, b = std::max(lo.pos, hi.pos);
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)ingest_threads(), (b - a) >> 16));
-            rc = ingest_interleaved_range(fd, a, b, path, R, T, L, ctx);
+            rc = ingest_interleaved_range(fd, a, b, path, R, T, L, ctx, sink);
         }
     } catch (const std::bad_alloc &) {
         rc = pg_fail(PG_ENOMEM, "out of memory while ingesting %s", path);
@@ -1444,6 +1501,48 @@ extern "C" int pg_ingest_fastq_shard(const char *path, int part, int n_parts, co
     if (rc) { delete R; return rc; }
     *out = R;
     return PG_OK;
+}
+}  // namespace
+
+extern "C" int pg_ingest_fastq_shard(const char *path, int part, int n_parts, const int64_t *newlines_before, pg_reads **out)
+{
+    if (!path || !out || !newlines_before || n_parts < 1 || part < 0 || part >= n_parts) return pg_fail(PG_EINVAL, "pg_ingest_fastq_shard: bad argument");
+    return ingest_shard_impl(path, part, n_parts, newlines_before, nullptr, out);
+}
+
+// the same ingests with the pieces handed to a sink (ingest_dev.hip: copies to the GPU); *out stays NULL (and the status PG_OK)
+// when the input is not an uncompressed interleaved file: the caller then takes pg_ingest_fastq and copies the arrays itself
+int pg_internal_ingest_to_sink(const char *path, int part, int n_parts, const int64_t *newlines_before, const pg_piece_sink *sink, pg_reads **out)
+{
+    *out = nullptr;
+    int fd; size_t size = 0; bool plain;
+    int rc = open_plain(path, fd, size, plain);
+    if (rc) return rc;
+    if (!plain) { close(fd); return PG_OK; }
+    if (n_parts > 1) { close(fd); return ingest_shard_impl(path, part, n_parts, newlines_before, sink, out); }
+    pg_reads *R = new (std::nothrow) pg_reads();
+    if (!R) { close(fd); return pg_fail(PG_ENOMEM, "out of memory"); }
+    try {
+        PhaseTimer tm;
+        const Latch L = find_latch(fd, size);
+        tm.lap("latch");
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)ingest_threads(), size >> 16));
+        rc = ingest_interleaved_range(fd, 0, size, path, R, T, L, ShardCtx(), sink);
+    } catch (const std::bad_alloc &) {
+        rc = pg_fail(PG_ENOMEM, "out of memory while ingesting %s", path);
+    }
+    close(fd);
+    if (rc) { delete R; return rc; }
+    *out = R;
+    return PG_OK;
+}
+
+int64_t pg_internal_reads_pieces(const pg_reads *r, const int64_t **soff, const int64_t **cstart)
+{
+    if (!r || r->piece_cstart.empty()) return -1;
+    *soff = r->piece_soff.data();
+    *cstart = r->piece_cstart.data();
+    return (int64_t)r->piece_cstart.size() - 1;
 }
 
 extern "C" void pg_reads_free(pg_reads *r) { delete r; }

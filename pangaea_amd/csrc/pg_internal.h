@@ -6,6 +6,19 @@
 // records the message for pg_last_error() on this thread and returns `code`
 int pg_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// the threaded interleaved ingest with a sink for its pieces (host.cpp; the sink of ingest_dev.hip copies them to the GPU): a
+// worker thread calls copy() with the packed characters of a finished piece (n_words words of codes and of validity bits, packed
+// from bit 0) and the word offset the piece was given in the staging arrays; copy() returns 0 or a pg_status whose message it
+// has recorded.  Pieces are at most capacity_words words together.
+struct pg_piece_sink {
+    void *ctx;
+    int64_t capacity_words;
+    int (*copy)(void *ctx, int worker, int64_t dst_word, const uint64_t *codes, const uint32_t *valid, int64_t n_words);
+};
+int pg_internal_ingest_to_sink(const char *path, int part, int n_parts, const int64_t *newlines_before, const pg_piece_sink *sink, pg_reads **out);
+// the pieces of a pg_reads that came through a sink: piece p lies at word soff[p] of the staging arrays and belongs at characters
+// [cstart[p], cstart[p + 1]) of the stream; returns their number, -1 for a pg_reads with host arrays
+int64_t pg_internal_reads_pieces(const pg_reads *r, const int64_t **soff, const int64_t **cstart);
 
 // the row shuffle of kernels.hip (S2 + S3), for the pipelines of other translation units: the (row, bin) words of bucket b
 // lie at words_e[in_begin[b] .. emit_end[b]) inside `workspace` (layout below; emit_end at emit_off, uint64 per bucket)

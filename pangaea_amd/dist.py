@@ -139,8 +139,9 @@ def shard_stream(stream: ReadStream, rank: int, world: int) -> ReadStream:
                       valid_lower=lower, valid_lowq=lowq)
 
 
-def ingest_shard(reads1: str, reads2: str | None = None, group=None) -> ReadStream:
-    """this rank's part of the input, as a host stream.
+def ingest_shard(reads1: str, reads2: str | None = None, group=None, device="cpu") -> ReadStream:
+    """this rank's part of the input (a host stream unless ``device`` is a GPU and the byte-range ingest applies, which then
+    copies its pieces there while it parses: ``pg_ingest_fastq_device``).
 
     An uncompressed interleaved file (what ``run_pangaea`` sorts the reads into) is cut by bytes: every rank counts the
     newlines of its own range, the counts are all-gathered (the only communication), and each rank reads and parses
@@ -163,7 +164,7 @@ def ingest_shard(reads1: str, reads2: str | None = None, group=None) -> ReadStre
     else:
         dist.all_gather(counts, mine, group=group)
     before = np.concatenate([[0], np.cumsum([int(c.item()) for c in counts])]).astype(np.int64)
-    return ReadStream.from_fastq_shard(reads1, rank, world, before)
+    return ReadStream.from_fastq_shard(reads1, rank, world, before, device=device)
 
 
 def _staged(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -85,8 +85,8 @@ def to_pickle_atomic(frame: pd.DataFrame, path: str) -> None:
             os.remove(tmp)
 
 
-def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | None) -> ReadStream:
-    """this rank's host stream: from the packed-stream cache when one is given and is newer than the reads, else from the
+def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | None, device="cpu") -> ReadStream:
+    """this rank's stream (on ``device`` already when the ingest could copy it there piece by piece, `pg_ingest_fastq_device`): from the packed-stream cache when one is given and is newer than the reads, else from the
     FASTQ file(s) (and the cache is written for the next pass)"""
     cache = None
     if stream_cache:
@@ -99,7 +99,7 @@ def _ingest(reads1: str, reads2: str | None, world: int, stream_cache: str | Non
         if fresh:
             logging.info(f"packed read stream from {cache}")
             return ReadStream.load(cache)
-    part = pdist.ingest_shard(reads1, reads2) if world > 1 else ReadStream.from_fastq(reads1, reads2)
+    part = pdist.ingest_shard(reads1, reads2, device=device) if world > 1 else ReadStream.from_fastq(reads1, reads2, device=device)
     if cache:
         part.save(cache)
     return part
@@ -130,7 +130,7 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     world = torch.distributed.get_world_size() if pdist.is_distributed() else 1
-    stream = _ingest(reads1, reads2, world, stream_cache).to(device)
+    stream = _ingest(reads1, reads2, world, stream_cache, device).to(device)
     # one rank: the table's sizing pass (a HyperLogLog sketch of the distinct k-mers) is launched first and runs on the GPU while
     # the host assembles the rows
     from . import kmer as _kmer

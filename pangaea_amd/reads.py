@@ -104,6 +104,10 @@ class ReadStream:
     def from_fastq(cls, reads1: str, reads2: str | None = None, device: str | torch.device = "cpu") -> "ReadStream":
         """ingest an interleaved FASTQ (``reads2`` None) or an R1/R2 pair; gzip or plain"""
         L = _lib.load()
+        if reads2 is None and torch.device(device).type == "cuda":
+            s = cls._ingest_to_device(L, str(reads1), 0, 1, None, torch.device(device))
+            if s is not None:
+                return s
         h = C.c_void_p()
         _lib.check(L.pg_ingest_fastq(str(reads1).encode(), str(reads2).encode() if reads2 else None, C.byref(h)))
         return cls._from_handle(L, h).to(device)
@@ -120,6 +124,10 @@ class ReadStream:
             newlines_before = np.concatenate([[0], np.cumsum([cls.count_newlines(reads, i, n_parts) for i in range(n_parts)])])
         before = np.ascontiguousarray(newlines_before, dtype=np.int64)
         assert before.shape == (n_parts + 1,)
+        if torch.device(device).type == "cuda":
+            s = cls._ingest_to_device(L, str(reads), int(part), int(n_parts), before, torch.device(device))
+            if s is not None:
+                return s
         h = C.c_void_p()
         _lib.check(L.pg_ingest_fastq_shard(str(reads).encode(), int(part), int(n_parts),
                                            before.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(h)))
@@ -131,6 +139,49 @@ class ReadStream:
         n = C.c_int64()
         _lib.check(_lib.load().pg_fastq_count_newlines(str(reads).encode(), int(part), int(n_parts), C.byref(n)))
         return int(n.value)
+
+    @classmethod
+    def _ingest_to_device(cls, L, reads: str, part: int, n_parts: int, before, device) -> "ReadStream | None":
+        """``pg_ingest_fastq_device``: the parser threads copy finished pieces to the GPU while the others parse on, the shift
+        into place is a kernel, no host copy of the stream exists.  None when the input is not an uncompressed file (or
+        ``PANGAEA_INGEST_ON_HOST=1``): the caller takes the host ingest and copies."""
+        if os.environ.get("PANGAEA_INGEST_ON_HOST", "0") not in ("", "0"):
+            return None
+        try:
+            with open(reads, "rb") as f:
+                if f.read(2) == b"\x1f\x8b":
+                    return None
+            size = os.path.getsize(reads)
+        except OSError:
+            return None                                      # (the host ingest reports it)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(device):
+            cap = int(L.pg_ingest_staging_words(size))
+            sc = torch.empty(cap, dtype=torch.int64, device=device)
+            sv = torch.empty(cap, dtype=torch.int32, device=device)
+            torch.cuda.current_stream().synchronize()        # (the copies run on the library's own streams)
+            h = C.c_void_p()
+            _lib.check(L.pg_ingest_fastq_device(reads.encode(), part, n_parts,
+                                                None if before is None else before.ctypes.data_as(C.POINTER(C.c_int64)), size,
+                                                C.c_void_p(sc.data_ptr()), C.c_void_p(sv.data_ptr()), cap, C.byref(h)))
+            if not h:
+                return None
+            owner = _IngestHandle(L, h)
+            nw, nr = L.pg_reads_n_words(h), L.pg_reads_n_runs(h)
+            codes = torch.empty(nw, dtype=torch.int64, device=device)
+            valid = torch.empty(nw, dtype=torch.int32, device=device)
+            _lib.check(L.pg_ingest_place(h, C.c_void_p(sc.data_ptr()), C.c_void_p(sv.data_ptr()), cap,
+                                         C.c_void_p(codes.data_ptr()), C.c_void_p(valid.data_ptr()), nw,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            lower_ptr = L.pg_reads_lower(h)
+            lower = torch.from_numpy(np.ctypeslib.as_array(C.cast(lower_ptr, C.POINTER(C.c_int32)), shape=(nw,)).copy()).to(device) if lower_ptr else None
+            run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
+            names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
+            out = cls(codes, valid, int(L.pg_reads_n_chars(h)), run_off, names, int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)),
+                      L.pg_reads_mode(h).decode(), valid_lower=lower)
+            del owner
+        return out
 
     @classmethod
     def _from_handle(cls, L, h) -> "ReadStream":
