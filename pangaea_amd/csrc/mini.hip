@@ -892,9 +892,10 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     const uint32_t n_steps = n_ss + n_lb + (n_ring + 64u * NS - 1u) / (64u * NS);
     if (n_steps == 0u) return;                                   // (uniform)
     // a step's rows: first word of row 0 (A0), rows that belong to it (NV), words of its class (LIM), first slots of its records (GST)
-    struct StepGeo { uint32_t a0, nv, lim, gst; };
+    struct StepGeo { uint32_t a0, nv, lim, gst, kind; };
     auto geometry = [&](uint32_t st) -> StepGeo {
         StepGeo g;
+        g.kind = st < n_ss ? 0u : st < n_ss + n_lb ? 1u : 2u;
         if (st < n_ss) {
             const uint32_t left = n_sb - st * GS;
             g.a0 = st * (64u * CXS * GS); g.nv = (left < (uint32_t)GS ? left : (uint32_t)GS) * CXS; g.lim = long_base;
@@ -913,7 +914,16 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     auto fetch_rows = [&](const StepGeo &g, uint32_t (&w)[NS]) {
         const uint32_t *row0 = prov_b + g.a0;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) w[i] = row0[64 * i + lane];
+        for (int i = 0; i < NS; ++i) {
+#ifdef PG_DIAG_ROWS
+            // (diagnostic, WRONG results: a third of the rows are not stored by the count loop and read as copies of their neighbours
+            // here -- same instructions, fewer bytes: what would a denser provisional format buy?)
+            const uint32_t ie = g.kind == 0u ? ((i & 3) == 3 ? i - 1 : i) : g.kind == 1u ? (i >= 6 ? i - 3 : i) : i;
+            w[i] = row0[64 * ie + lane];
+#else
+            w[i] = row0[64 * i + lane];
+#endif
+        }
     };
     // raw words -> bins -> (row, bin) words; equal neighbours inside a record become ONE word with the run length on top
     auto process = [&](const StepGeo &g, uint32_t (&w)[NS]) {
@@ -1311,6 +1321,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     uint32_t *rowp = prov_b + (CX < CAP ? 0u : long_base) + (uint32_t)((i0 - ra) >> 6) * (64u * CX) + lane;
 #pragma unroll
                     for (int j = 0; j < CX; ++j)
+#ifdef PG_DIAG_ROWS
+                        if (j < (CX < CAP ? 3 : 6))
+#endif
                         rowp[64 * j] = __builtin_amdgcn_inverse_ballot_w64(pm[j]) ? (row << lb) | sl[j] : WORD_NONE;
                 } else
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
