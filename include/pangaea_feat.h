@@ -376,9 +376,9 @@ int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_t word_begi
 int64_t pg_mini_records_bytes(int64_t n_records, const pg_table *t);
 int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize);
 /* merge_ws (may be NULL: the word-wise lookups): pg_mini_merge_words() 4-byte words of device memory for the MERGED form of the
- * lookups -- the k-mers of a record that share row and bin travel as one word with a count; provisional words in fixed slots
- * per record, sized from the plan's record counts (the plan workspace's first 8-byte word: records; third: records of more
- * than 4 k-mers).  Opt-in besides: PG_MINI_MERGE=1 in the environment. */
+ * lookups (the default; PG_MINI_MERGE=0 in the environment or a NULL buffer: word-wise) -- the k-mers of a record that share row
+ * and bin travel as one word with a count; the provisional data are the k-mers' 2-byte slot numbers in fixed places per record,
+ * sized from the plan's record counts (the plan workspace's first 8-byte word: records; third: records of more than 4 k-mers). */
 int64_t pg_mini_merge_words(int64_t n_words, int64_t n_records, int64_t n_long_records, const pg_table *t);
 int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                   const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
@@ -410,7 +410,8 @@ int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int v
  *   pg_mini_lookup_half   bins_in[bin_elem[b] ..) = the bins of bucket b's entries, in the order they were sent -> the lookups of
  *                         the provisional words and the row-group scatter, exactly as pg_mini_count ends;
  *                         pg_mini_abundance_from_emitted(local, ...) then writes the rows.
- * half_ws: pg_mini_half_bytes(local), 256-byte aligned device memory; merge_ws as for pg_mini_count (the same buffer in both calls). */
+ * half_ws: pg_mini_half_bytes(local), 256-byte aligned device memory; merge_ws as for pg_mini_count (the same buffer in both calls);
+ * rec_ws: the count half's record workspace, untouched in between (the merged lookups read the records' lengths and rows again). */
 int64_t pg_mini_half_bytes(const pg_table *local);
 int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *local,
                        const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
@@ -420,7 +421,8 @@ int pg_mini_gather_entries(const pg_table *local, const void *half_ws, int64_t h
                            const int64_t *dst_elem, uint64_t *out, void *stream);
 int pg_mini_merge_bins(const uint64_t *recv, int64_t part_stride, const int64_t *seg, int n_parts, const pg_table *t,
                        int64_t bucket_begin, int64_t bucket_end, int window, int vsize, uint16_t *bins_out, uint32_t *status, void *stream);
-int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
+int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, const void *rec_ws, int64_t rec_ws_bytes,
+                        int64_t n_words_counted,
                         int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *merge_ws, int64_t merge_ws_words,
                         const void *half_ws, int64_t half_ws_bytes,
                         const uint16_t *bins_in, const int64_t *bin_elem, uint32_t *status, void *stream);

@@ -798,31 +798,35 @@ __device__ __forceinline__ void wordwise_lookup(const WordCtx &c)
 //     word = (run length - 1) << MERGE_CSHIFT | row << vbits | bin,
 // so that ranks, region starts, staging and copy-out are paid per record and per run instead of per occurrence (measured on the
 // bench workload: 0.28 words left per provisional word).
-// The provisional words of this form lie in FIXED slots, so that the lookup phase can fetch them without reading anything else
-// first: the bucket's word range is
-//     [ batches of short records: 64 x CXS words each | batches of long records: 64 x CAP words each | singles ]
-// and word j of the record that lane l treated in batch b of its class sits at class_base + b x 64 x CX + j x 64 + l -- a
-// k-mer that left no word there (outside every row, not settled by the first probe) leaves NONE.  Every store of the count loop
-// is a whole aligned 256-byte row of a wavefront, there is no position to claim per batch, and the words of the general
-// insert ("singles", which arrive one by one) are appended behind the batches.  The range is sized from the classes' record
-// counts, which the plan tallies (header[2]): 17 % more provisional bytes than the compacted layout of the word-wise form.
+// The provisional data of this form lie in FIXED places, so that the lookup phase can fetch them without reading anything else
+// first, and they are 2 bytes per k-mer: the bucket's range is
+//     [ batches of short records: CXS rows of 64 halfwords each | batches of long records: CAP rows each ]
+// and halfword (b x CX + j) x 64 + l of a class holds the SLOT of k-mer j of the record that lane l treated in batch b -- written
+// exactly once: by the count loop when the first probe settled the k-mer, else by the general insert when it has found or made
+// the slot (the ring carries the halfword's position next to the code).  Which halfwords mean anything follows from the record
+// itself (its length and its row, re-read from the records' meta plane: batch b, lane l = record 64 b + l of its class), so
+// nothing has to be cleared or marked, every occurrence of a record is in its lane's hands in the lookup phase (runs are never
+// broken by k-mers that took the slow path) and the buffer's size follows from the classes' record counts alone, which the plan
+// tallies (header[2]): 12 bytes per short record, 22 per long one, against 16 / 36 + a word per slow-path k-mer in round 3's first
+// layout (4-byte (row, slot) words with 0xffffffff in the places of absent k-mers, the singles appended behind the batches).
 constexpr int MERGE_CSHIFT = PG_SHUFFLE_COUNT_SHIFT;              // needs row bits + vbits <= 28 (mini_merge_form)
-constexpr uint32_t WORD_NONE = 0xffffffffu;                       // (never a provisional word: rows stay below 2^20 in this form)
+constexpr uint32_t WORD_NONE = 0xffffffffu;                       // (never a (row, bin) word: rows stay below 2^20 in this form)
 struct MergeArgs {
-    uint32_t *prov;                                              // the provisional words of the MERGE form
-    unsigned long long cap;                                      // its capacity, in words (the buckets claim their ranges on the word cursor)
+    uint32_t *prov;                                              // the provisional slots of the MERGE form (halfwords, addressed as dwords)
+    unsigned long long cap;                                      // its capacity, in dwords (the buckets claim their ranges on the word cursor)
 };
-// ---- the record-wise lookups of the MERGE form: provisional (row, slot) words -> (run, row, bin) words, scattered by the first
-// digit of their row group into the row shuffle's regions.  Called by a whole workgroup of BLK threads once the bucket's
-// 2-byte bins lie at the start of the dynamic LDS (MergeLds layout).
+// ---- the record-wise lookups of the MERGE form: provisional slots -> (run, row, bin) words, scattered by the first digit of
+// their row group into the row shuffle's regions.  Called by a whole workgroup of BLK threads once the bucket's 2-byte bins lie
+// at the start of the dynamic LDS (MergeLds layout).
 struct MergeCtx {
     unsigned char *lds;                                          // dynamic LDS (bins16 first)
     uint32_t smask;
-    int lb, vbits;
+    int vbits;
     ShufArgs sh;
     uint32_t *status;
-    const uint32_t *prov_b;                                      // the bucket's word range
-    uint32_t n_sb, n_lb, n_ring;                                 // batches of short / long records, singles
+    const uint32_t *prov_b;                                      // the bucket's range (dwords of two slots)
+    const uint32_t *meta_s, *meta_l;                             // meta words of the bucket's short / long records
+    uint32_t n_s, n_l;                                           // ... and how many there are
     unsigned long long *dbg;                                     // PG_MINI_STAMPS builds: cycle sums of the phases (diagnostic)
 };
 
@@ -832,9 +836,6 @@ struct MergeCtx {
 #ifndef PG_MERGE_WPL
 #define PG_MERGE_WPL 12
 #endif
-#ifndef PG_MERGE_NS
-#define PG_MERGE_NS 8
-#endif
 template <int BLK, int DIG> struct MergeLds {
     static constexpr int WPL = (BLK == 1024 && DIG == 1024) ? PG_MERGE_WPL : (PG_MERGE_WPL < 10 ? PG_MERGE_WPL : 10);   // (144 KiB with 1024 threads, 72 KiB with 512: two workgroups per CU)
     static constexpr uint32_t TILE = WPL * BLK;
@@ -842,31 +843,35 @@ template <int BLK, int DIG> struct MergeLds {
     static constexpr uint32_t BUF1 = BUF + 4 * TILE;
     static constexpr uint32_t CNT = BUF1 + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
 };
-// slots of a step of the lookup phase (and the slack the word buffer needs behind its last bucket: a step reads whole rows)
+// a step of the lookup phase: two batches of short records or one batch of long ones per wavefront (one batch when the table's
+// records are not sorted into classes); KS k-mers per lane, NL loads per lane (the slot rows + the records' meta words)
 template <int CAP> struct MergeStep {
-    static constexpr int CXS = CAP > PG_SHORT_MAX_ ? PG_SHORT_MAX_ : CAP;
-    static constexpr int NS = PG_MERGE_NS < CAP ? CAP : PG_MERGE_NS;
-    static constexpr int GS = CAP > PG_SHORT_MAX_ ? NS / CXS : 0;               // batches of short records per step
+    static constexpr bool TWO = CAP > PG_SHORT_MAX_;
+    static constexpr int CXS = TWO ? PG_SHORT_MAX_ : CAP;
+    static constexpr int KS = TWO ? (CAP > 2 * CXS ? CAP : 2 * CXS) : CAP;
+    static constexpr int NL = TWO ? 2 + 2 * CXS : 1 + CAP;
+    static constexpr int SLACK = 32 * (KS + 2);                                 // dwords a step may read behind the bucket's range (whole rows)
+    static_assert(!TWO || (CAP <= 2 * CXS + 1 && NL == 10), "the long batch's rows fit the short step's loads");
 };
 
 template <int CAP, int BLK, int DIG>
 __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 {
-    // Two stages, repeated until the bucket's words are used up (once or twice per bucket).
-    // A (no barrier inside): every wavefront walks over its share of the work in STEPS of NS rows of 64 words -- GS batches of
-    //   short records (a lane takes one record of each), one batch of long records, or NS x 64 singles --: fetch the rows (they
-    //   lie at A0 + 64 i + lane: one scalar base, constant offsets, nothing to read first), turn the words into bins, merge equal
-    //   neighbouring (row, bin) words of a record into one word with a count, append the step's words to a stage of FL::TILE words
-    //   in LDS (one returning add per step claims the positions).  The rows of the NEXT step are in flight meanwhile, and the
-    //   wavefronts are at different points of the loop at any time.
+    // Two stages, repeated until the bucket's records are used up (once or twice per bucket).
+    // A (no barrier inside): every wavefront walks over its share of the work in STEPS -- two batches of short records (a lane
+    //   takes one record of each) or one batch of long records --: fetch the slot rows and the records' meta words (one scalar base
+    //   + constant offsets each, nothing to read first), turn the slots into bins, merge equal neighbouring (row, bin) words of a
+    //   record into one word with a count, append the step's words to a stage of FL::TILE words in LDS (one returning add per
+    //   step claims the positions).  The loads of the NEXT step are in flight meanwhile, and the wavefronts are at different
+    //   points of the loop at any time.
     // B (when the stage is full or the work is done): the staged words are sorted by the first digit of their row group into a
     //   second buffer (WPL per lane: rank, scan, place) and copied out to the group regions, one global cursor add per digit.
     using FL = MergeLds<BLK, DIG>;
     using ST = MergeStep<CAP>;
     constexpr int DPT = DIG / BLK, WAVES_B = BLK / 64, WPL = FL::WPL;
-    constexpr int CXS = ST::CXS, NS = ST::NS, GS = ST::GS;
+    constexpr bool TWO = ST::TWO;
+    constexpr int CXS = ST::CXS, KS = ST::KS, NL = ST::NL;
     constexpr uint32_t NONE = WORD_NONE;
-    static_assert(CAP <= NS && GS * CXS <= NS, "slots of a step");
     __shared__ uint32_t staged, valid_end, busy;
     const uint16_t *bins16 = reinterpret_cast<const uint16_t *>(c.lds);
     uint32_t *buf = reinterpret_cast<uint32_t *>(c.lds + FL::BUF), *sorted = reinterpret_cast<uint32_t *>(c.lds + FL::BUF1), *cnt = reinterpret_cast<uint32_t *>(c.lds + FL::CNT);
@@ -874,10 +879,12 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     unsigned long long *gbase = reinterpret_cast<unsigned long long *>(c.lds + FL::GBASE);
     const ShufArgs &sh = c.sh;
     const uint32_t smask = c.smask;
-    const int lb = c.lb, vbits = c.vbits;
+    const int vbits = c.vbits;
     uint32_t *const status = c.status;
     const uint32_t *const prov_b = c.prov_b;
+    const uint32_t *const meta_s = c.meta_s, *const meta_l = c.meta_l;
     const uint32_t lane = lane_id(), wave = uniform32(threadIdx.x >> 6);
+    const uint32_t half_lane = lane >> 1, parity_shift = (lane & 1u) * 16u;      // a row of 64 halfwords is read as 32 dwords: two lanes share one
     const uint32_t dmask = (1u << sh.gb1) - 1u;
     uint32_t *const wout = sh.words_out;
 #ifdef PG_MINI_STAMPS
@@ -886,60 +893,73 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 #else
 #define PG_MLAP(K) do { } while (0)
 #endif
-    const uint32_t n_sb = GS ? uniform32(c.n_sb) : 0u, n_lb = uniform32(c.n_lb), n_ring = uniform32(c.n_ring);
-    const uint32_t long_base = uniform32(c.n_sb) * 64u * CXS, single_base = long_base + n_lb * 64u * CAP;
-    const uint32_t n_ss = GS ? (n_sb + GS - 1) / (GS ? GS : 1) : 0u;            // steps of short batches, then one per long batch, then the singles
-    const uint32_t n_steps = n_ss + n_lb + (n_ring + 64u * NS - 1u) / (64u * NS);
+    const uint32_t n_s = TWO ? uniform32(c.n_s) : 0u, n_l = uniform32(c.n_l);
+    const uint32_t n_sb = (n_s + 63u) >> 6, n_lb = (n_l + 63u) >> 6;
+    const uint32_t long_base = n_sb * 32u * CXS;                 // (dwords: a row of 64 slots is 32 of them)
+    const uint32_t n_ss = TWO ? (n_sb + 1u) >> 1 : 0u;           // steps of short batches, then one per long batch
+    const uint32_t n_steps = n_ss + n_lb;
     if (n_steps == 0u) return;                                   // (uniform)
-    // a step's rows: first word of row 0 (A0), rows that belong to it (NV), words of its class (LIM), first slots of its records (GST)
-    struct StepGeo { uint32_t a0, nv, lim, gst, kind; };
+    // a step: first dword of its slot rows (A0), is it a step of short records (SHORT), first record of its (first) batch and the
+    // records of its class (REC, NCLS)
+    struct StepGeo { uint32_t a0, is_short, rec, ncls; };
     auto geometry = [&](uint32_t st) -> StepGeo {
         StepGeo g;
-        g.kind = st < n_ss ? 0u : st < n_ss + n_lb ? 1u : 2u;
-        if (st < n_ss) {
-            const uint32_t left = n_sb - st * GS;
-            g.a0 = st * (64u * CXS * GS); g.nv = (left < (uint32_t)GS ? left : (uint32_t)GS) * CXS; g.lim = long_base;
-            g.gst = 0;
-#pragma unroll
-            for (int t = 0; t < (GS ? GS : 1); ++t) g.gst |= 1u << (t * CXS);
-        } else if (st < n_ss + n_lb) {
-            g.a0 = long_base + (st - n_ss) * (64u * CAP); g.nv = CAP; g.lim = single_base; g.gst = 1u;
-        } else {
-            g.a0 = single_base + (st - n_ss - n_lb) * (64u * NS); g.nv = NS; g.lim = single_base + n_ring; g.gst = (1u << NS) - 1u;
-        }
+        if (TWO && st < n_ss) { g.a0 = st * (64u * CXS); g.is_short = 1u; g.rec = st * 128u; g.ncls = n_s; }
+        else { g.a0 = long_base + (st - n_ss) * (32u * CAP); g.is_short = 0u; g.rec = (st - n_ss) * 64u; g.ncls = n_l; }
         return g;
     };
-    // the loads of a step: a scalar base and constant offsets (whole rows; rows beyond the step's own are read and ignored: the
-    // buffer has slack for them).  Nothing is computed from the values here.
-    auto fetch_rows = [&](const StepGeo &g, uint32_t (&w)[NS]) {
-        const uint32_t *row0 = prov_b + g.a0;
+    // the loads of a step: scalar bases and constant offsets (whole rows; what lies beyond the step's own rows is read and
+    // ignored: the buffer has slack for it; a record index beyond its class is clamped).  Nothing is computed from the values here.
+    //   w[0] = meta word of the lane's (first) record, w[1 + i] = slot row i, w[9] (two classes) = meta word of the second short
+    //   record, or slot row 8 of a long one
+    auto fetch_rows = [&](const StepGeo &g, uint32_t (&w)[NL]) {
+        const uint32_t *rows = prov_b + g.a0;
+        const uint32_t *meta_c = g.is_short ? meta_s : meta_l;
+        const uint32_t last = g.ncls - 1u;
+        const uint32_t ia = g.rec + lane < last ? g.rec + lane : last;
+        w[0] = meta_c[ia];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-#ifdef PG_DIAG_ROWS
-            // (diagnostic, WRONG results: a third of the rows are not stored by the count loop and read as copies of their neighbours
-            // here -- same instructions, fewer bytes: what would a denser provisional format buy?)
-            const uint32_t ie = g.kind == 0u ? ((i & 3) == 3 ? i - 1 : i) : g.kind == 1u ? (i >= 6 ? i - 3 : i) : i;
-            w[i] = row0[64 * ie + lane];
-#else
-            w[i] = row0[64 * i + lane];
-#endif
+        for (int i = 0; i < (TWO ? 2 * CXS : CAP); ++i) w[1 + i] = rows[32 * i + half_lane];
+        if (TWO) {
+            const uint32_t ib = g.rec + 64u + lane < last ? g.rec + 64u + lane : last;
+            const uint32_t *p9 = g.is_short ? meta_c : rows + 32 * (2 * CXS);
+            w[NL - 1] = p9[g.is_short ? ib : half_lane];
         }
     };
-    // raw words -> bins -> (row, bin) words; equal neighbours inside a record become ONE word with the run length on top
-    auto process = [&](const StepGeo &g, uint32_t (&w)[NS]) {
-        uint32_t b1[NS];
+    // meta words + slots -> bins -> (row, bin) words; equal neighbours inside a record become ONE word with the run length on top
+    auto process = [&](const StepGeo &g, const uint32_t (&r)[NL], uint32_t (&w)[KS]) {
+        const uint32_t ma = r[0];
+        const uint32_t row_a = ma >> META_ROW_SHIFT, n_a = ((ma >> META_D2_BITS) & (uint32_t)(MINI_MAX_LEN - 1)) + 1u;
+        const bool ok_a = g.rec + lane < g.ncls && row_a != MINI_ROW_NONE;
+        // the record that k-mer slots CXS .. KS - 1 belong to: the second short record, or the long one again
+        uint32_t row_x = row_a, n_x = n_a;
+        bool ok_x = ok_a;
+        if (TWO) {
+            const uint32_t mb = r[NL - 1];
+            const uint32_t row_b = mb >> META_ROW_SHIFT, n_b = ((mb >> META_D2_BITS) & (uint32_t)(MINI_MAX_LEN - 1)) + 1u;
+            const bool ok_b = g.rec + 64u + lane < g.ncls && row_b != MINI_ROW_NONE;
+            row_x = g.is_short ? row_b : row_a;
+            n_x = g.is_short ? n_b + (uint32_t)CXS : n_a;        // (a short record has at most CXS k-mers: slot 2 CXS is never its own)
+            ok_x = g.is_short ? ok_b : ok_a;
+        }
+        uint32_t b1[KS];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) b1[i] = bins16[w[i] & smask];
+        for (int i = 0; i < KS; ++i) {
+            const uint32_t pair = r[i < 2 * CXS || !TWO ? 1 + i : NL - 1];
+            b1[i] = bins16[(pair >> parity_shift) & 0xffffu & smask];
+        }
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const bool ok = (uint32_t)i < g.nv && g.a0 + 64u * i + lane < g.lim && w[i] != NONE && (uint32_t)(b1[i] - 1u) < 0xfffeu;
-            w[i] = ok ? ((w[i] >> lb) << vbits) | (b1[i] - 1u) : NONE;
+        for (int i = 0; i < KS; ++i) {
+            const bool first = !TWO || i < CXS;
+            const bool ok = (first ? ok_a && (uint32_t)i < n_a : ok_x && (uint32_t)i < n_x) && (uint32_t)(b1[i] - 1u) < 0xfffeu;
+            w[i] = ok ? ((first ? row_a : row_x) << vbits) | (b1[i] - 1u) : NONE;
         }
         uint32_t len = 0;
 #pragma unroll
-        for (int i = NS - 1; i >= 0; --i) {
+        for (int i = KS - 1; i >= 0; --i) {
             const uint32_t cur = w[i];
-            const uint32_t before = (i == 0 || ((g.gst >> i) & 1u)) ? NONE : w[i > 0 ? i - 1 : 0];
+            const bool rec_start = i == 0 || (TWO && i == CXS && g.is_short);
+            const uint32_t before = rec_start ? NONE : w[i > 0 ? i - 1 : 0];
             const bool head = cur != NONE && cur != before;
             w[i] = head ? (len << MERGE_CSHIFT) | cur : NONE;
             len = (cur != NONE && !head) ? len + 1u : 0u;
@@ -965,31 +985,32 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }
     uint32_t step = wave;                                        // this wavefront's next step
     bool pending = false;                                        // pw[] holds words that did not fit the stage yet (wave-uniform)
-    uint32_t pw[NS];                                             // the words of the step in hand
-    uint32_t cw[NS];                                             // the raw rows of `step`, in flight or here (not kept across stage B)
+    uint32_t pw[KS];                                             // the words of the step in hand
+    uint32_t cw[NL];                                             // what `step` loaded, in flight or here (not kept across stage B)
     lds_sync();
     for (;;) {
-        // the rows of `step`: at the start, and again behind every stage B, which had the registers
+        // the loads of `step`: at the start, and again behind every stage B, which had the registers
         fetch_rows(geometry(step < n_steps ? step : 0u), cw);
         // ---- A
         for (;;) {
             if (!pending) {
                 if (step >= n_steps) break;                      // (uniform)
                 const StepGeo g = geometry(step);
+                uint32_t raw[NL];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) pw[i] = cw[i];
+                for (int i = 0; i < NL; ++i) raw[i] = cw[i];
                 step += WAVES_B;
                 // (scheduling barriers: the compiler must neither sink these requests below the work on the step in hand nor pull
                 // that work -- and with it the wait for what was just requested -- up in front of them)
                 __builtin_amdgcn_sched_barrier(0);
-                fetch_rows(geometry(step < n_steps ? step : 0u), cw);      // the next step's rows: in flight while this one is worked on
+                fetch_rows(geometry(step < n_steps ? step : 0u), cw);      // the next step's loads: in flight while this one is worked on
                 __builtin_amdgcn_sched_barrier(0);
-                process(g, pw);
+                process(g, raw, pw);
                 pending = true;
             }
             uint32_t n = 0;
 #pragma unroll
-            for (int j = 0; j < NS; ++j) n += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pw[j] != NONE));
+            for (int j = 0; j < KS; ++j) n += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pw[j] != NONE));
             if (n == 0) { pending = false; continue; }           // (uniform)
             uint32_t at = 0;
             if (lane == 0) at = atomicAdd(&staged, n);
@@ -999,7 +1020,7 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
                 break;
             }
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
+            for (int j = 0; j < KS; ++j) {
                 const unsigned long long hm = __builtin_amdgcn_ballot_w64(pw[j] != NONE);
                 if (hm == 0ull) continue;                        // (uniform)
                 if (pw[j] != NONE) buf[at + lanes_below(hm)] = pw[j];
@@ -1139,13 +1160,13 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // every occurrence that lies in a row leaves exactly one word: the bucket's word range is claimed before the first word is
         // written (one global add).  The total comes with the records (the second scatter pass tallies it per bucket); without that
         // pass -- at most 256 buckets -- a pre-pass over the meta plane counts it.
-        // (MERGE: fixed slots for the words of every batch, then room for the singles -- see MergeArgs)
-        const unsigned long long fixed_words = MERGE ? 64ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
-                                                       + 64ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP : 0ull;
+        // (MERGE: nothing but fixed places, 2 bytes per k-mer of every batch of 64 records -- see MergeArgs; claimed in dwords)
+        const unsigned long long fixed_words = MERGE ? 32ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
+                                                       + 32ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP : 0ull;
         if (kwords) {
             if (threadIdx.x == 0) {
                 n_lookups = kwords[blockIdx.x];
-                wbase = atomicAdd(word_cursor, n_lookups + fixed_words);
+                wbase = atomicAdd(word_cursor, MERGE ? fixed_words : n_lookups);
             }
         } else {
             unsigned long long mine = 0;
@@ -1161,7 +1182,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 unsigned long long run = 0;
                 for (int w = 0; w < (BLK / 64); ++w) run += wave_words[w];
                 n_lookups = run;
-                wbase = atomicAdd(word_cursor, run + fixed_words);
+                wbase = atomicAdd(word_cursor, MERGE ? fixed_words : run);
             }
         }
     }
@@ -1169,8 +1190,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     if (MERGE && emit_slots) {
         // (the word buffer was sized from the plan's record counts; a range that does not fit it -- a plan of other reads -- is
         // not written: bit 2 of the status word, as for the record buffers)
-        const unsigned long long need = n_lookups + 64ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
-                                        + 64ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP + 64ull * MergeStep<CAP>::NS;
+        const unsigned long long need = 32ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
+                                        + 32ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP + (unsigned long long)MergeStep<CAP>::SLACK;
         if (wbase + need > mg.cap) {                             // (uniform)
             if (threadIdx.x == 0) atomicOr(status, PG_STATUS_PLAN_MISMATCH);
             return;
@@ -1188,10 +1209,12 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (lane == 0) at = atomicAdd(&emitted, n_words);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
     };
-    // MERGE: the bucket's word range = batches of short records | batches of long records | singles (see MergeArgs)
+    // MERGE: the bucket's range = batches of short records | batches of long records, a halfword per k-mer (see MergeArgs)
     constexpr uint32_t CXS_ = CAP > SHORT_MAX ? SHORT_MAX : CAP;
     const uint32_t n_sb = (uint32_t)((rs - r0 + 63) >> 6), n_lb = (uint32_t)((r1 - rs + 63) >> 6);
-    const uint32_t long_base = n_sb * 64u * CXS_, single_base = long_base + n_lb * 64u * CAP;
+    const uint32_t long_base = n_sb * 64u * CXS_;                // (halfwords)
+    const uint32_t np_half = long_base + n_lb * 64u * CAP;       // (... of the bucket, for the checked build)
+    uint16_t *const prov_h = reinterpret_cast<uint16_t *>(prov_b);
     const uint32_t np_all = (uint32_t)n_lookups;                 // (emit_slots: the bucket's words, known before the first is written)
     PG_STAMP(0);
     bool full = false;
@@ -1201,20 +1224,20 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     auto slow_round = [&](bool act) {
         const uint32_t at = (head + lane) & (RING - 1);
         const uint64_t c = act ? ring[at] : 0ull;
-        const uint32_t rw = act && emit_slots ? ring_row[at] : MINI_ROW_NONE;
+        constexpr uint32_t RING_NONE = MERGE ? 0xffffffffu : MINI_ROW_NONE;      // (MERGE: ring_row holds places, not rows)
+        const uint32_t rw = act && emit_slots ? ring_row[at] : RING_NONE;
         const uint32_t sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act);
         full |= act && sl == 0xffffffffu;
         if (emit_slots) {
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
-            const bool put = rw != MINI_ROW_NONE;
+            const bool put = rw != RING_NONE;
             const unsigned long long qm = __ballot(put);
+            if (MERGE) {
+                // (the ring carried the k-mer's own place among the bucket's halfwords instead of its row)
+                if (put) gstore(prov_h, (uint64_t)rw, (uint64_t)np_half, (uint16_t)(sl == 0xffffffffu ? 0xffffu : sl & smask), status);
+            } else
             if (qm) {                                            // (uniform)
-                if (MERGE) {                                     // singles: behind the batches' fixed slots
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&emitted_ring, (uint32_t)__popcll(qm));
-                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-                    if (put) gstore(prov_b, (uint64_t)single_base + at + lanes_below(qm), (uint64_t)single_base + np_all, (rw << lb) | (sl & smask), status);
-                } else {
+                {
                     const uint32_t at = claim((uint32_t)__popcll(qm));
                     if (put) gstore(prov_b, (uint64_t)at + lanes_below(qm), (uint64_t)np_all, (rw << lb) | (sl & smask), status);
                 }
@@ -1233,6 +1256,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             const int n = live ? (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1 : 0;
             const uint32_t row = m >> META_ROW_SHIFT;
             const bool in_row = live && row != MINI_ROW_NONE;
+            // (MERGE) the lane's first halfword in the bucket's range: k-mer j of its record has place0 + 64 j
+            const uint32_t place0 = (CX < CAP ? 0u : long_base) + (uint32_t)((i0 - ra) >> 6) * (64u * CX) + lane;
             if (in_row) mine += (unsigned long long)n;
             const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
             i = i0 + BLK + lane;                           // the next batch's loads fly during this one
@@ -1299,7 +1324,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
                         const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
                         ring[at] = code[j];
-                        if (emit_slots) ring_row[at] = row;
+                        // (MERGE: the general insert writes the slot to the k-mer's own place: the ring carries that place)
+                        if (emit_slots) ring_row[at] = MERGE ? (row != MINI_ROW_NONE ? place0 + 64u * j : 0xffffffffu) : row;
                     }
                     tail += (uint32_t)__popcll(mask);
                     if (tail - head >= 64) {
@@ -1317,14 +1343,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             PG_WLAP(3);                                          // (ring pushes, general inserts)
             if (emit_slots) {
                 if (MERGE) {
-                    // fixed slots: row j of the batch = the j-th k-mers of its 64 records, whole rows, NONE where a k-mer left no word
-                    uint32_t *rowp = prov_b + (CX < CAP ? 0u : long_base) + (uint32_t)((i0 - ra) >> 6) * (64u * CX) + lane;
+                    // fixed places: halfword row j of the batch = the slots of the j-th k-mers of its 64 records; a k-mer that the
+                    // first probe did not settle gets its slot from the general insert, one outside every row gets none
 #pragma unroll
                     for (int j = 0; j < CX; ++j)
-#ifdef PG_DIAG_ROWS
-                        if (j < (CX < CAP ? 3 : 6))
-#endif
-                        rowp[64 * j] = __builtin_amdgcn_inverse_ballot_w64(pm[j]) ? (row << lb) | sl[j] : WORD_NONE;
+                        if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) gstore(prov_h, (uint64_t)place0 + 64u * j, (uint64_t)np_half, (uint16_t)sl[j], status);
                 } else
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
                 // shuffle do not like runs of equal words).  (Deferring these stores to the next iteration's top, behind its
@@ -1462,8 +1485,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         const uint32_t np = (uint32_t)n_lookups;
         if (MERGE) {
             MergeCtx mc;
-            mc.lds = lds; mc.smask = smask; mc.lb = lb; mc.vbits = vbits; mc.sh = sh; mc.status = status;
-            mc.prov_b = prov_b; mc.n_sb = n_sb; mc.n_lb = n_lb; mc.n_ring = emitted_ring;
+            mc.lds = lds; mc.smask = smask; mc.vbits = vbits; mc.sh = sh; mc.status = status;
+            mc.prov_b = prov_b; mc.meta_s = meta + r0; mc.meta_l = meta + rs; mc.n_s = (uint32_t)(rs - r0); mc.n_l = (uint32_t)(r1 - rs);
 #ifdef PG_MINI_STAMPS
             mc.dbg = dbg;
 #endif
@@ -1762,7 +1785,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_lookup_half_merge_kernel(const un
                                                                       const unsigned long long *__restrict__ wbeg, const uint32_t *__restrict__ ring_cnt,
                                                                       const unsigned long long *__restrict__ occ,
                                                                       const uint16_t *__restrict__ bins_in, const long long *__restrict__ bin_elem,
-                                                                      int log2_bucket, int vbits, const uint32_t *__restrict__ mprov, ShufArgs sh, uint32_t *status)
+                                                                      int log2_bucket, int vbits, const uint32_t *__restrict__ mprov,
+                                                                      const uint32_t *__restrict__ meta, ShufArgs sh, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t n_slots = 1u << log2_bucket, smask = n_slots - 1u;
@@ -1797,9 +1821,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_lookup_half_merge_kernel(const un
     }
     __syncthreads();
     MergeCtx mc;
-    mc.lds = lds; mc.smask = smask; mc.lb = log2_bucket; mc.vbits = vbits; mc.sh = sh; mc.status = status;
+    mc.lds = lds; mc.smask = smask; mc.vbits = vbits; mc.sh = sh; mc.status = status;
     mc.prov_b = mprov + wbeg[blockIdx.x];
-    mc.n_sb = (uint32_t)((rs - r0 + 63) >> 6); mc.n_lb = (uint32_t)((r1 - rs + 63) >> 6); mc.n_ring = ring_cnt[blockIdx.x];
+    mc.meta_s = meta + r0; mc.meta_l = meta + rs; mc.n_s = (uint32_t)(rs - r0); mc.n_l = (uint32_t)(r1 - rs);
     mc.dbg = nullptr;
     merged_lookup<CAP, BLK, DIG>(mc);
 }
@@ -1913,6 +1937,17 @@ struct MiniRecLayout { size_t cap, total; };
 MiniRecLayout mini_rec_layout(size_t cap, size_t)
 {
     return MiniRecLayout{cap, 24 * cap};
+}
+
+// the largest record capacity (a multiple of 256) whose layout fits a workspace of that many bytes
+size_t mini_rec_cap(int64_t rec_ws_bytes, size_t nb)
+{
+    size_t cap = 0;
+    if (rec_ws_bytes > 0) {
+        cap = (size_t)rec_ws_bytes / 24 / 256 * 256;
+        while (cap >= 256 && mini_rec_layout(cap, nb).total > (size_t)rec_ws_bytes) cap -= 256;
+    }
+    return cap;
 }
 
 int check_mini_rows(const pg_rows *rows, const char *who)
@@ -2068,12 +2103,7 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     if ((reinterpret_cast<uintptr_t>(plan_ws) & 255) != 0 || (reinterpret_cast<uintptr_t>(rec_ws) & 255) != 0)
         return pg_fail(PG_EINVAL, "pg_mini_count: workspaces must be 256-byte aligned");
     // the largest record capacity (a multiple of 256) whose layout fits the workspace
-    const size_t nb_l = (size_t)1 << p.bits;
-    size_t cap = 0;
-    if (rec_ws_bytes > 0) {
-        cap = (size_t)rec_ws_bytes / 24 / 256 * 256;
-        while (cap >= 256 && mini_rec_layout(cap, nb_l).total > (size_t)rec_ws_bytes) cap -= 256;
-    }
+    const size_t cap = mini_rec_cap(rec_ws_bytes, (size_t)1 << p.bits);
     if (cap < 256) return pg_fail(PG_EINVAL, "pg_mini_count: record workspace of %lld bytes (pg_mini_records_bytes)", (long long)rec_ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)plan_ws;
@@ -2226,9 +2256,8 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
                            shuffle_ws_bytes, status, stream, nullptr, merge_ws, merge_ws_words);
 }
 
-// words of the merged form's provisional-word buffer (pg_mini_count's merge_ws): fixed slots for every batch of 64 records of
-// either class, room for the singles (at most one per character), a step's slack.  n_records / n_long_records: the first and
-// third 8-byte word of the plan workspace.
+// dwords of the merged form's provisional buffer (pg_mini_count's merge_ws): a halfword per k-mer slot of every batch of 64
+// records of either class, a step's slack.  n_records / n_long_records: the first and third 8-byte word of the plan workspace.
 extern "C" int64_t pg_mini_merge_words(int64_t n_words, int64_t n_records, int64_t n_long_records, const pg_table *t)
 {
     int rc = check_mini(t, "pg_mini_merge_words");
@@ -2241,8 +2270,10 @@ extern "C" int64_t pg_mini_merge_words(int64_t n_words, int64_t n_records, int64
     plan_mini(t, n_words, &p);
     const bool two = cap_t > SHORT_MAX && p.bits2 > 0;               // (without a second scatter pass the classes are not sorted apart: all "long")
     const int64_t n_long = two ? n_long_records : n_records, n_short = two ? n_records - n_long_records : 0;
-    const int64_t fixed = 64 * (int64_t)(two ? SHORT_MAX : cap_t) * (n_short / 64 + nb) + 64 * (int64_t)cap_t * (n_long / 64 + nb);
-    return (fixed + n_words * 32 + 64 * 16 + 255) / 256 * 256;
+    // (dwords: a batch of 64 records has a row of 64 halfwords = 32 dwords per k-mer of its class's cap; every bucket rounds both
+    // classes up to whole batches; a step's slack behind the last bucket)
+    const int64_t fixed = 32 * (int64_t)(two ? SHORT_MAX : cap_t) * (n_short / 64 + nb) + 32 * (int64_t)cap_t * (n_long / 64 + nb);
+    return (fixed + 32 * 16 + 255) / 256 * 256;
 }
 
 // ---- N > 1 ranks (see the kernels above): workspace of the count half: entry slabs | occupancy bitmaps | ring counts
@@ -2320,7 +2351,8 @@ extern "C" int pg_mini_merge_bins(const uint64_t *recv, int64_t part_stride, con
     return check_launch("pg_mini_merge_bins");
 }
 
-extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_counted,
+extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, const void *rec_ws, int64_t rec_ws_bytes,
+                                   int64_t n_words_counted,
                                    int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, const void *merge_ws, int64_t merge_ws_words,
                                    const void *half_ws, int64_t half_ws_bytes,
                                    const uint16_t *bins_in, const int64_t *bin_elem, uint32_t *status, void *stream)
@@ -2348,6 +2380,11 @@ extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, c
     const unsigned nb = 1u << p.bits;
     const auto *occ = (const unsigned long long *)((const char *)half_ws + hl.occ_off);
     if (merge) {
+        // (the merged form reads the records' meta words again: lengths and rows say which provisional slots mean anything)
+        if (!rec_ws) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: the merged form needs the count half's record workspace");
+        const size_t rcap = mini_rec_cap(rec_ws_bytes, (size_t)1 << p.bits);
+        if (rcap < 256) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: record workspace of %lld bytes (pg_mini_records_bytes)", (long long)rec_ws_bytes);
+        const uint32_t *meta_b = (const uint32_t *)((const uint64_t *)rec_ws + 2 * rcap) + rcap;     // [bases A | bases B | meta A | meta B]
         const auto *off = (const unsigned long long *)(ws + p.off_off);
         const auto *cur2 = (const unsigned long long *)(ws + p.cur2_off);
         const auto *ring = (const uint32_t *)((const char *)half_ws + hl.ring_off);
@@ -2359,7 +2396,7 @@ extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, c
             const size_t lds_ = MergeLds<BIG_BLOCK, DIG_>::END;                                                             \
             if ((rc = raise_lds_limit((const void *)(mini_lookup_half_merge_kernel<CAP_, BIG_BLOCK, DIG_>), lds_, "pg_mini_lookup_half"))) return rc; \
             hipLaunchKernelGGL((mini_lookup_half_merge_kernel<CAP_, BIG_BLOCK, DIG_>), dim3(nb), dim3(BIG_BLOCK), lds_, s2, off, n_short, wbeg, ring, occ, \
-                               bins_in, (const long long *)bin_elem, local->log2_bucket_slots, ctx.vbits, (const uint32_t *)merge_ws, sh, status); \
+                               bins_in, (const long long *)bin_elem, local->log2_bucket_slots, ctx.vbits, (const uint32_t *)merge_ws, meta_b, sh, status); \
         } while (0)
 #define PG_LOOKUP_HALF_MC(CAP_) do { if (ctx.gb1 > 10) PG_LOOKUP_HALF_M(CAP_, 2048); else PG_LOOKUP_HALF_M(CAP_, 1024); } while (0)
         switch (cap_k) {

@@ -447,7 +447,8 @@ class KmerTable:
         L = _lib.load()
         plan_ws = self._mini_plan[1]
         with torch.cuda.device(self.device):
-            _lib.check(L.pg_mini_lookup_half(self.desc(), C.byref(keep.rows_desc), plan_ws.data_ptr(), plan_ws.numel(), n_words, vsize,
+            _lib.check(L.pg_mini_lookup_half(self.desc(), C.byref(keep.rows_desc), plan_ws.data_ptr(), plan_ws.numel(),
+                                             self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(), n_words, vsize,
                                              self._shuffle_ws.data_ptr(), self._shuffle_ws.numel(),
                                              self._merge_ws.data_ptr() if getattr(self, "_merge_ws", None) is not None else None,
                                              self._merge_ws.numel() if getattr(self, "_merge_ws", None) is not None else 0,
