@@ -1008,9 +1008,12 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
                 process(g, raw, pw);
                 pending = true;
             }
+            // (the ballots are taken once and the lanes picked from the scalar masks: a predicate that crosses the branches below
+            // would be re-materialised per use as v_cndmask + v_cmp)
+            unsigned long long hm[KS];
             uint32_t n = 0;
 #pragma unroll
-            for (int j = 0; j < KS; ++j) n += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pw[j] != NONE));
+            for (int j = 0; j < KS; ++j) { hm[j] = __builtin_amdgcn_ballot_w64(pw[j] != NONE); n += (uint32_t)__popcll(hm[j]); }
             if (n == 0) { pending = false; continue; }           // (uniform)
             uint32_t at = 0;
             if (lane == 0) at = atomicAdd(&staged, n);
@@ -1021,10 +1024,9 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
             }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(pw[j] != NONE);
-                if (hm == 0ull) continue;                        // (uniform)
-                if (pw[j] != NONE) buf[at + lanes_below(hm)] = pw[j];
-                at += (uint32_t)__popcll(hm);
+                if (hm[j] == 0ull) continue;                     // (uniform)
+                if (__builtin_amdgcn_inverse_ballot_w64(hm[j])) buf[at + lanes_below(hm[j])] = pw[j];
+                at += (uint32_t)__popcll(hm[j]);
             }
             pending = false;
         }
