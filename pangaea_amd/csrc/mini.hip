@@ -954,15 +954,16 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
             const bool ok = (first ? ok_a && (uint32_t)i < n_a : ok_x && (uint32_t)i < n_x) && (uint32_t)(b1[i] - 1u) < 0xfffeu;
             w[i] = ok ? ((first ? row_a : row_x) << vbits) | (b1[i] - 1u) : NONE;
         }
-        uint32_t len = 0;
+        // (from the last slot down: `run` = how many slots behind this one repeat it.  Two absent neighbours also count as "the same",
+        // which never reaches a head: the run is reset where an absent slot follows a present one)
+        uint32_t run = 0;
 #pragma unroll
         for (int i = KS - 1; i >= 0; --i) {
             const uint32_t cur = w[i];
             const bool rec_start = i == 0 || (TWO && i == CXS && g.is_short);
-            const uint32_t before = rec_start ? NONE : w[i > 0 ? i - 1 : 0];
-            const bool head = cur != NONE && cur != before;
-            w[i] = head ? (len << MERGE_CSHIFT) | cur : NONE;
-            len = (cur != NONE && !head) ? len + 1u : 0u;
+            const bool same = !rec_start && cur == w[i > 0 ? i - 1 : 0];
+            w[i] = same || cur == NONE ? NONE : (run << MERGE_CSHIFT) | cur;
+            run = same ? run + 1u : 0u;
         }
     };
     // this thread's digits of a tile: claim their ranges in the group regions (one global add per digit and tile), scan
