@@ -1322,7 +1322,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             PG_WLAP(2);                                          // (hits added, positions claimed)
 #pragma unroll
             for (int j = 0; j < CX; ++j) {
+#if PG_DIAG_NORING + 0 == 1                                      // (diagnostic, WRONG results: nothing but the first probes -- what do the ring and the general insert cost?)
+                const unsigned long long mask = 0ull & qm[j];
+#else
                 const unsigned long long mask = qm[j];
+#endif
                 if (mask) {                                      // (uniform)
                     if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
                         const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
@@ -1331,7 +1335,12 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                         if (emit_slots) ring_row[at] = MERGE ? (row != MINI_ROW_NONE ? place0 + 64u * j : 0xffffffffu) : row;
                     }
                     tail += (uint32_t)__popcll(mask);
+#if PG_DIAG_NORING + 0 == 2                                      // (diagnostic, WRONG results: the pushes without the general insert)
+                    if (tail - head >= 64) head += 64;
+                    if (false) {
+#else
                     if (tail - head >= 64) {
+#endif
 #ifdef PG_MINI_STAMPS
                         const unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
