@@ -513,7 +513,8 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
             const int64_t i = t0 + j * BLOCK + threadIdx.x;
             if (i < r1) {
                 const uint32_t d = digit_of(rm[j]);
-                const uint32_t kw = (rm[j] >> META_ROW_SHIFT) != MINI_ROW_NONE ? ((rm[j] >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1u : 0u;
+                // (kwords == NULL: the merged lookups do not need the tally)
+                const uint32_t kw = kwords && (rm[j] >> META_ROW_SHIFT) != MINI_ROW_NONE ? ((rm[j] >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1u : 0u;
                 dr[j] = (d << 16) | (atomicAdd(&L.cnt[d], 1u | (kw << 16)) & 0xffffu);
             }
         }
@@ -1166,10 +1167,12 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // (MERGE: nothing but fixed places, 2 bytes per k-mer of every batch of 64 records -- see MergeArgs; claimed in dwords)
         const unsigned long long fixed_words = MERGE ? 32ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
                                                        + 32ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP : 0ull;
-        if (kwords) {
+        if (MERGE) {
+            if (threadIdx.x == 0) wbase = atomicAdd(word_cursor, fixed_words);
+        } else if (kwords) {
             if (threadIdx.x == 0) {
                 n_lookups = kwords[blockIdx.x];
-                wbase = atomicAdd(word_cursor, MERGE ? fixed_words : n_lookups);
+                wbase = atomicAdd(word_cursor, n_lookups);
             }
         } else {
             unsigned long long mine = 0;
@@ -1185,7 +1188,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 unsigned long long run = 0;
                 for (int w = 0; w < (BLK / 64); ++w) run += wave_words[w];
                 n_lookups = run;
-                wbase = atomicAdd(word_cursor, MERGE ? fixed_words : run);
+                wbase = atomicAdd(word_cursor, run);
             }
         }
     }
@@ -2174,11 +2177,14 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     } else {
         off = region_off;                                   // buckets = regions
     }
+    // (the merged lookups size their buffer from record counts: the second pass need not tally the k-mers in rows per bucket)
+    const bool merge_a2 = window > 0 && merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize);
     if (word_end > word_begin) {
         if (p.bits2) {
             const int tiles_x = 96;
             hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
-                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l, kwords,
+                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l,
+                               merge_a2 ? (unsigned long long *)nullptr : kwords,
                                (const unsigned long long *)header, (unsigned long long)cap, status);
         }
     }
