@@ -424,7 +424,11 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 // last position that ends no valid k-mer, whichever is later; its k-mers share one row (that of its last character)
 #pragma unroll
                 for (int e = 0; e < 32; ++e) {
+#if PG_DIAG_A1 + 0 == 2                                          // (diagnostic, WRONG results: the first pass without placement and stores)
+                    if (((has & wmask) >> e & 1u) && dr[e] == 0xffffffffu) {
+#else
                     if ((has & wmask) >> e & 1u) {
+#endif
                         const uint32_t b = dr[e] >> 16, d = b >> bits2;
                         const uint32_t at = L.start[d] + (dr[e] & 0xffffu);
                         const uint32_t below = e ? ((has | ~lw.ok) & ((1u << e) - 1u)) : 0u;     // ends / non-k-mers before e
@@ -438,12 +442,21 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 }
             }
             lds_sync();
+#if PG_DIAG_A1 + 0 == 2
+            const uint32_t tot = 0;
+#else
             const uint32_t tot = L.start[N1];
+#endif
             for (uint32_t i = threadIdx.x; i < tot; i += S1_BLOCK) {
                 // (a record beyond the buffers is dropped: cannot happen with the plan of THIS stream -- the offsets are exact --,
                 // and the plan of another one is reported below)
                 const unsigned long long g = L.gbase[L.dig[i]] + i;
-                if (g < rec_cap) {
+#if PG_DIAG_A1 + 0 == 1                                          // (diagnostic, WRONG results: the first pass without its stores)
+                if (g == 0xffffffffffffffffull)
+#else
+                if (g < rec_cap)
+#endif
+                {
                     out_bases[g] = L.bases[i];
                     out_meta[g] = L.meta[i];
                 }
