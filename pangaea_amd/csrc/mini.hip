@@ -857,13 +857,14 @@ template <int BLK, int DIG> struct MergeLds {
     static constexpr uint32_t BUF1 = BUF + 4 * TILE;
     static constexpr uint32_t CNT = BUF1 + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
 };
-// a step of the lookup phase: two batches of short records or one batch of long ones per wavefront (one batch when the table's
-// records are not sorted into classes); KS k-mers per lane, NL loads per lane (the slot rows + the records' meta words)
+// a step of the lookup phase: two batches of short records or one batch of long ones per wavefront (a table whose records are
+// not sorted into classes -- caps of at most PG_SHORT_MAX k-mers -- has short records only); KS k-mers per lane, NL loads per
+// lane (the slot rows + the records' meta words)
 template <int CAP> struct MergeStep {
     static constexpr bool TWO = CAP > PG_SHORT_MAX_;
     static constexpr int CXS = TWO ? PG_SHORT_MAX_ : CAP;
-    static constexpr int KS = TWO ? (CAP > 2 * CXS ? CAP : 2 * CXS) : CAP;
-    static constexpr int NL = TWO ? 2 + 2 * CXS : 1 + CAP;
+    static constexpr int KS = CAP > 2 * CXS ? CAP : 2 * CXS;
+    static constexpr int NL = 2 + 2 * CXS;
     static constexpr int SLACK = 32 * (KS + 2);                                 // dwords a step may read behind the bucket's range (whole rows)
     static_assert(!TWO || (CAP <= 2 * CXS + 1 && NL == 10), "the long batch's rows fit the short step's loads");
 };
@@ -896,7 +897,9 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     const int vbits = c.vbits;
     uint32_t *const status = c.status;
     const uint32_t *const prov_b = c.prov_b;
-    const uint32_t *const meta_s = c.meta_s, *const meta_l = c.meta_l;
+    // (one class only: its records -- handed over as the "long" ones, which is what the count loop's second range is -- are
+    // treated two batches per step, as short records are)
+    const uint32_t *const meta_s = TWO ? c.meta_s : c.meta_l, *const meta_l = c.meta_l;
     const uint32_t lane = lane_id(), wave = uniform32(threadIdx.x >> 6);
     const uint32_t half_lane = lane >> 1, parity_shift = (lane & 1u) * 16u;      // a row of 64 halfwords is read as 32 dwords: two lanes share one
     const uint32_t dmask = (1u << sh.gb1) - 1u;
@@ -907,10 +910,10 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 #else
 #define PG_MLAP(K) do { } while (0)
 #endif
-    const uint32_t n_s = TWO ? uniform32(c.n_s) : 0u, n_l = uniform32(c.n_l);
+    const uint32_t n_s = uniform32(TWO ? c.n_s : c.n_l), n_l = TWO ? uniform32(c.n_l) : 0u;
     const uint32_t n_sb = (n_s + 63u) >> 6, n_lb = (n_l + 63u) >> 6;
     const uint32_t long_base = n_sb * 32u * CXS;                 // (dwords: a row of 64 slots is 32 of them)
-    const uint32_t n_ss = TWO ? (n_sb + 1u) >> 1 : 0u;           // steps of short batches, then one per long batch
+    const uint32_t n_ss = (n_sb + 1u) >> 1;                      // steps of short batches, then one per long batch
     const uint32_t n_steps = n_ss + n_lb;
     if (n_steps == 0u) return;                                   // (uniform)
     // a step: first dword of its slot rows (A0), is it a step of short records (SHORT), first record of its (first) batch and the
@@ -918,7 +921,7 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     struct StepGeo { uint32_t a0, is_short, rec, ncls; };
     auto geometry = [&](uint32_t st) -> StepGeo {
         StepGeo g;
-        if (TWO && st < n_ss) { g.a0 = st * (64u * CXS); g.is_short = 1u; g.rec = st * 128u; g.ncls = n_s; }
+        if (!TWO || st < n_ss) { g.a0 = st * (64u * CXS); g.is_short = 1u; g.rec = st * 128u; g.ncls = n_s; }
         else { g.a0 = long_base + (st - n_ss) * (32u * CAP); g.is_short = 0u; g.rec = (st - n_ss) * 64u; g.ncls = n_l; }
         return g;
     };
@@ -933,8 +936,8 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         const uint32_t ia = g.rec + lane < last ? g.rec + lane : last;
         w[0] = meta_c[ia];
 #pragma unroll
-        for (int i = 0; i < (TWO ? 2 * CXS : CAP); ++i) w[1 + i] = rows[32 * i + half_lane];
-        if (TWO) {
+        for (int i = 0; i < 2 * CXS; ++i) w[1 + i] = rows[32 * i + half_lane];
+        {
             const uint32_t ib = g.rec + 64u + lane < last ? g.rec + 64u + lane : last;
             const uint32_t *p9 = g.is_short ? meta_c : rows + 32 * (2 * CXS);
             w[NL - 1] = p9[g.is_short ? ib : half_lane];
@@ -948,7 +951,7 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         // the record that k-mer slots CXS .. KS - 1 belong to: the second short record, or the long one again
         uint32_t row_x = row_a, n_x = n_a;
         bool ok_x = ok_a;
-        if (TWO) {
+        {
             const uint32_t mb = r[NL - 1];
             const uint32_t row_b = mb >> META_ROW_SHIFT, n_b = ((mb >> META_D2_BITS) & (uint32_t)(MINI_MAX_LEN - 1)) + 1u;
             const bool ok_b = g.rec + 64u + lane < g.ncls && row_b != MINI_ROW_NONE;
@@ -959,12 +962,12 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         uint32_t b1[KS];
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
-            const uint32_t pair = r[i < 2 * CXS || !TWO ? 1 + i : NL - 1];
+            const uint32_t pair = r[i < 2 * CXS ? 1 + i : NL - 1];
             b1[i] = bins16[(pair >> parity_shift) & 0xffffu & smask];
         }
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
-            const bool first = !TWO || i < CXS;
+            const bool first = i < CXS;
             const bool ok = (first ? ok_a && (uint32_t)i < n_a : ok_x && (uint32_t)i < n_x) && (uint32_t)(b1[i] - 1u) < 0xfffeu;
             w[i] = ok ? ((first ? row_a : row_x) << vbits) | (b1[i] - 1u) : NONE;
         }
@@ -974,7 +977,7 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 #pragma unroll
         for (int i = KS - 1; i >= 0; --i) {
             const uint32_t cur = w[i];
-            const bool rec_start = i == 0 || (TWO && i == CXS && g.is_short);
+            const bool rec_start = i == 0 || (i == CXS && g.is_short);
             const bool same = !rec_start && cur == w[i > 0 ? i - 1 : 0];
             w[i] = same || cur == NONE ? NONE : (run << MERGE_CSHIFT) | cur;
             run = same ? run + 1u : 0u;
