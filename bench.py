@@ -133,6 +133,7 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
     n = synth.write_fastq_fast(stream, cfg, fq, n_pairs)
     synth.write_fastq_fast(stream, cfg, warm, min(20_000, n_pairs))
     size = os.path.getsize(fq)
+    os.sync()                                           # (the file has just been written: its write-back must not run under the timed passes)
 
     def run(path):
         lap = {}
