@@ -387,7 +387,9 @@ struct UnitLines { const char *p[8]; size_t n[8]; int count; size_t off; };   //
 // sequential reader of file bytes [begin, end) through one block buffer; hands out lines and 8-line units
 class UnitReader {
 public:
-    UnitReader(int fd, size_t begin, size_t end, size_t block) : fd_(fd), base_(begin), end_(end), buf_(block) {}
+    // (the buffer has SLACK bytes behind its logical capacity: 32-byte vector loads may start at any byte of a line)
+    static constexpr size_t SLACK = 64;
+    UnitReader(int fd, size_t begin, size_t end, size_t block) : fd_(fd), base_(begin), end_(end), cap_(block), buf_(block + SLACK) {}
     bool io_error() const { return io_error_; }
     size_t offset() const { return base_ + cur_; }
     // the rest of the current line (up to and including its '\n'); false if the range ends first
@@ -419,6 +421,8 @@ public:
         for (;;) {
             size_t q = cur_;
             int k = 0;
+            if (simd_) q = scan_lines_avx2(u, k, want);
+            else
             while (k < want && q < have_) {
                 const char *b = buf_.data() + q;
                 const char *nl = (const char *)memchr(b, '\n', have_ - q);
@@ -439,13 +443,32 @@ public:
         }
     }
 private:
+    // up to `want` lines from cur_ on, their newlines found 32 bytes at a time (one pass over the unit instead of a memchr call
+    // per line); returns where the next line starts
+    __attribute__((target("avx2"))) size_t scan_lines_avx2(UnitLines &u, int &k, int want) const
+    {
+        const char *buf = buf_.data();
+        const __m256i nl = _mm256_set1_epi8('\n');
+        size_t start = cur_;
+        for (size_t pos = cur_; pos < have_ && k < want; pos += 32) {
+            uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(buf + pos)), nl));
+            if (have_ - pos < 32) m &= (1u << (have_ - pos)) - 1u;          // (bytes behind the data: the slack, stale)
+            while (m && k < want) {
+                const size_t at = pos + (size_t)__builtin_ctz(m);
+                u.p[k] = buf + start; u.n[k] = at - start; ++k;
+                start = at + 1;
+                m &= m - 1;
+            }
+        }
+        return start;
+    }
     // keep the unread tail, read on; false at the end of the range (or on error)
     bool more()
     {
         if (cur_ > 0) { memmove(buf_.data(), buf_.data() + cur_, have_ - cur_); base_ += cur_; have_ -= cur_; cur_ = 0; }
-        if (have_ == buf_.size()) buf_.resize(buf_.size() * 2);
+        if (have_ == cap_) { cap_ *= 2; buf_.resize(cap_ + SLACK); }
         const size_t at = base_ + have_;
-        const size_t want = std::min(buf_.size() - have_, end_ > at ? end_ - at : 0);
+        const size_t want = std::min(cap_ - have_, end_ > at ? end_ - at : 0);
         if (want == 0) { eof_ = true; return false; }
         const ssize_t got = pread(fd_, buf_.data() + have_, want, (off_t)at);
         if (got <= 0) { eof_ = true; io_error_ = got < 0 || at < end_; return false; }
@@ -454,6 +477,7 @@ private:
     }
     int fd_;
     size_t base_, end_;                 // file offset of buf_[0]; end of the range
+    size_t cap_;                        // bytes of buf_ that hold file data at most (SLACK more are allocated)
     std::vector<char> buf_;
     size_t have_ = 0, cur_ = 0;
     bool eof_ = false, io_error_ = false;
@@ -556,6 +580,7 @@ struct LocalStream {          // one thread's characters, packed from bit 0
     std::vector<LowerMask> lower;         // sparse: sequencer reads are upper case
     std::vector<uint32_t> lowq;           // paired files only (with_q): bases of quality below '?' -- dense, those are common
     bool with_q = false, any_q = false;
+    bool slack32 = false;                 // every line handed to put_line may be read 32 bytes past its end (UnitReader::SLACK)
     int64_t n = 0;
     uint64_t cw = 0; uint32_t vw = 0, qw = 0;
     const bool simd = simd_ok();
@@ -613,6 +638,18 @@ struct LocalStream {          // one thread's characters, packed from bit 0
             pack32_avx2(s + i, cb, vb);
             if (vb != 0xffffffffu) note_lower(s + i, 32, cb);
             put_bits(cb, vb, 32);
+        }
+        if (simd && slack32) {
+            // the last < 32 characters and the separator in one step: the 32-byte load runs past the line (into the next one, or
+            // into the slack behind the reader's buffer) and what it finds there is masked off
+            const int rem = (int)(len - i);
+            pack32_avx2(s + i, cb, vb);
+            const uint32_t keep = (1u << rem) - 1u;
+            vb &= keep;
+            cb &= (1ull << (2 * rem)) - 1ull;
+            if (vb != keep) note_lower(s + i, rem, cb);
+            put_bits(cb, vb, rem + 1);
+            return;
         }
         for (; i + 8 <= len; i += 8) {
             uint64_t x; memcpy(&x, s + i, 8); pack8(x, cb, vb);
@@ -700,6 +737,7 @@ int ingest_interleaved_range(int fd, size_t A, size_t B, const char *path, pg_re
         LocalStream &st = local[sink ? worker : t];
         if (rb[t] >= rb[t + 1]) return;
         st.reset();
+        st.slack32 = true;
         UnitReader rd(fd, rb[t], B, block);
         uint64_t line = nl_before[t];                      // index (from A) of the first line that starts in this range
         if (!at_line_start[t]) { if (!rd.skip_line()) { o.io_error = rd.io_error(); return; } ++line; }
