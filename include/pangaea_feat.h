@@ -118,6 +118,8 @@ const uint32_t *pg_reads_lower(const pg_reads *r);
 const uint32_t *pg_reads_lowq(const pg_reads *r);
 const int64_t *pg_reads_run_off(const pg_reads *r); /* [n_runs + 1] */
 const char *pg_reads_run_name(const pg_reads *r, int64_t i);
+/* every run name followed by a NUL into out[0 .. cap); returns the bytes needed (cap = 0, out = NULL: size only) */
+int64_t pg_reads_run_names(const pg_reads *r, char *out, int64_t cap);
 /* "" (undecided), "10x" or "stLFR": the header mode the file latched (count_tnf.cpp:27-32) */
 const char *pg_reads_mode(const pg_reads *r);
 /* Surviving rows: runs with a non-empty barcode and more than min_len characters

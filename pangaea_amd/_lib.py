@@ -94,6 +94,7 @@ def load() -> C.CDLL:
         "pg_reads_lowq": (vp, [vp]),
         "pg_reads_run_off": (vp, [vp]),
         "pg_reads_run_name": (cp, [vp, i64]),
+        "pg_reads_run_names": (i64, [vp, C.c_char_p, i64]),
         "pg_reads_mode": (cp, [vp]),
         "pg_reads_rows": (i64, [vp, i32, vp]),
         "pg_words_for": (i64, [i64]),
@@ -153,7 +154,7 @@ def load() -> C.CDLL:
 EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_fastq_count_newlines", "pg_ingest_fastq_shard", "pg_ingest_staging_words", "pg_ingest_fastq_device", "pg_ingest_place",
            "pg_set_ingest_threads", "pg_reads_free", "pg_reads_n_chars",
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
-           "pg_reads_valid", "pg_reads_lower", "pg_reads_lowq", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
+           "pg_reads_valid", "pg_reads_lower", "pg_reads_lowq", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_run_names", "pg_reads_mode", "pg_reads_rows", "pg_words_for",
            "pg_pack_ascii", "pg_pack_ascii_lower", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_distinct_sketch", "pg_kmer_count_workspace_bytes",
            "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed", "pg_kmer_rebuild_bucketed", "pg_kmer_rebuild_bucketed_range", "pg_table_bucket_fill", "pg_kmer_count_deferred", "pg_deferred_gather", "pg_deferred_gather_planes", "pg_kmer_rebuild_planes_range", "pg_table_bucket_fill_range", "pg_table_compact_planes_range", "pg_table_compact", "pg_kmer_merge_wide", "pg_abundance_workspace_bytes",
            "pg_abundance_from_records", "pg_abundance_from_emitted", "pg_kmer_count_bucketed_emit",

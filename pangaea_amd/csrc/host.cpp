@@ -1599,6 +1599,18 @@ extern "C" const char *pg_reads_run_name(const pg_reads *r, int64_t i)
     if (i < 0 || i >= (int64_t)r->run_name.size()) return "";
     return r->run_name[(size_t)i].c_str();
 }
+// all run names in one call (51 k ctypes calls for the names of a 10 M-pair file took 25 ms): the names, each followed by a
+// NUL, into out[0 .. cap); returns the bytes that takes (call with cap = 0 to size the buffer)
+extern "C" int64_t pg_reads_run_names(const pg_reads *r, char *out, int64_t cap)
+{
+    int64_t need = 0;
+    for (const std::string &n : r->run_name) need += (int64_t)n.size() + 1;
+    if (out && cap >= need) {
+        char *q = out;
+        for (const std::string &n : r->run_name) { memcpy(q, n.data(), n.size()); q += n.size(); *q++ = 0; }
+    }
+    return need;
+}
 extern "C" const char *pg_reads_mode(const pg_reads *r)
 {
     return r->mode == MODE_10X ? "10x" : r->mode == MODE_STLFR ? "stLFR" : "";

@@ -177,11 +177,21 @@ class ReadStream:
             lower_ptr = L.pg_reads_lower(h)
             lower = torch.from_numpy(np.ctypeslib.as_array(C.cast(lower_ptr, C.POINTER(C.c_int32)), shape=(nw,)).copy()).to(device) if lower_ptr else None
             run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
-            names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
+            names = cls._run_names(L, h, nr)
             out = cls(codes, valid, int(L.pg_reads_n_chars(h)), run_off, names, int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)),
                       L.pg_reads_mode(h).decode(), valid_lower=lower)
             del owner
         return out
+
+    @staticmethod
+    def _run_names(L, h, nr: int) -> list:
+        """the run names of a handle, fetched in one call"""
+        need = int(L.pg_reads_run_names(h, None, 0))
+        buf = C.create_string_buffer(max(1, need))
+        L.pg_reads_run_names(h, buf, need)
+        names = buf.raw[:need].decode().split("\0")[:-1] if need else []
+        assert len(names) == nr
+        return names
 
     @classmethod
     def _from_handle(cls, L, h) -> "ReadStream":
@@ -195,7 +205,7 @@ class ReadStream:
         lowq_ptr = L.pg_reads_lowq(h)
         lowq = torch.from_numpy(np.ctypeslib.as_array(C.cast(lowq_ptr, C.POINTER(C.c_int32)), shape=(nw,))) if lowq_ptr else None
         run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
-        names = [L.pg_reads_run_name(h, i).decode() for i in range(nr)]
+        names = cls._run_names(L, h, nr)
         out = cls(torch.from_numpy(codes), torch.from_numpy(valid), int(L.pg_reads_n_chars(h)), run_off, names,
                   int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)), L.pg_reads_mode(h).decode(), _owner=owner,
                   valid_lower=lower, valid_lowq=lowq)
