@@ -1082,6 +1082,10 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         }
         lds_sync();                                              // (the stage is free again: the next round's wavefronts may append)
         PG_MLAP(1);                                              // (ranks, cursor adds, scan, placement)
+        // (not unrolled: the three iterations a full stage takes would each keep their own four 64-bit store bases -- wout + position
+        // -- alive across the whole round loop: 24 vector registers, some of them spilled and reloaded in front of the stores with
+        // a wait for every store in flight)
+#pragma unroll 1
         for (uint32_t i0 = 0; i0 < n_valid; i0 += 4 * BLK) {
             uint32_t r[4];
             unsigned long long g[4];
