@@ -1114,8 +1114,8 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 // the other ranks hold occurrences of the same k-mers --, so instead of the slice and the lookups the bucket leaves
 //   * its occupied slots (code << 22 | count) in slot order, compacted, in its slab of `ent` (the entries that travel to the
 //     bucket's owner: pg_mini_gather_entries), their number in `fill`, and WHICH slots they are as a bitmap in `occ`;
-//   * what the lookup half needs to find the bucket's provisional words again: where they start (`wbeg`) and how many of them
-//     the general insert wrote from the end of the range (`ring_cnt`).
+//   * what the lookup half needs to find the bucket's provisional words (merged form: slots) again: where they start (`wbeg`)
+//     (`ring_cnt`: the singles of the merged form's first layout; always 0 since the general insert writes into fixed places).
 // mini_lookup_half_kernel finishes the bucket once the owner has answered with the bins of exactly these entries, in order.
 struct HalfArgs {
     unsigned long long *ent;                                     // bucket b: entries from b << log2 bucket slots
