@@ -293,9 +293,10 @@ class ReadStream:
 
     def rows(self, min_len: int) -> Rows:
         lens = np.diff(self.run_off)
-        keep = np.array([bool(n) for n in self.run_names], dtype=bool) & (lens > int(min_len))
-        idx = np.nonzero(keep)[0].astype(np.int64)
-        return Rows(idx, [self.run_names[i] for i in idx], self.run_off[idx].copy(), self.run_off[idx + 1].copy())
+        named = np.fromiter(map(len, self.run_names), dtype=np.int64, count=len(self.run_names)) > 0
+        idx = np.nonzero(named & (lens > int(min_len)))[0].astype(np.int64)
+        names = list(map(self.run_names.__getitem__, idx.tolist()))
+        return Rows(idx, names, self.run_off[idx].copy(), self.run_off[idx + 1].copy())
 
     # ------------------------------------------------------------------ host decode (tests / FASTQ export)
 
