@@ -1310,7 +1310,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 const uint64_t fw = FW << ((rc_sh0 - 2 * j) & 63), rc = RC << (2 * j);        // (j beyond the cap: no such k-mer, any value will do)
                 code[j] = (fw < rc ? fw : rc) >> rc_sh0;
                 sl[j] = mini_slot_hash<WIDE>(code[j]) & smask;
+#if PG_DIAG_LDS + 0 == 2                                         // (diagnostic, WRONG results: the count loop without its LDS probes)
+                cur[j] = (unsigned long long)sl[j] << 40;
+#else
                 cur[j] = tab[sl[j]];
+#endif
             }
             // (ballots of single comparisons, combined as scalars: the ballot of a compound predicate is compiled as
             // v_cndmask + v_cmp on top of the scalar logic)
@@ -1328,8 +1332,10 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     hit = act & __builtin_amdgcn_ballot_w64(cur[j] != 0) & __builtin_amdgcn_ballot_w64((cur[j] >> HASH_CBITS) == code[j]);
                     // (the count sits in the low 22 bits of the slot's low dword and stops far below 2^22: a 32-bit LDS add is enough)
                     const unsigned long long room = __builtin_amdgcn_ballot_w64(((uint32_t)cur[j] & HASH_SAT) == 0);
+#if PG_DIAG_LDS + 0 == 0                                         // (1, 2: diagnostic, WRONG results: without the adds)
                     __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(&tab[sl[j]]), __builtin_amdgcn_inverse_ballot_w64(hit & room) ? 1u : 0u,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                 }
                 pm[j] = hit & in_row_m;
                 qm[j] = act & ~hit;
