@@ -1491,6 +1491,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // 0 = slot never filled, 0xffff = bin out of range, else bin + 1.  (Every lane first reads all its slots -- the bins
         // land on top of the first quarter of the table.)
         uint16_t mybin[16];
+        const float rcp_window = 1.0f / (float)window;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const uint32_t i = q * BLK + threadIdx.x;
@@ -1507,7 +1508,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     if (c > HASH_SAT) c = HASH_SAT;
                     slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
                 }
-                const uint32_t bin = c / window;
+                const uint32_t bin = div_uniform(c, window, rcp_window);
                 mybin[q] = (uint16_t)(v ? (bin < vsize ? bin + 1u : 0xffffu) : 0u);
             }
         }
@@ -1547,6 +1548,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         return;
     }
     // the packed slice (an empty table needs no clearing: every slot is written); then counts -> bins, in place
+    const float rcp_window_g = window ? 1.0f / (float)window : 0.0f;
     for (uint32_t i = threadIdx.x; i < n_slots; i += BLK) {
         const unsigned long long v = tab[i];
         if (WIDE) {
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             slice[i] = v;
             slice_counts[i] = c;
             if (window && v) {
-                const uint32_t bin = c / window;
+                const uint32_t bin = div_uniform(c, window, rcp_window_g);
                 cnts[i] = bin < vsize ? bin + 1u : BIN_NONE;
             }
             continue;
@@ -1563,7 +1565,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (c > HASH_SAT) c = HASH_SAT;
         slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
         if (window && v) {
-            const uint32_t bin = c / window;
+            const uint32_t bin = div_uniform(c, window, rcp_window_g);
             tab[i] = (v & ~(unsigned long long)HASH_CMASK) | (bin < vsize ? bin + 1u : BIN_NONE);
         }
     }
@@ -1749,6 +1751,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_merge_bins_kernel(const unsign
     __syncthreads();
     uint64_t *slice = t.slots + ((uint64_t)(bucket0 + blockIdx.x) << t.log2_bucket);
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+    const float rcp_window = 1.0f / (float)window;
     for (int p = 0; p < n_parts; ++p) {
         const long long a = seg[(long long)p * (n_owned + 1) + blockIdx.x], b = seg[(long long)p * (n_owned + 1) + blockIdx.x + 1];
         for (long long e = a + threadIdx.x; e < b; e += BIG_BLOCK) {
@@ -1759,7 +1762,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_merge_bins_kernel(const unsign
                 const unsigned long long cur = tab[s];
                 if (cur == 0ull) break;
                 if ((cur >> HASH_CBITS) == code) {
-                    const uint32_t bin = (uint32_t)(cur & HASH_CMASK) / window;
+                    const uint32_t bin = div_uniform((uint32_t)(cur & HASH_CMASK), window, rcp_window);
                     out = bin < vsize ? bin + 1u : 0xffffu;
                     break;
                 }
