@@ -1162,6 +1162,12 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     // [r0, rs) short records (at most SHORT_MAX k-mers; the second scatter pass put them first), [rs, r1) the others
     const int64_t rs = n_short && CAP > SHORT_MAX ? r0 + (int64_t)n_short[blockIdx.x] : r0;
     const bool emit_slots = SLOTS && window != 0;
+    // every lane's first record of both classes, requested before anything else: with one workgroup per CU nothing hides a bucket's
+    // start (bounds -> table cleared -> range claimed -> barrier -> first records -> first probes), so the records' round trip
+    // runs under the clearing of the table and the claim
+    const int64_t i_s = r0 + (int64_t)wave * 64 + lane, i_l = rs + (int64_t)wave * 64 + lane;
+    const uint64_t first_s = i_s < rs ? bases[i_s] : 0ull, first_l = i_l < r1 ? bases[i_l] : 0ull;
+    const uint32_t first_ms = i_s < rs ? meta[i_s] : 0xffffffffu, first_ml = i_l < r1 ? meta[i_l] : 0xffffffffu;
 #ifdef PG_MINI_STAMPS
     unsigned long long *dbg = word_cursor + 7;                   // header[8..]: phase cycle sums (diagnostic build only)
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -1271,11 +1277,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         }
     };
     // ---- count: wavefront w takes the batches [ra + 64 (w + 16 t), + 64) of a class; CX = k-mers per record at most there
-    auto count_range = [&](auto cx, int64_t ra, int64_t rb) {
+    auto count_range = [&](auto cx, int64_t ra, int64_t rb, uint64_t R, uint32_t m) {       // (R, m: the lane's first record of the range, loaded at the top of the kernel)
         constexpr int CX = decltype(cx)::value;
         int64_t i = ra + (int64_t)wave * 64 + lane;
-        uint64_t R = i < rb ? bases[i] : 0ull;
-        uint32_t m = i < rb ? meta[i] : 0xffffffffu;
         for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BLK) {
             PG_WLAP(0);                                          // (loop top: the record has arrived, last batch's stores are out)
             const bool live = i0 + lane < rb;
@@ -1409,8 +1413,10 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #ifndef PG_SHORT_CX
 #define PG_SHORT_CX SHORT_MAX
 #endif
-    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs);       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
-    count_range(std::integral_constant<int, CAP>{}, rs, r1);
+#if PG_DIAG_BARE + 0 == 0                                        // (1, 2: diagnostic, WRONG results: a bucket's fixed costs -- no records / no slice either)
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms);       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
+    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml);
+#endif
     if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
 #ifdef PG_MINI_STAMPS
     if (lane == 0) {
@@ -1506,7 +1512,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 } else {
                     c = (uint32_t)(v & HASH_CMASK);
                     if (c > HASH_SAT) c = HASH_SAT;
+#if PG_DIAG_BARE + 0 != 2
                     slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
+#endif
                 }
                 const uint32_t bin = div_uniform(c, window, rcp_window);
                 mybin[q] = (uint16_t)(v ? (bin < vsize ? bin + 1u : 0xffffu) : 0u);
