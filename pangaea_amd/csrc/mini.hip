@@ -852,7 +852,7 @@ struct MergeCtx {
 #endif
 template <int BLK, int DIG> struct MergeLds {
     static constexpr int WPL = (BLK == 1024 && DIG == 1024) ? PG_MERGE_WPL : (PG_MERGE_WPL < 10 ? PG_MERGE_WPL : 10);   // (144 KiB with 1024 threads, 72 KiB with 512: two workgroups per CU)
-    static constexpr uint32_t TILE = WPL * BLK;
+    static constexpr uint32_t TILE = WPL * BLK;                          // (>= 64 x 9 words per wavefront: what the wavefronts carry over from a full stage fits an empty one)
     static constexpr uint32_t BUF = BLK == 1024 ? 32 * 1024 : 16 * 1024;        // (the 2-byte bins of the table's slots lie in front)
     static constexpr uint32_t BUF1 = BUF + 4 * TILE;
     static constexpr uint32_t CNT = BUF1 + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
@@ -1005,49 +1005,57 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     uint32_t step = wave;                                        // this wavefront's next step
     bool pending = false;                                        // pw[] holds words that did not fit the stage yet (wave-uniform)
     uint32_t pw[KS];                                             // the words of the step in hand
-    uint32_t cw[NL];                                             // what `step` loaded, in flight or here (not kept across stage B)
+    // the words of pw[] -> the stage; false (and nothing written) when they do not fit this round any more
+    auto append = [&]() -> bool {
+        // (the ballots are taken once and the lanes picked from the scalar masks: a predicate that crosses the branches below
+        // would be re-materialised per use as v_cndmask + v_cmp)
+        unsigned long long hm[KS];
+        uint32_t n = 0;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { hm[j] = __builtin_amdgcn_ballot_w64(pw[j] != NONE); n += (uint32_t)__popcll(hm[j]); }
+        if (n == 0) return true;                                 // (uniform)
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&staged, n);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at + n > FL::TILE) {                                 // the stage is full: this step's words wait for the next round
+            if (lane == 0) atomicMin(&valid_end, at);
+            return false;
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            if (hm[j] == 0ull) continue;                         // (uniform)
+            if (__builtin_amdgcn_inverse_ballot_w64(hm[j])) buf[at + lanes_below(hm[j])] = pw[j];
+            at += (uint32_t)__popcll(hm[j]);
+        }
+        return true;
+    };
+    // one step: its loads are in `mine`; the next step's go out into `next` first, then the step is worked on and appended.
+    // 0: done, 1: no step left, 2: the stage is full (the step's words stay in pw[])
+    auto one_step = [&](uint32_t (&mine)[NL], uint32_t (&next)[NL]) -> int {
+        if (step >= n_steps) return 1;                           // (uniform)
+        const StepGeo g = geometry(step);
+        step += WAVES_B;
+        // (scheduling barriers: the compiler must neither sink these requests below the work on the step in hand nor pull
+        // that work -- and with it the wait for what was just requested -- up in front of them)
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_rows(geometry(step < n_steps ? step : 0u), next);  // the next step's loads: in flight while this one is worked on
+        __builtin_amdgcn_sched_barrier(0);
+        process(g, mine, pw);
+        return append() ? 0 : 2;
+    };
     lds_sync();
     for (;;) {
-        // the loads of `step`: at the start, and again behind every stage B, which had the registers
-        fetch_rows(geometry(step < n_steps ? step : 0u), cw);
-        // ---- A
-        for (;;) {
-            if (!pending) {
-                if (step >= n_steps) break;                      // (uniform)
-                const StepGeo g = geometry(step);
-                uint32_t raw[NL];
-#pragma unroll
-                for (int i = 0; i < NL; ++i) raw[i] = cw[i];
-                step += WAVES_B;
-                // (scheduling barriers: the compiler must neither sink these requests below the work on the step in hand nor pull
-                // that work -- and with it the wait for what was just requested -- up in front of them)
-                __builtin_amdgcn_sched_barrier(0);
-                fetch_rows(geometry(step < n_steps ? step : 0u), cw);      // the next step's loads: in flight while this one is worked on
-                __builtin_amdgcn_sched_barrier(0);
-                process(g, raw, pw);
-                pending = true;
+        // ---- A.  (What a full stage left in pw[] goes first: the stage is empty now.  The loads of `step` are requested again
+        // behind every stage B, which had the registers; the two buffers swap roles from step to step: no copies)
+        if (pending) pending = !append();                        // (a step's words always fit an empty stage: 64 KS words per wavefront)
+        if (!pending) {
+            uint32_t ca[NL], cb[NL];
+            fetch_rows(geometry(step < n_steps ? step : 0u), ca);
+            for (;;) {
+                int r = one_step(ca, cb);
+                if (r == 0) r = one_step(cb, ca);
+                if (r) { pending = r == 2; break; }
             }
-            // (the ballots are taken once and the lanes picked from the scalar masks: a predicate that crosses the branches below
-            // would be re-materialised per use as v_cndmask + v_cmp)
-            unsigned long long hm[KS];
-            uint32_t n = 0;
-#pragma unroll
-            for (int j = 0; j < KS; ++j) { hm[j] = __builtin_amdgcn_ballot_w64(pw[j] != NONE); n += (uint32_t)__popcll(hm[j]); }
-            if (n == 0) { pending = false; continue; }           // (uniform)
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(&staged, n);
-            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-            if (at + n > FL::TILE) {                             // the stage is full: this step's words wait for the next round
-                if (lane == 0) atomicMin(&valid_end, at);
-                break;
-            }
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                if (hm[j] == 0ull) continue;                     // (uniform)
-                if (__builtin_amdgcn_inverse_ballot_w64(hm[j])) buf[at + lanes_below(hm[j])] = pw[j];
-                at += (uint32_t)__popcll(hm[j]);
-            }
-            pending = false;
         }
         if (lane == 0 && (pending || step < n_steps)) atomicOr(&busy, 1u);
 #pragma unroll
