@@ -980,7 +980,7 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
             const uint32_t cur = w[i];
             const bool rec_start = i == 0 || (i == CXS && g.is_short);
             const bool same = !rec_start && cur == w[i > 0 ? i - 1 : 0];
-            w[i] = same || cur == NONE ? NONE : (run << MERGE_CSHIFT) | cur;
+            w[i] = same ? NONE : (run << MERGE_CSHIFT) | cur;     // (an absent slot stays absent: NONE is all ones)
             run = same ? run + 1u : 0u;
         }
     };
