@@ -1064,6 +1064,13 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         PG_MLAP(0);                                              // (stage A)
         const uint32_t n_valid = staged < valid_end ? staged : valid_end;
         const bool more = busy != 0u;
+#if PG_DIAG_MERGE + 0 == 1                                       // (diagnostic, WRONG results: the lookup phase without its sort rounds and copy-out)
+        lds_sync();
+        if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }
+        lds_sync();
+        if (!more) break;
+        continue;
+#endif
         // ---- B: the staged words [0, n_valid), WPL per lane: rank, scan, place into the second buffer, copy out
         uint32_t rk[WPL];
         {
