@@ -844,18 +844,18 @@ struct MergeCtx {
     unsigned long long *dbg;                                     // PG_MINI_STAMPS builds: cycle sums of the phases (diagnostic)
 };
 
-// LDS of the MERGE form's lookup phase: the 2-byte bins in front, then TWO buffers of WPL words per lane -- the stage the
-// wavefronts append their run words to, and the buffer the stage is sorted INTO (no word has to sit in a register across the
-// scan: the sort reads the stage twice instead)
+// LDS of the MERGE form's lookup phase: the 2-byte bins in front, then the stage the wavefronts append their run words to --
+// WPL words per lane, sorted IN PLACE: every lane keeps its WPL words and their places in registers across the scan (the first
+// layouts of round 3 sorted into a second buffer of the same size instead, i.e. half the stage and twice the sort rounds per
+// bucket: the kernel of those days had no registers to spare)
 #ifndef PG_MERGE_WPL
-#define PG_MERGE_WPL 12
+#define PG_MERGE_WPL 24
 #endif
 template <int BLK, int DIG> struct MergeLds {
-    static constexpr int WPL = (BLK == 1024 && DIG == 1024) ? PG_MERGE_WPL : (PG_MERGE_WPL < 10 ? PG_MERGE_WPL : 10);   // (144 KiB with 1024 threads, 72 KiB with 512: two workgroups per CU)
+    static constexpr int WPL = (BLK == 1024 && DIG == 1024) ? PG_MERGE_WPL : (PG_MERGE_WPL < 20 ? PG_MERGE_WPL : 20);   // (144 KiB with 1024 threads, 72 KiB with 512: two workgroups per CU)
     static constexpr uint32_t TILE = WPL * BLK;                          // (>= 64 x 9 words per wavefront: what the wavefronts carry over from a full stage fits an empty one)
     static constexpr uint32_t BUF = BLK == 1024 ? 32 * 1024 : 16 * 1024;        // (the 2-byte bins of the table's slots lie in front)
-    static constexpr uint32_t BUF1 = BUF + 4 * TILE;
-    static constexpr uint32_t CNT = BUF1 + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
+    static constexpr uint32_t CNT = BUF + 4 * TILE, START = CNT + 4 * DIG, GBASE = START + 4 * (DIG + 8), WAVE = GBASE + 8 * DIG, END = WAVE + 64;
 };
 // a step of the lookup phase: two batches of short records or one batch of long ones per wavefront (a table whose records are
 // not sorted into classes -- caps of at most PG_SHORT_MAX k-mers -- has short records only); KS k-mers per lane, NL loads per
@@ -889,7 +889,7 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
     constexpr uint32_t NONE = WORD_NONE;
     __shared__ uint32_t staged, valid_end, busy;
     const uint16_t *bins16 = reinterpret_cast<const uint16_t *>(c.lds);
-    uint32_t *buf = reinterpret_cast<uint32_t *>(c.lds + FL::BUF), *sorted = reinterpret_cast<uint32_t *>(c.lds + FL::BUF1), *cnt = reinterpret_cast<uint32_t *>(c.lds + FL::CNT);
+    uint32_t *buf = reinterpret_cast<uint32_t *>(c.lds + FL::BUF), *cnt = reinterpret_cast<uint32_t *>(c.lds + FL::CNT);
     uint32_t *start = reinterpret_cast<uint32_t *>(c.lds + FL::START), *wave_tot = reinterpret_cast<uint32_t *>(c.lds + FL::WAVE);
     unsigned long long *gbase = reinterpret_cast<unsigned long long *>(c.lds + FL::GBASE);
     const ShufArgs &sh = c.sh;
@@ -1071,32 +1071,30 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         if (!more) break;
         continue;
 #endif
-        // ---- B: the staged words [0, n_valid), WPL per lane: rank, scan, place into the second buffer, copy out
-        uint32_t rk[WPL];
-        {
-            uint32_t w[WPL];
-#pragma unroll
-            for (int j = 0; j < WPL; ++j) w[j] = buf[j * BLK + threadIdx.x];
-#pragma unroll
-            for (int j = 0; j < WPL; ++j) {
-                const uint32_t i = j * BLK + threadIdx.x;
-                rk[j] = __hip_atomic_fetch_add(&cnt[(w[j] >> sh.dshift) & dmask], i < n_valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        lds_sync();
-        if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }     // (everybody has read them: a barrier lies in between)
-        claim_and_scan();
+        // ---- B: the staged words [0, n_valid), WPL per lane (as many of them as the round has: uniform tests): rank, scan, place
+        // -- in place: every word is in its lane's registers before the first barrier --, copy out
         {
             uint32_t w[WPL], at[WPL];
 #pragma unroll
-            for (int j = 0; j < WPL; ++j) w[j] = buf[j * BLK + threadIdx.x];
+            for (int j = 0; j < WPL; ++j) w[j] = (uint32_t)(j * BLK) < n_valid ? buf[j * BLK + threadIdx.x] : 0u;
 #pragma unroll
-            for (int j = 0; j < WPL; ++j) at[j] = start[(w[j] >> sh.dshift) & dmask] + rk[j];
+            for (int j = 0; j < WPL; ++j) {
+                const uint32_t i = j * BLK + threadIdx.x;
+                at[j] = 0;
+                if ((uint32_t)(j * BLK) < n_valid)                  // (uniform)
+                    at[j] = __hip_atomic_fetch_add(&cnt[(w[j] >> sh.dshift) & dmask], i < n_valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            lds_sync();
+            if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }     // (everybody has read them: a barrier lies in between)
+            claim_and_scan();
 #pragma unroll
             for (int j = 0; j < WPL; ++j)
-                if ((uint32_t)(j * BLK) + threadIdx.x < n_valid) sorted[at[j]] = w[j];
+                if ((uint32_t)(j * BLK) < n_valid) at[j] += start[(w[j] >> sh.dshift) & dmask];
+#pragma unroll
+            for (int j = 0; j < WPL; ++j)
+                if ((uint32_t)(j * BLK) + threadIdx.x < n_valid) buf[at[j]] = w[j];
         }
-        lds_sync();                                              // (the stage is free again: the next round's wavefronts may append)
+        lds_sync();
         PG_MLAP(1);                                              // (ranks, cursor adds, scan, placement)
         // (not unrolled: the three iterations a full stage takes would each keep their own four 64-bit store bases -- wout + position
         // -- alive across the whole round loop: 24 vector registers, some of them spilled and reloaded in front of the stores with
@@ -1108,7 +1106,7 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = i0 + u * BLK + threadIdx.x;
-                r[u] = sorted[i < FL::TILE ? i : 0u];
+                r[u] = buf[i < FL::TILE ? i : 0u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BLK + threadIdx.x;
@@ -1120,9 +1118,8 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         if (threadIdx.x == 0) { atomicAdd(&c.dbg[48 + 6], 1ull); atomicAdd(&c.dbg[48 + 7], (unsigned long long)n_valid); }
 #endif
         PG_MLAP(2);                                              // (copy-out)
-        // (no barrier here: the next round appends to the stage, sorts into `sorted` only behind two more barriers, and gbase /
-        // start are rewritten behind the same)
         if (!more) break;                                        // (uniform)
+        lds_sync();                                              // (the stage is free again: the next round's wavefronts may append)
     }
 }
 
