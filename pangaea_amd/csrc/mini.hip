@@ -1282,7 +1282,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             const unsigned long long qm = __ballot(put);
             if (MERGE) {
                 // (the ring carried the k-mer's own place among the bucket's halfwords instead of its row)
+#if PG_DIAG_NOSTORE + 0 < 2
                 if (put) gstore(prov_h, (uint64_t)rw, (uint64_t)np_half, (uint16_t)(sl == 0xffffffffu ? 0xffffu : sl & smask), status);
+#endif
             } else
             if (qm) {                                            // (uniform)
                 {
@@ -1315,8 +1317,13 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 const uint32_t arrived = (uint32_t)FW;
                 asm volatile("" : "+v"(i) : "v"(arrived));
             }
+#ifdef PG_DIAG_NOLOAD                                            // (diagnostic, WRONG results: the count loop on made-up records)
+            R = i < rb ? (uint64_t)i * 0x9E3779B97F4A7C15ull : 0ull;
+            m = i < rb ? ((uint32_t)i * 2654435761u & 0xfffff87fu) | (6u << 7) : 0xffffffffu;
+#else
             R = i < rb ? bases[i] : 0ull;
             m = i < rb ? meta[i] : 0xffffffffu;
+#endif
             // Straight-line code from here to the ballots: the reads and the adds go out for every lane (a lane without a j-th k-mer
             // reads some slot and adds 0 to it), so that no predicate crosses a branch -- a predicate that does comes back as
             // v_cndmask + v_cmp per use, and the branches around each predicated add cost more than the add
@@ -1408,7 +1415,14 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     // first probe did not settle gets its slot from the general insert, one outside every row gets none
 #pragma unroll
                     for (int j = 0; j < CX; ++j)
-                        if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) gstore(prov_h, (uint64_t)place0 + 64u * j, (uint64_t)np_half, (uint16_t)sl[j], status);
+#if PG_DIAG_NOSTORE + 0 == 3                                     // (3: no store instruction in the count loop at all)
+                        if (false)
+#elif PG_DIAG_NOSTORE + 0 >= 1                                   // (diagnostic, WRONG results: without the slot stores of the first probes; 2: nor those of the general insert)
+                        if (__builtin_amdgcn_inverse_ballot_w64(pm[j]) && sl[j] == 0xffffffffu)
+#else
+                        if (__builtin_amdgcn_inverse_ballot_w64(pm[j]))
+#endif
+                            gstore(prov_h, (uint64_t)place0 + 64u * j, (uint64_t)np_half, (uint16_t)sl[j], status);
                 } else
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
                 // shuffle do not like runs of equal words).  (Deferring these stores to the next iteration's top, behind its
@@ -1550,7 +1564,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // final words never make a trip of their own through HBM
         unsigned char *lds = reinterpret_cast<unsigned char *>(tab);
         const uint32_t np = (uint32_t)n_lookups;
-#if PG_DIAG_BARE + 0 == 4                                        // (diagnostic: a bucket's fixed costs without the lookup phase)
+#if PG_DIAG_BARE + 0 == 4 || defined(PG_DIAG_NOLOOKUP)           // (diagnostic: without the lookup phase -- BARE = 4: a bucket's fixed costs)
         return;
 #endif
         if (MERGE) {
