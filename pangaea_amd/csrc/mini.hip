@@ -1295,8 +1295,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         }
     };
     // ---- count: wavefront w takes the batches [ra + 64 (w + 16 t), + 64) of a class; CX = k-mers per record at most there
-    auto count_range = [&](auto cx, int64_t ra, int64_t rb, uint64_t R, uint32_t m) {       // (R, m: the lane's first record of the range, loaded at the top of the kernel)
+    auto count_range = [&](auto cx, int64_t ra, int64_t rb, uint64_t R, uint32_t m, auto with_ring) {       // (R, m: the lane's first record of the range, loaded at the top of the kernel)
         constexpr int CX = decltype(cx)::value;
+        constexpr bool RING_ = decltype(with_ring)::value;       // (false: a diagnostic pass compiled without the ring's code)
         int64_t i = ra + (int64_t)wave * 64 + lane;
         for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BLK) {
             PG_WLAP(0);                                          // (loop top: the record has arrived, last batch's stores are out)
@@ -1381,7 +1382,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #if PG_DIAG_NORING + 0 == 1                                      // (diagnostic, WRONG results: nothing but the first probes -- what do the ring and the general insert cost?)
                 const unsigned long long mask = 0ull & qm[j];
 #else
-                const unsigned long long mask = qm[j];
+                const unsigned long long mask = RING_ ? qm[j] : 0ull;
 #endif
                 if (mask) {                                      // (uniform)
                     if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
@@ -1444,8 +1445,12 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #define PG_SHORT_CX SHORT_MAX
 #endif
 #if PG_DIAG_BARE + 0 == 0                                        // (1, 2: diagnostic, WRONG results: a bucket's fixed costs -- no records / no slice either)
-    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms);       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
-    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml);
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::true_type{});       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
+    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::true_type{});
+#ifdef PG_DIAG_TWICE                                             // (diagnostic, WRONG results: a second pass over the bucket's records, in which every first probe hits; 2: ... compiled without the ring's code)
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::integral_constant<bool, PG_DIAG_TWICE + 0 != 2>{});
+    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::integral_constant<bool, PG_DIAG_TWICE + 0 != 2>{});
+#endif
 #endif
     if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
 #ifdef PG_MINI_STAMPS
