@@ -606,9 +606,11 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 // instructions on mask bookkeeping, and those -- not the LDS -- were the cost of this path.
 // WIDE (k > 21): tab[] holds code + 1 (0 = empty) and the counts live in their own 32-bit plane cnts[].
 template <bool WIDE>
-__device__ __forceinline__ uint32_t mini_insert_slow(unsigned long long *tab, uint32_t *cnts, uint32_t smask, uint32_t limit, uint64_t code, bool act)
+__device__ __forceinline__ uint32_t mini_insert_slow(unsigned long long *tab, uint32_t *cnts, uint32_t smask, uint32_t limit, uint64_t code, bool act, uint32_t skip = 0u)
 {
-    uint32_t s = mini_slot_hash<WIDE>(code) & smask;
+    // (skip = 1: the first probe has seen the home slot taken by ANOTHER key -- nothing ever leaves a slot, so the search starts
+    // behind it: one dependent LDS round trip less for most of what comes off the ring)
+    uint32_t s = (mini_slot_hash<WIDE>(code) + skip) & smask;
     uint32_t res = act ? 0xffffffffu : 0u;
     bool todo = act;
     const unsigned long long fresh = WIDE ? (unsigned long long)(code + 1ull) : (unsigned long long)((code << HASH_CBITS) | 1ull);
@@ -1271,10 +1273,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     // one pending occurrence per lane off the ring: the general insert, and its word
     auto slow_round = [&](bool act) {
         const uint32_t at = (head + lane) & (RING - 1);
-        const uint64_t c = act ? ring[at] : 0ull;
+        const uint64_t c_ = act ? ring[at] : 0ull;
+        const uint64_t c = c_ & ~(1ull << 63);                   // (bit 63: the home slot was taken by another key when the first probe looked)
         constexpr uint32_t RING_NONE = MERGE ? 0xffffffffu : MINI_ROW_NONE;      // (MERGE: ring_row holds places, not rows)
         const uint32_t rw = act && emit_slots ? ring_row[at] : RING_NONE;
-        const uint32_t sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act);
+        const uint32_t sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
         full |= act && sl == 0xffffffffu;
         if (emit_slots) {
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
@@ -1387,7 +1390,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 if (mask) {                                      // (uniform)
                     if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
                         const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
-                        ring[at] = code[j];
+                        ring[at] = code[j] | (cur[j] != 0ull ? 1ull << 63 : 0ull);     // (a slot that is not empty and not a hit holds another key)
                         // (MERGE: the general insert writes the slot to the k-mer's own place: the ring carries that place)
                         if (emit_slots) ring_row[at] = MERGE ? (row != MINI_ROW_NONE ? place0 + 64u * j : 0xffffffffu) : row;
                     }
