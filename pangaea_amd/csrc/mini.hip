@@ -1268,6 +1268,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     const uint32_t np_all = (uint32_t)n_lookups;                 // (emit_slots: the bucket's words, known before the first is written)
     PG_STAMP(0);
     bool full = false;
+    bool twice_pass = false;                                     // (diagnostic builds: the second pass of PG_DIAG_TWICE is running)
+    (void)twice_pass;
     unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
     uint32_t head = 0, tail = 0;                                 // ring positions (wave-uniform)
     // one pending occurrence per lane off the ring: the general insert, and its word
@@ -1277,7 +1279,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         const uint64_t c = c_ & ~(1ull << 63);                   // (bit 63: the home slot was taken by another key when the first probe looked)
         constexpr uint32_t RING_NONE = MERGE ? 0xffffffffu : MINI_ROW_NONE;      // (MERGE: ring_row holds places, not rows)
         const uint32_t rw = act && emit_slots ? ring_row[at] : RING_NONE;
+#if PG_DIAG_TWICE + 0 == 4                                       // (diagnostic, WRONG results: rounds that read the ring and hash but do not probe -- second pass only makes sense)
+        const uint32_t sl = twice_pass ? (mini_slot_hash<WIDE>(c) + (uint32_t)(c_ >> 63)) & smask : mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
+#else
         const uint32_t sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
+#endif
         full |= act && sl == 0xffffffffu;
         if (emit_slots) {
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
@@ -1300,7 +1306,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     // ---- count: wavefront w takes the batches [ra + 64 (w + 16 t), + 64) of a class; CX = k-mers per record at most there
     auto count_range = [&](auto cx, int64_t ra, int64_t rb, uint64_t R, uint32_t m, auto with_ring) {       // (R, m: the lane's first record of the range, loaded at the top of the kernel)
         constexpr int CX = decltype(cx)::value;
-        constexpr bool RING_ = decltype(with_ring)::value;       // (false: a diagnostic pass compiled without the ring's code)
+        constexpr int RING_ = (int)decltype(with_ring)::value;  // (0: a diagnostic pass compiled without the ring's code; 2: pushes only; 3: pushes + rounds that do not probe)
         int64_t i = ra + (int64_t)wave * 64 + lane;
         for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BLK) {
             PG_WLAP(0);                                          // (loop top: the record has arrived, last batch's stores are out)
@@ -1399,7 +1405,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     if (tail - head >= 64) head += 64;
                     if (false) {
 #else
-                    if (tail - head >= 64) {
+                    if (RING_ == 2) { if (tail - head >= 64) head += 64; }
+                    if (RING_ != 2 && tail - head >= 64) {
 #endif
 #ifdef PG_MINI_STAMPS
                         const unsigned long long ts = __builtin_amdgcn_s_memtime();
@@ -1448,11 +1455,13 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #define PG_SHORT_CX SHORT_MAX
 #endif
 #if PG_DIAG_BARE + 0 == 0                                        // (1, 2: diagnostic, WRONG results: a bucket's fixed costs -- no records / no slice either)
-    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::true_type{});       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
-    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::true_type{});
-#ifdef PG_DIAG_TWICE                                             // (diagnostic, WRONG results: a second pass over the bucket's records, in which every first probe hits; 2: ... compiled without the ring's code)
-    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::integral_constant<bool, PG_DIAG_TWICE + 0 != 2>{});
-    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::integral_constant<bool, PG_DIAG_TWICE + 0 != 2>{});
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::integral_constant<int, 1>{});       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
+    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::integral_constant<int, 1>{});
+#ifdef PG_DIAG_TWICE                                             // (diagnostic, WRONG results: a second pass over the bucket's records -- every key is in the table; 2: compiled without the ring's code; 3: pushes only; 4: rounds that do not probe)
+    twice_pass = true;
+    constexpr int TW_ = PG_DIAG_TWICE + 0 == 2 ? 0 : PG_DIAG_TWICE + 0 == 3 ? 2 : 1;
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::integral_constant<int, TW_>{});
+    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::integral_constant<int, TW_>{});
 #endif
 #endif
     if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
