@@ -581,6 +581,7 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
 // occurrence -- it knows the slot when the insert is done -- and once the counts have become bins in place, the provisional
 // words are streamed back (they are fresh in L2 / MALL) and turned into (row, bin) words by ONE LDS read each: no second
 // derivation of the k-mers, no second probing.  General form: the records are read and probed a second time.
+constexpr uint32_t RING_NOPLACE = 0xffff0000u;              // (MERGE: a ring entry of a k-mer outside every row; places stay below it)
 constexpr int RING = 128;                                    // entries per wavefront ring: < 64 waiting + <= 64 pushed per step
 constexpr int COUNT_WAVES = BIG_BLOCK / 64;
 constexpr uint32_t BIN_NONE = (uint32_t)HASH_CMASK;          // a slot's count field after the counts have become bins: bin + 1, or this
@@ -1242,7 +1243,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // not written: bit 2 of the status word, as for the record buffers)
         const unsigned long long need = 32ull * (unsigned long long)((rs - r0 + 63) >> 6) * (CAP > SHORT_MAX ? SHORT_MAX : CAP)
                                         + 32ull * (unsigned long long)((r1 - rs + 63) >> 6) * CAP + (unsigned long long)MergeStep<CAP>::SLACK;
-        if (wbase + need > mg.cap) {                             // (uniform)
+        if (wbase + need > mg.cap || 2ull * need >= (unsigned long long)RING_NOPLACE) {      // (uniform; places are 32-bit halfword numbers below RING_NOPLACE)
             if (threadIdx.x == 0) atomicOr(status, PG_STATUS_PLAN_MISMATCH);
             return;
         }
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         const uint32_t at = (head + lane) & (RING - 1);
         const uint64_t c_ = act ? ring[at] : 0ull;
         const uint64_t c = c_ & ~(1ull << 63);                   // (bit 63: the home slot was taken by another key when the first probe looked)
-        constexpr uint32_t RING_NONE = MERGE ? 0xffffffffu : MINI_ROW_NONE;      // (MERGE: ring_row holds places, not rows)
+        constexpr uint32_t RING_NONE = MERGE ? 0xffffffffu : MINI_ROW_NONE;      // (MERGE: ring_row holds places, not rows; no place: anything from RING_NOPLACE on)
         const uint32_t rw = act && emit_slots ? ring_row[at] : RING_NONE;
 #if PG_DIAG_TWICE + 0 == 4                                       // (diagnostic, WRONG results: rounds that read the ring and hash but do not probe -- second pass only makes sense)
         const uint32_t sl = twice_pass ? (mini_slot_hash<WIDE>(c) + (uint32_t)(c_ >> 63)) & smask : mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
@@ -1287,7 +1288,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         full |= act && sl == 0xffffffffu;
         if (emit_slots) {
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
-            const bool put = rw != RING_NONE;
+            const bool put = MERGE ? rw < RING_NOPLACE : rw != RING_NONE;
             const unsigned long long qm = __ballot(put);
             if (MERGE) {
                 // (the ring carried the k-mer's own place among the bucket's halfwords instead of its row)
@@ -1316,6 +1317,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             const bool in_row = live && row != MINI_ROW_NONE;
             // (MERGE) the lane's first halfword in the bucket's range: k-mer j of its record has place0 + 64 j
             const uint32_t place0 = (CX < CAP ? 0u : long_base) + (uint32_t)((i0 - ra) >> 6) * (64u * CX) + lane;
+            // (what the ring carries for k-mer j is ring_place0 + 64 j: its place, or -- outside every row -- something at or beyond RING_NOPLACE)
+            const uint32_t ring_place0 = row != MINI_ROW_NONE ? place0 : RING_NOPLACE;
             if (in_row) mine += (unsigned long long)n;
             const uint64_t FW = rev2_64(R), RC = R ^ 0xAAAAAAAAAAAAAAAAull;
             i = i0 + BLK + lane;                           // the next batch's loads fly during this one
@@ -1398,7 +1401,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                         const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
                         ring[at] = code[j] | (cur[j] != 0ull ? 1ull << 63 : 0ull);     // (a slot that is not empty and not a hit holds another key)
                         // (MERGE: the general insert writes the slot to the k-mer's own place: the ring carries that place)
-                        if (emit_slots) ring_row[at] = MERGE ? (row != MINI_ROW_NONE ? place0 + 64u * j : 0xffffffffu) : row;
+                        if (emit_slots) ring_row[at] = MERGE ? ring_place0 + 64u * j : row;
                     }
                     tail += (uint32_t)__popcll(mask);
 #if PG_DIAG_NORING + 0 == 2                                      // (diagnostic, WRONG results: the pushes without the general insert)
