@@ -615,21 +615,30 @@ __device__ __forceinline__ uint32_t mini_insert_slow(unsigned long long *tab, ui
     uint32_t res = act ? 0xffffffffu : 0u;
     bool todo = act;
     const unsigned long long fresh = WIDE ? (unsigned long long)(code + 1ull) : (unsigned long long)((code << HASH_CBITS) | 1ull);
-    for (uint32_t i = 0; i < limit; ++i) {
-        if (!__any(todo)) break;
-        unsigned long long cur = tab[s];                        // (settled lanes read their last slot again: harmless)
-        if (todo && cur == 0) cur = atomicCAS(&tab[s], 0ull, fresh);
+    // one slot of the chain: claim it if it is empty, count on it if it holds the key; true when the lane is settled
+    auto visit = [&](uint32_t at, unsigned long long cur) {
+        if (todo && cur == 0) cur = atomicCAS(&tab[at], 0ull, fresh);
         const bool claimed = todo && cur == 0;
         if (WIDE) {
             const bool match = todo && cur == fresh;
-            if (claimed || match) { atomicAdd(&cnts[s], 1u); res = s; todo = false; }
+            if (claimed || match) { atomicAdd(&cnts[at], 1u); res = at; todo = false; }
         } else {
             const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
             // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
-            if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[s]), 1u);   // (the count is in the low dword)
-            if (claimed || match) { res = s; todo = false; }
+            if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[at]), 1u);   // (the count is in the low dword)
+            if (claimed || match) { res = at; todo = false; }
         }
-        s = todo ? (s + 1) & smask : s;
+    };
+    // TWO slots per turn, both reads in flight together: a turn is a dependent LDS round trip (two where a slot is claimed), and
+    // the round lasts as long as its longest chain.  The second slot is only visited by lanes whose first one holds another key
+    // (what was read from it may be stale by then: a claim goes through compare-and-swap, which answers with what is there).
+    for (uint32_t i = 0; i < limit; i += 2) {
+        if (!__any(todo)) break;
+        const uint32_t s1 = (s + 1) & smask;
+        const unsigned long long cur0 = tab[s], cur1 = tab[s1];  // (settled lanes read their last slots again: harmless)
+        visit(s, cur0);
+        visit(s1, cur1);
+        s = todo ? (s + 2) & smask : s;
     }
     return res;
 }
