@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 6   /* 6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
+#define PG_ABI_VERSION 7   /* 7: pg_build_flags (what kind of build a loaded library is);
+                              6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
                               5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
                               4: pg_mini_records_bytes takes the table, status bits;
                               3: PG_TABLE_MINI and the super-k-mer entry points; 2: packed hash slots keyed by pg_key42(code) */
@@ -51,6 +52,15 @@ typedef enum {
 } pg_status;
 
 int pg_abi_version(void);
+/* What kind of build this library is -- 0 for the product (libpangaea_feat.so as `make` builds it).  A loader refuses anything
+ * else unless it asked for it: a checked library is slower, a variant may compute WRONG results (timing experiments).
+ *   PG_BUILD_CHECKED  the super-k-mer kernels check every global store against its buffer's capacity (PG_STATUS_BOUNDS)
+ *   PG_BUILD_STAMPS   phase timers inside the bucket kernels (-DPG_MINI_STAMPS)
+ *   PG_BUILD_VARIANT  built with extra compiler flags (`make variant NAME=... KFLAGS=...`): not the product, whatever it does */
+#define PG_BUILD_CHECKED 1u
+#define PG_BUILD_STAMPS 2u
+#define PG_BUILD_VARIANT 4u
+uint32_t pg_build_flags(void);
 const char *pg_last_error(void);
 /* number of visible HIP devices, or a negative pg_status */
 int pg_device_count(void);

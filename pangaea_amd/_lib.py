@@ -10,9 +10,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PANGAEA_LIB=checked: the build whose super-k-mer kernels check every global store against the capacity of its buffer
-# (make -C pangaea_amd/csrc CHECKED=1; include/pangaea_feat.h: PG_STATUS_BOUNDS) -- slower, for tests of new kernel code
-LIB_PATH = os.path.join(_HERE, "libpangaea_feat_checked.so" if os.environ.get("PANGAEA_LIB", "") == "checked" else "libpangaea_feat.so")
+# Which library: libpangaea_feat.so, the product, unless PANGAEA_LIB says otherwise --
+#   PANGAEA_LIB=checked   the build whose super-k-mer kernels check every global store against the capacity of its buffer
+#                         (make -C pangaea_amd/csrc checked; include/pangaea_feat.h: PG_STATUS_BOUNDS): slower, tests of new kernel code
+#   PANGAEA_LIB=<path>    a variant (make -C pangaea_amd/csrc variant NAME=.. KFLAGS=..): timing experiments, phase stamps.  A variant
+#                         may compute wrong results, so load() refuses one (pg_build_flags() != 0) without PANGAEA_ALLOW_VARIANT=1.
+# Nothing ever has to be copied over the product library to try another build.
+_WANT = os.environ.get("PANGAEA_LIB", "")
+LIB_PATH = (os.path.join(_HERE, "libpangaea_feat.so") if not _WANT else os.path.join(_HERE, "libpangaea_feat_checked.so") if _WANT == "checked"
+            else os.path.abspath(_WANT))
+BUILD_CHECKED, BUILD_STAMPS, BUILD_VARIANT = 1, 2, 4
 STATUS_TABLE_FULL, STATUS_OVERFLOW_LIST, STATUS_PLAN_MISMATCH, STATUS_BOUNDS = 1, 2, 4, 8
 _LIB = None
 
@@ -25,7 +32,7 @@ HASH_COUNT_SAT = 1 << 21
 TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
-ABI_VERSION = 6
+ABI_VERSION = 7
 MINI_MIN_K, MINI_MAX_LOG2_BUCKETS, MINI_MAX_ROWS, MINI_WIDE_MAX_LOG2_BUCKET_SLOTS = 13, 16, (1 << 21) - 2, 13
 SHUFFLE_MAX_VSIZE = 512
 DEFERRED_MAX_GROUP_LOG2 = 3
@@ -73,6 +80,7 @@ def load() -> C.CDLL:
     rp = C.POINTER(pg_rows)
     sig = {
         "pg_abi_version": (i32, []),
+        "pg_build_flags": (C.c_uint32, []),
         "pg_last_error": (cp, []),
         "pg_device_count": (i32, []),
         "pg_ingest_fastq": (i32, [cp, cp, C.POINTER(vp)]),
@@ -147,11 +155,18 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if L.pg_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: ABI version {L.pg_abi_version()} != {ABI_VERSION}")
+    # the product is flags == 0; a checked library only when it was asked for by name; anything else (a timing experiment may
+    # compute wrong results) only with PANGAEA_ALLOW_VARIANT=1 -- whatever the file is called
+    flags = int(L.pg_build_flags())
+    allowed = BUILD_CHECKED if _WANT == "checked" else 0
+    if flags & ~allowed and os.environ.get("PANGAEA_ALLOW_VARIANT", "") != "1":
+        raise RuntimeError(f"{LIB_PATH}: pg_build_flags() = {flags} (1 checked, 2 stamps, 4 variant) -- not the product build; "
+                           "rebuild it (make -C pangaea_amd/csrc) or set PANGAEA_ALLOW_VARIANT=1 for an experiment")
     _LIB = L
     return L
 
 
-EXPORTS = ["pg_abi_version", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_fastq_count_newlines", "pg_ingest_fastq_shard", "pg_ingest_staging_words", "pg_ingest_fastq_device", "pg_ingest_place",
+EXPORTS = ["pg_abi_version", "pg_build_flags", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_fastq_count_newlines", "pg_ingest_fastq_shard", "pg_ingest_staging_words", "pg_ingest_fastq_device", "pg_ingest_place",
            "pg_set_ingest_threads", "pg_reads_free", "pg_reads_n_chars",
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
            "pg_reads_valid", "pg_reads_lower", "pg_reads_lowq", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_run_names", "pg_reads_mode", "pg_reads_rows", "pg_words_for",

@@ -424,11 +424,7 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 // last position that ends no valid k-mer, whichever is later; its k-mers share one row (that of its last character)
 #pragma unroll
                 for (int e = 0; e < 32; ++e) {
-#if PG_DIAG_A1 + 0 == 2                                          // (diagnostic, WRONG results: the first pass without placement and stores)
-                    if (((has & wmask) >> e & 1u) && dr[e] == 0xffffffffu) {
-#else
                     if ((has & wmask) >> e & 1u) {
-#endif
                         const uint32_t b = dr[e] >> 16, d = b >> bits2;
                         const uint32_t at = L.start[d] + (dr[e] & 0xffffu);
                         const uint32_t below = e ? ((has | ~lw.ok) & ((1u << e) - 1u)) : 0u;     // ends / non-k-mers before e
@@ -442,20 +438,12 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 }
             }
             lds_sync();
-#if PG_DIAG_A1 + 0 == 2
-            const uint32_t tot = 0;
-#else
             const uint32_t tot = L.start[N1];
-#endif
             for (uint32_t i = threadIdx.x; i < tot; i += S1_BLOCK) {
                 // (a record beyond the buffers is dropped: cannot happen with the plan of THIS stream -- the offsets are exact --,
                 // and the plan of another one is reported below)
                 const unsigned long long g = L.gbase[L.dig[i]] + i;
-#if PG_DIAG_A1 + 0 == 1                                          // (diagnostic, WRONG results: the first pass without its stores)
-                if (g == 0xffffffffffffffffull)
-#else
                 if (g < rec_cap)
-#endif
                 {
                     out_bases[g] = L.bases[i];
                     out_meta[g] = L.meta[i];
@@ -664,9 +652,6 @@ __device__ __forceinline__ uint32_t mini_lookup_slow(const unsigned long long *t
 #ifndef PG_SHORT_MAX
 #define PG_SHORT_MAX 4
 #endif
-#ifndef PG_DIAG_COUNT
-#define PG_DIAG_COUNT 0                  // diagnostic builds only (results are wrong): 1 = no word stores in the count loop, 2 = no lookup phase, 4 = no copy-out stores in the lookup phase
-#endif
 // where the SLOTS form scatters its (row, bin) words: straight into the row shuffle's group regions (pg_shuffle_ctx)
 struct ShufArgs {
     const unsigned long long *goff;
@@ -797,10 +782,6 @@ __device__ __forceinline__ void wordwise_lookup(const WordCtx &c)
             for (int u = 0; u < 4; ++u) r[u] = buf[i0 + u * BLK + threadIdx.x];            // (< FL::TILE: total <= FL::TILE = 16 blocks)
 #pragma unroll
             for (int u = 0; u < 4; ++u) g[u] = gbase[(r[u] >> sh.dshift) & dmask] + i0 + u * BLK + threadIdx.x;
-#if PG_DIAG_COUNT & 4
-            asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
-            continue;                                        // (diagnostic: everything but the copy-out's stores)
-#endif
             if (sh.narrow) {                                 // (the group region implies the rows' upper bits)
                 uint16_t *out16 = reinterpret_cast<uint16_t *>(sh.words_out);
 #pragma unroll
@@ -1076,13 +1057,6 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
         PG_MLAP(0);                                              // (stage A)
         const uint32_t n_valid = staged < valid_end ? staged : valid_end;
         const bool more = busy != 0u;
-#if PG_DIAG_MERGE + 0 == 1                                       // (diagnostic, WRONG results: the lookup phase without its sort rounds and copy-out)
-        lds_sync();
-        if (threadIdx.x == 0) { staged = 0; valid_end = NONE; busy = 0; }
-        lds_sync();
-        if (!more) break;
-        continue;
-#endif
         // ---- B: the staged words [0, n_valid), WPL per lane (as many of them as the round has: uniform tests): rank, scan, place
         // -- in place: every word is in its lane's registers before the first barrier --, copy out
         {
@@ -1166,9 +1140,6 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(status, PG_STATUS_PLAN_MISMATCH);
         return;
     }
-#if PG_DIAG_BARE + 0 == 3                                        // (diagnostic: what launching the workgroups costs)
-    return;
-#endif
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ uint32_t emitted, emitted_ring;
     __shared__ unsigned long long n_lookups, wbase;
@@ -1278,8 +1249,6 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     const uint32_t np_all = (uint32_t)n_lookups;                 // (emit_slots: the bucket's words, known before the first is written)
     PG_STAMP(0);
     bool full = false;
-    bool twice_pass = false;                                     // (diagnostic builds: the second pass of PG_DIAG_TWICE is running)
-    (void)twice_pass;
     unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
     uint32_t head = 0, tail = 0;                                 // ring positions (wave-uniform)
     // one pending occurrence per lane off the ring: the general insert, and its word
@@ -1289,11 +1258,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         const uint64_t c = c_ & ~(1ull << 63);                   // (bit 63: the home slot was taken by another key when the first probe looked)
         constexpr uint32_t RING_NONE = MERGE ? 0xffffffffu : MINI_ROW_NONE;      // (MERGE: ring_row holds places, not rows; no place: anything from RING_NOPLACE on)
         const uint32_t rw = act && emit_slots ? ring_row[at] : RING_NONE;
-#if PG_DIAG_TWICE + 0 == 4                                       // (diagnostic, WRONG results: rounds that read the ring and hash but do not probe -- second pass only makes sense)
-        const uint32_t sl = twice_pass ? (mini_slot_hash<WIDE>(c) + (uint32_t)(c_ >> 63)) & smask : mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
-#else
         const uint32_t sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
-#endif
         full |= act && sl == 0xffffffffu;
         if (emit_slots) {
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
@@ -1301,9 +1266,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             const unsigned long long qm = __ballot(put);
             if (MERGE) {
                 // (the ring carried the k-mer's own place among the bucket's halfwords instead of its row)
-#if PG_DIAG_NOSTORE + 0 < 2
                 if (put) gstore(prov_h, (uint64_t)rw, (uint64_t)np_half, (uint16_t)(sl == 0xffffffffu ? 0xffffu : sl & smask), status);
-#endif
             } else
             if (qm) {                                            // (uniform)
                 {
@@ -1314,9 +1277,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         }
     };
     // ---- count: wavefront w takes the batches [ra + 64 (w + 16 t), + 64) of a class; CX = k-mers per record at most there
-    auto count_range = [&](auto cx, int64_t ra, int64_t rb, uint64_t R, uint32_t m, auto with_ring) {       // (R, m: the lane's first record of the range, loaded at the top of the kernel)
+    auto count_range = [&](auto cx, int64_t ra, int64_t rb, uint64_t R, uint32_t m) {       // (R, m: the lane's first record of the range, loaded at the top of the kernel)
         constexpr int CX = decltype(cx)::value;
-        constexpr int RING_ = (int)decltype(with_ring)::value;  // (0: a diagnostic pass compiled without the ring's code; 2: pushes only; 3: pushes + rounds that do not probe)
         int64_t i = ra + (int64_t)wave * 64 + lane;
         for (int64_t i0 = ra + (int64_t)wave * 64; i0 < rb; i0 += BLK) {
             PG_WLAP(0);                                          // (loop top: the record has arrived, last batch's stores are out)
@@ -1339,13 +1301,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 const uint32_t arrived = (uint32_t)FW;
                 asm volatile("" : "+v"(i) : "v"(arrived));
             }
-#ifdef PG_DIAG_NOLOAD                                            // (diagnostic, WRONG results: the count loop on made-up records)
-            R = i < rb ? (uint64_t)i * 0x9E3779B97F4A7C15ull : 0ull;
-            m = i < rb ? ((uint32_t)i * 2654435761u & 0xfffff87fu) | (6u << 7) : 0xffffffffu;
-#else
             R = i < rb ? bases[i] : 0ull;
             m = i < rb ? meta[i] : 0xffffffffu;
-#endif
             // Straight-line code from here to the ballots: the reads and the adds go out for every lane (a lane without a j-th k-mer
             // reads some slot and adds 0 to it), so that no predicate crosses a branch -- a predicate that does comes back as
             // v_cndmask + v_cmp per use, and the branches around each predicated add cost more than the add
@@ -1359,11 +1316,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 const uint64_t fw = FW << ((rc_sh0 - 2 * j) & 63), rc = RC << (2 * j);        // (j beyond the cap: no such k-mer, any value will do)
                 code[j] = (fw < rc ? fw : rc) >> rc_sh0;
                 sl[j] = mini_slot_hash<WIDE>(code[j]) & smask;
-#if PG_DIAG_LDS + 0 == 2                                         // (diagnostic, WRONG results: the count loop without its LDS probes)
-                cur[j] = (unsigned long long)sl[j] << 40;
-#else
                 cur[j] = tab[sl[j]];
-#endif
             }
             // (ballots of single comparisons, combined as scalars: the ballot of a compound predicate is compiled as
             // v_cndmask + v_cmp on top of the scalar logic)
@@ -1381,10 +1334,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     hit = act & __builtin_amdgcn_ballot_w64(cur[j] != 0) & __builtin_amdgcn_ballot_w64((cur[j] >> HASH_CBITS) == code[j]);
                     // (the count sits in the low 22 bits of the slot's low dword and stops far below 2^22: a 32-bit LDS add is enough)
                     const unsigned long long room = __builtin_amdgcn_ballot_w64(((uint32_t)cur[j] & HASH_SAT) == 0);
-#if PG_DIAG_LDS + 0 == 0                                         // (1, 2: diagnostic, WRONG results: without the adds)
                     __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(&tab[sl[j]]), __builtin_amdgcn_inverse_ballot_w64(hit & room) ? 1u : 0u,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
                 }
                 pm[j] = hit & in_row_m;
                 qm[j] = act & ~hit;
@@ -1400,11 +1351,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             PG_WLAP(2);                                          // (hits added, positions claimed)
 #pragma unroll
             for (int j = 0; j < CX; ++j) {
-#if PG_DIAG_NORING + 0 == 1                                      // (diagnostic, WRONG results: nothing but the first probes -- what do the ring and the general insert cost?)
-                const unsigned long long mask = 0ull & qm[j];
-#else
-                const unsigned long long mask = RING_ ? qm[j] : 0ull;
-#endif
+                const unsigned long long mask = qm[j];
                 if (mask) {                                      // (uniform)
                     if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
                         const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
@@ -1413,13 +1360,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                         if (emit_slots) ring_row[at] = MERGE ? ring_place0 + 64u * j : row;
                     }
                     tail += (uint32_t)__popcll(mask);
-#if PG_DIAG_NORING + 0 == 2                                      // (diagnostic, WRONG results: the pushes without the general insert)
-                    if (tail - head >= 64) head += 64;
-                    if (false) {
-#else
-                    if (RING_ == 2) { if (tail - head >= 64) head += 64; }
-                    if (RING_ != 2 && tail - head >= 64) {
-#endif
+                    if (tail - head >= 64) {
 #ifdef PG_MINI_STAMPS
                         const unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
@@ -1438,13 +1379,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                     // first probe did not settle gets its slot from the general insert, one outside every row gets none
 #pragma unroll
                     for (int j = 0; j < CX; ++j)
-#if PG_DIAG_NOSTORE + 0 == 3                                     // (3: no store instruction in the count loop at all)
-                        if (false)
-#elif PG_DIAG_NOSTORE + 0 >= 1                                   // (diagnostic, WRONG results: without the slot stores of the first probes; 2: nor those of the general insert)
-                        if (__builtin_amdgcn_inverse_ballot_w64(pm[j]) && sl[j] == 0xffffffffu)
-#else
                         if (__builtin_amdgcn_inverse_ballot_w64(pm[j]))
-#endif
                             gstore(prov_h, (uint64_t)place0 + 64u * j, (uint64_t)np_half, (uint16_t)sl[j], status);
                 } else
                 // the words, slot by slot (neighbours in the buffer come from different records: the row histograms behind the
@@ -1453,9 +1388,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 {
 #pragma unroll
                 for (int j = 0; j < CX; ++j) {
-#if !(PG_DIAG_COUNT & 1)
                     if (__builtin_amdgcn_inverse_ballot_w64(pm[j])) gstore(prov_b, (uint64_t)at + lanes_below(pm[j]), (uint64_t)np_all, (row << lb) | sl[j], status);
-#endif
                     at += (uint32_t)__popcll(pm[j]);
                 }
                 }
@@ -1463,19 +1396,8 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             PG_WLAP(4);                                          // (the words' stores, waited for)
         }
     };
-#ifndef PG_SHORT_CX
-#define PG_SHORT_CX SHORT_MAX
-#endif
-#if PG_DIAG_BARE + 0 == 0                                        // (1, 2: diagnostic, WRONG results: a bucket's fixed costs -- no records / no slice either)
-    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::integral_constant<int, 1>{});       // (PG_SHORT_CX > SHORT_MAX: idle steps on purpose, a diagnostic)
-    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::integral_constant<int, 1>{});
-#ifdef PG_DIAG_TWICE                                             // (diagnostic, WRONG results: a second pass over the bucket's records -- every key is in the table; 2: compiled without the ring's code; 3: pushes only; 4: rounds that do not probe)
-    twice_pass = true;
-    constexpr int TW_ = PG_DIAG_TWICE + 0 == 2 ? 0 : PG_DIAG_TWICE + 0 == 3 ? 2 : 1;
-    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? PG_SHORT_CX : CAP)>{}, r0, rs, first_s, first_ms, std::integral_constant<int, TW_>{});
-    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml, std::integral_constant<int, TW_>{});
-#endif
-#endif
+    count_range(std::integral_constant<int, (CAP > SHORT_MAX ? SHORT_MAX : CAP)>{}, r0, rs, first_s, first_ms);
+    count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml);
     if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
 #ifdef PG_MINI_STAMPS
     if (lane == 0) {
@@ -1491,9 +1413,6 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (lane == 0 && mine) atomicAdd(&n_lookups, mine);
     }
     __syncthreads();
-#if PG_DIAG_COUNT & 2
-    if (emit_slots) return;                                      // (diagnostic: the count phase alone, with or without its stores)
-#endif
     if (HALF) {
         // the bucket's occupied slots, in slot order: a bitmap of the occupancy (64 consecutive slots = the lanes of one wavefront:
         // a ballot), ranks from the popcounts of its words, the entries written to consecutive places (coalesced).  The LDS table
@@ -1571,9 +1490,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 } else {
                     c = (uint32_t)(v & HASH_CMASK);
                     if (c > HASH_SAT) c = HASH_SAT;
-#if PG_DIAG_BARE + 0 != 2
                     slice[i] = v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull;
-#endif
                 }
                 const uint32_t bin = div_uniform(c, window, rcp_window);
                 // (the merged lookups read the bin itself, 0xffff = none; the word-wise ones bin + 1, 0 = slot never filled)
@@ -1593,9 +1510,6 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         // final words never make a trip of their own through HBM
         unsigned char *lds = reinterpret_cast<unsigned char *>(tab);
         const uint32_t np = (uint32_t)n_lookups;
-#if PG_DIAG_BARE + 0 == 4 || defined(PG_DIAG_NOLOOKUP)           // (diagnostic: without the lookup phase -- BARE = 4: a bucket's fixed costs)
-        return;
-#endif
         if (MERGE) {
             MergeCtx mc;
             mc.lds = lds; mc.smask = smask; mc.vbits = vbits; mc.sh = sh; mc.status = status;
@@ -2076,6 +1990,23 @@ int check_mini_rows(const pg_rows *rows, const char *who)
 }
 
 }  // namespace
+
+// (compiled into the translation unit whose kernels the flags change: a library linked from a checked / stamped / variant
+// mini.o says so whatever its file name is)
+extern "C" uint32_t pg_build_flags(void)
+{
+    uint32_t f = 0;
+#ifdef PG_CHECKED
+    f |= PG_BUILD_CHECKED;
+#endif
+#ifdef PG_MINI_STAMPS
+    f |= PG_BUILD_STAMPS;
+#endif
+#ifdef PG_VARIANT
+    f |= PG_BUILD_VARIANT;
+#endif
+    return f;
+}
 
 extern "C" int64_t pg_mini_plan_bytes(int64_t n_words, const pg_table *t)
 {

@@ -72,7 +72,7 @@ __device__ __forceinline__ void lds_sync()
 }
 
 // A global store that names the capacity (in elements) of the buffer it writes into.  Ordinary builds: a plain store.  Checked
-// builds (make CHECKED=1 -> libpangaea_feat_checked.so, PANGAEA_LIB=checked loads it; the GPU suite's super-k-mer cases run
+// builds (make checked -> libpangaea_feat_checked.so, PANGAEA_LIB=checked loads it; the GPU suite's super-k-mer cases run
 // through it once): an index outside the buffer is NOT written and sets PG_STATUS_BOUNDS -- a kernel whose indexing is wrong
 // fails a test instead of faulting the GPU (a memory fault of one process can reset every GPU of the host).
 template <class T, class V> __device__ __forceinline__ void gstore(T *p, uint64_t idx, uint64_t cap, V v, uint32_t *status)

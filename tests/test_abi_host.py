@@ -30,7 +30,26 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, f"declared in pangaea_feat.h but not exported: {missing}"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.load().pg_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.load().pg_abi_version() == _lib.ABI_VERSION == 7
+
+
+def test_in_tree_library_is_the_product_build():
+    """a variant (make variant ..., possibly wrong results) or a stamped build can never pose as libpangaea_feat.so: its flags say so,
+    and load() refuses any library with flags it was not asked for"""
+    import subprocess
+    import sys
+    lib = C.CDLL(os.path.join(ROOT, "pangaea_amd", "libpangaea_feat.so"))
+    lib.pg_build_flags.restype = C.c_uint32
+    assert lib.pg_build_flags() == 0
+    chk = os.path.join(ROOT, "pangaea_amd", "libpangaea_feat_checked.so")
+    if os.path.exists(chk):
+        code = "from pangaea_amd import _lib; _lib.load()"
+        env = dict(os.environ, PANGAEA_LIB=chk)                 # the checked library by PATH, not by name: refused
+        env.pop("PANGAEA_ALLOW_VARIANT", None)
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+        assert r.returncode != 0 and "pg_build_flags" in r.stderr
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, PANGAEA_ALLOW_VARIANT="1"), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_product_package_never_touches_the_oracle():

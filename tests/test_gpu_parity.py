@@ -43,6 +43,9 @@ def test_loaded_library_is_the_in_tree_hip_build():
     assert torch.cuda.is_available()
     assert os.path.dirname(_lib.LIB_PATH).endswith("pangaea_amd")
     assert _lib.load().pg_device_count() >= 1
+    # ... and it is the PRODUCT build: no timing experiment, no phase stamps (a checked library only when the run asked for it)
+    want = _lib.BUILD_CHECKED if os.environ.get("PANGAEA_LIB", "") == "checked" else 0
+    assert _lib.load().pg_build_flags() == want
 
 
 # ------------------------------------------------------------------ golden vectors of the reference binaries

@@ -1,13 +1,13 @@
-# rocprofv3 kernel averages of bench.py for the in-tree library and each library given (diagnostic builds: timings only)
+# rocprofv3 kernel averages of bench.py for the in-tree library and each variant library given (variants: timings only).
+# Variants are selected with PANGAEA_LIB=<path> PANGAEA_ALLOW_VARIANT=1 (exported: rocprofv3 must start python itself, not env).
 # usage: bash tools/kernel_time_libs.sh pattern a.so b.so ...
 pat=$1; shift
 cd $GRAFT_REPO_ROOT
-cp pangaea_amd/libpangaea_feat.so /tmp/lib_new.so
 export TMPDIR=/tmp
-for which in new "$@"; do
-  if [ $which = new ]; then cp /tmp/lib_new.so pangaea_amd/libpangaea_feat.so; else cp $which pangaea_amd/libpangaea_feat.so; fi
+for which in product "$@"; do
+  if [ $which = product ]; then unset PANGAEA_LIB PANGAEA_ALLOW_VARIANT; else export PANGAEA_LIB=$(realpath $which) PANGAEA_ALLOW_VARIANT=1; fi
   rm -rf /tmp/kt_prof
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --e2e-pairs 0 --steps 4 --warmup 1 > /dev/null 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --e2e-pairs 0 --steps 4 --warmup 1 $BENCH_ARGS > /dev/null 2>&1)
   python3 - "$which" "$pat" <<'PY'
 import csv, glob, sys
 which, pat = sys.argv[1], sys.argv[2]
@@ -17,4 +17,4 @@ for f in glob.glob('/tmp/kt_prof/**/*kernel_stats.csv', recursive=True):
             print(which, r['Name'][:70].replace('(anonymous namespace)::',''), r['Calls'], round(float(r['AverageNs']) / 1e6, 3))
 PY
 done
-cp /tmp/lib_new.so pangaea_amd/libpangaea_feat.so
+unset PANGAEA_LIB PANGAEA_ALLOW_VARIANT
