@@ -453,8 +453,8 @@ def main():
                                             "in-step": "computed in every step, in front of the count",
                                             "once": "computed ONCE before the timed steps (comparison figure: only valid because the bench repeats one batch)"}[args.plan]
                                           if mini else "bucket histogram inside the step"),
-                       "records_per_pair": (ms.local._mini_plan[2] / args.pairs if ms is not None and ms.local._mini_plan else
-                                            table._mini_plan[2] / args.pairs if mini and table._mini_plan else 260.0),
+                       "records_per_pair": (ms.local.plan_counts()[0] / args.pairs if ms is not None and ms.local._mini_plan else
+                                            table.plan_counts()[0] / args.pairs if mini and table._mini_plan else 260.0),
                        "exchange_bytes_per_rank": ({"sent": ms.bytes_sent, "received": ms.bytes_received} if ms is not None else None),
                        "local_bucket_slots": (1 << ms.local.log2_bucket if ms is not None else None),
                        "tnf_rows": ("on a stream of their own beside the table kernels" if beside else "behind the row histograms"),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 7   /* 7: pg_build_flags (what kind of build a loaded library is);
+#define PG_ABI_VERSION 7   /* 7: pg_build_flags (what kind of build a loaded library is), pg_mini_gather_entries names its buffer's size;
                               6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
                               5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
                               4: pg_mini_records_bytes takes the table, status bits;
@@ -411,7 +411,7 @@ int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *rows, int v
  *                         them in fill[bucket] (device int64), the occupancy bitmaps and the provisional (row, slot) words.
  *                         `local` has the UNION's bucket count and, per bucket, slots for this rank's own k-mers; its `data` is
  *                         never written.
- *   pg_mini_gather_entries  bucket b's entries -> out[dst_elem[b] ..): the send buffer, bucket ranges in owner order
+ *   pg_mini_gather_entries  bucket b's entries -> out[dst_elem[b] ..): the send buffer (out_elems entries), bucket ranges in owner order
  *   (all-to-all: 8 bytes per entry)
  *   pg_mini_merge_bins    owner side, buckets [bucket_begin, bucket_end) of the union table `t`: part p's entries of owned bucket i
  *                         lie at recv[p * part_stride + seg[p * (n_owned + 1) + i] .. seg[p * (n_owned + 1) + i + 1]); the parts are
@@ -430,7 +430,7 @@ int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, int64_t wor
                        int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *merge_ws, int64_t merge_ws_words,
                        void *half_ws, int64_t half_ws_bytes, int64_t *fill, uint32_t *status, void *stream);
 int pg_mini_gather_entries(const pg_table *local, const void *half_ws, int64_t half_ws_bytes, const int64_t *fill,
-                           const int64_t *dst_elem, uint64_t *out, void *stream);
+                           const int64_t *dst_elem, uint64_t *out, int64_t out_elems, uint32_t *status, void *stream);
 int pg_mini_merge_bins(const uint64_t *recv, int64_t part_stride, const int64_t *seg, int n_parts, const pg_table *t,
                        int64_t bucket_begin, int64_t bucket_end, int window, int vsize, uint16_t *bins_out, uint32_t *status, void *stream);
 int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, const void *rec_ws, int64_t rec_ws_bytes,

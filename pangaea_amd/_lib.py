@@ -140,7 +140,7 @@ def load() -> C.CDLL:
         "pg_mini_merge_words": (i64, [i64, i64, i64, tp]),
         "pg_mini_half_bytes": (i64, [tp]),
         "pg_mini_count_half": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp]),
-        "pg_mini_gather_entries": (i32, [tp, vp, i64, vp, vp, vp, vp]),
+        "pg_mini_gather_entries": (i32, [tp, vp, i64, vp, vp, vp, i64, vp, vp]),
         "pg_mini_merge_bins": (i32, [vp, i64, vp, i32, tp, i64, i64, i32, i32, vp, vp, vp]),
         "pg_mini_lookup_half": (i32, [tp, rp, vp, i64, vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp]),
         "pg_mini_abundance_from_emitted": (i32, [tp, rp, i32, vp, vp, i64, i64, vp, i64, vp]),

@@ -1251,18 +1251,63 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     bool full = false;
     unsigned long long mine = 0;                                 // k-mers of this lane's records that lie inside a row
     uint32_t head = 0, tail = 0;                                 // ring positions (wave-uniform)
-    // one pending occurrence per lane off the ring: the general insert, and its word
+    // one pending occurrence per lane off the ring: the general insert, and its word.
+    // Packed slots (k <= 21): ONE turn per round.  A ring entry is code | next slot to visit << 42 | turns taken << 56; the round
+    // reads that slot and the one behind it (both reads in flight), claims or counts, and a lane that is not settled by them puts
+    // its entry BACK on the ring, two slots further on -- a round used to last as long as the longest probe chain among its 64
+    // lanes (three to four dependent turns of three LDS round trips each, every other lane waiting), now a lane costs as many
+    // turns as its own chain has (1.15 on average at load 0.35).  After 255 turns (510 slots) the bucket counts as full.
+    constexpr uint64_t RING_CODE = (1ull << 42) - 1ull;
+    constexpr int RING_SLOT_SHIFT = 42, RING_TURN_SHIFT = 56;
+    static_assert(PG_BUCKET_MAX_LOG2_SLOTS <= RING_TURN_SHIFT - RING_SLOT_SHIFT, "a slot index fits its field of the ring entry");
     auto slow_round = [&](bool act) {
         const uint32_t at = (head + lane) & (RING - 1);
         const uint64_t c_ = act ? ring[at] : 0ull;
-        const uint64_t c = c_ & ~(1ull << 63);                   // (bit 63: the home slot was taken by another key when the first probe looked)
         constexpr uint32_t RING_NONE = MERGE ? 0xffffffffu : MINI_ROW_NONE;      // (MERGE: ring_row holds places, not rows; no place: anything from RING_NOPLACE on)
         const uint32_t rw = act && emit_slots ? ring_row[at] : RING_NONE;
-        const uint32_t sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
-        full |= act && sl == 0xffffffffu;
+        uint32_t sl;
+        bool settled = act;                                      // (lanes whose word may be written this round)
+        if constexpr (WIDE) {
+            const uint64_t c = c_ & ~(1ull << 63);               // (bit 63: the home slot was taken by another key when the first probe looked)
+            sl = mini_insert_slow<WIDE>(tab, cnts, smask, limit, c, act, (uint32_t)(c_ >> 63));
+        } else {
+            const uint64_t code = c_ & RING_CODE;
+            const uint32_t s0 = (uint32_t)(c_ >> RING_SLOT_SHIFT) & smask, s1 = (s0 + 1u) & smask;
+            const uint32_t turns = (uint32_t)(c_ >> RING_TURN_SHIFT);
+            const unsigned long long fresh = (unsigned long long)((code << HASH_CBITS) | 1ull);
+            const unsigned long long cur0 = tab[s0], cur1 = tab[s1];
+            bool todo = act;
+            sl = act ? 0xffffffffu : 0u;
+            // one slot of the chain: claim it if it is empty, count on it if it holds the key (what was read may be stale by now:
+            // a claim goes through compare-and-swap, which answers with what is there)
+            auto visit = [&](uint32_t slot, unsigned long long cur) {
+                if (todo && cur == 0) cur = atomicCAS(&tab[slot], 0ull, fresh);
+                const bool claimed = todo && cur == 0;
+                const bool match = todo && cur != 0 && (cur >> HASH_CBITS) == code;
+                // stop growing at SAT; the overshoot is bounded by the lanes in flight and clamped when the slice is packed
+                if (match && (uint32_t)(cur & HASH_CMASK) < HASH_SAT) atomicAdd(reinterpret_cast<uint32_t *>(&tab[slot]), 1u);   // (the count is in the low dword)
+                if (claimed || match) { sl = slot; todo = false; }
+            };
+            visit(s0, cur0);
+            visit(s1, cur1);
+            // (a bucket with fewer slots than a lane may visit: it has seen them all)
+            const bool give_up = todo && (turns == 255u || 2u * (turns + 1u) >= limit);
+            const bool again = todo && !give_up;
+            settled = act && !again;
+            const unsigned long long am = __ballot(again);
+            if (am) {                                            // (uniform; the round's own 64 places are free: they were read above)
+                if (again) {
+                    const uint32_t to = (tail + lanes_below(am)) & (RING - 1);
+                    ring[to] = code | ((uint64_t)((s0 + 2u) & smask) << RING_SLOT_SHIFT) | ((uint64_t)(turns + 1u) << RING_TURN_SHIFT);
+                    if (emit_slots) ring_row[to] = rw;
+                }
+                tail += (uint32_t)__popcll(am);
+            }
+        }
+        full |= settled && sl == 0xffffffffu;
         if (emit_slots) {
             // (a full bucket still gets its word -- the slot of a k-mer that is not there reads as "no bin")
-            const bool put = MERGE ? rw < RING_NOPLACE : rw != RING_NONE;
+            const bool put = settled && (MERGE ? rw < RING_NOPLACE : rw != RING_NONE);
             const unsigned long long qm = __ballot(put);
             if (MERGE) {
                 // (the ring carried the k-mer's own place among the bucket's halfwords instead of its row)
@@ -1355,12 +1400,15 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                 if (mask) {                                      // (uniform)
                     if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
                         const uint32_t at = (tail + lanes_below(mask)) & (RING - 1);
-                        ring[at] = code[j] | (cur[j] != 0ull ? 1ull << 63 : 0ull);     // (a slot that is not empty and not a hit holds another key)
+                        // (a slot that is not empty and not a hit holds another key, and nothing ever leaves a slot: the search
+                        // starts behind it)
+                        if constexpr (WIDE) ring[at] = code[j] | (cur[j] != 0ull ? 1ull << 63 : 0ull);
+                        else ring[at] = code[j] | ((uint64_t)((sl[j] + (cur[j] != 0ull ? 1u : 0u)) & smask) << RING_SLOT_SHIFT);
                         // (MERGE: the general insert writes the slot to the k-mer's own place: the ring carries that place)
                         if (emit_slots) ring_row[at] = MERGE ? ring_place0 + 64u * j : row;
                     }
                     tail += (uint32_t)__popcll(mask);
-                    if (tail - head >= 64) {
+                    while (tail - head >= 64) {                  // (a round may put unsettled lanes back: at most as many as it took off)
 #ifdef PG_MINI_STAMPS
                         const unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
@@ -1398,7 +1446,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
     };
     count_range(std::integral_constant<int, (CAP > SHORT_MAX ? SHORT_MAX : CAP)>{}, r0, rs, first_s, first_ms);
     count_range(std::integral_constant<int, CAP>{}, rs, r1, first_l, first_ml);
-    if (tail != head) slow_round(lane < tail - head);            // what is left on the ring
+    while (tail != head) {                                       // what is left on the ring
+        const uint32_t left = tail - head < 64u ? tail - head : 64u;
+        slow_round(lane < left);
+        head += left;
+    }
 #ifdef PG_MINI_STAMPS
     if (lane == 0) {
         atomicAdd(&dbg[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - st0));     // per-wave end of the count loop
@@ -1453,16 +1505,17 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
             if (threadIdx.x == 0) n_entries = run;
         }
         __syncthreads();
-        unsigned long long *ent = hv.ent + ((uint64_t)blockIdx.x << t.log2_bucket);
+        // (capacities for the checked build: the slabs of all buckets of this launch)
+        const uint64_t ent0 = (uint64_t)blockIdx.x << t.log2_bucket, ent_cap = (uint64_t)gridDim.x << t.log2_bucket;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const uint32_t i = q * BLK + threadIdx.x;
             if (i < n_slots && v[q]) {
                 const unsigned long long m = occ_l[i >> 6];
-                ent[rank_l[i >> 6] + (uint32_t)__popcll(m & ((1ull << (i & 63u)) - 1ull))] = v[q];
+                gstore(hv.ent, ent0 + rank_l[i >> 6] + (uint32_t)__popcll(m & ((1ull << (i & 63u)) - 1ull)), ent_cap, v[q], status);
             }
         }
-        for (uint32_t wi = threadIdx.x; wi < n_occ; wi += BLK) hv.occ[(uint64_t)blockIdx.x * n_occ + wi] = occ_l[wi];
+        for (uint32_t wi = threadIdx.x; wi < n_occ; wi += BLK) gstore(hv.occ, (uint64_t)blockIdx.x * n_occ + wi, (uint64_t)gridDim.x * n_occ, occ_l[wi], status);
         if (threadIdx.x == 0) {
             hv.fill[blockIdx.x] = (long long)n_entries;
             hv.ring_cnt[blockIdx.x] = emitted_ring;
@@ -1681,11 +1734,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 //                                                                 provisional words (as the one-GPU kernel does), row-group scatter
 __global__ __launch_bounds__(BLOCK) void mini_gather_entries_kernel(const unsigned long long *__restrict__ ent, int log2_bucket,
                                                                     const long long *__restrict__ fill, const long long *__restrict__ dst_elem,
-                                                                    unsigned long long *__restrict__ out)
+                                                                    unsigned long long *__restrict__ out, unsigned long long out_cap, uint32_t *status)
 {
     const unsigned long long *src = ent + ((uint64_t)blockIdx.x << log2_bucket);
     const long long n = fill[blockIdx.x], d0 = dst_elem[blockIdx.x];
-    for (long long i = threadIdx.x; i < n; i += BLOCK) out[d0 + i] = src[i];
+    for (long long i = threadIdx.x; i < n; i += BLOCK) gstore(out, (uint64_t)(d0 + i), out_cap, src[i], status);
 }
 
 // one workgroup per OWNED bucket: part p's entries of owned bucket i lie at recv[p * part_stride + seg[p * (n_owned + 1) + i] ..
@@ -1734,8 +1787,8 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_merge_bins_kernel(const unsign
     }
     if (full) atomicOr(status, PG_STATUS_TABLE_FULL);
     __syncthreads();
-    uint64_t *slice = t.slots + ((uint64_t)(bucket0 + blockIdx.x) << t.log2_bucket);
-    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) slice[i] = tab[i];
+    const uint64_t slice0 = (uint64_t)(bucket0 + blockIdx.x) << t.log2_bucket;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) gstore(t.slots, slice0 + i, 1ull << t.log2_slots, tab[i], status);
     const float rcp_window = 1.0f / (float)window;
     for (int p = 0; p < n_parts; ++p) {
         const long long a = seg[(long long)p * (n_owned + 1) + blockIdx.x], b = seg[(long long)p * (n_owned + 1) + blockIdx.x + 1];
@@ -1753,7 +1806,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_merge_bins_kernel(const unsign
                 }
                 s = (s + 1) & smask;
             }
-            bins_out[(long long)p * part_stride + e] = (uint16_t)out;
+            gstore(bins_out, (uint64_t)((long long)p * part_stride + e), (uint64_t)n_parts * (uint64_t)part_stride, (uint16_t)out, status);
         }
     }
 }
@@ -2370,17 +2423,17 @@ extern "C" int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, 
 }
 
 extern "C" int pg_mini_gather_entries(const pg_table *local, const void *half_ws, int64_t half_ws_bytes, const int64_t *fill,
-                                      const int64_t *dst_elem, uint64_t *out, void *stream)
+                                      const int64_t *dst_elem, uint64_t *out, int64_t out_elems, uint32_t *status, void *stream)
 {
     int rc = check_mini(local, "pg_mini_gather_entries");
     if (rc) return rc;
-    if (!half_ws || !fill || !dst_elem || !out) return pg_fail(PG_EINVAL, "pg_mini_gather_entries: null argument");
+    if (!half_ws || !fill || !dst_elem || !out || !status || out_elems < 0) return pg_fail(PG_EINVAL, "pg_mini_gather_entries: null argument");
     const MiniHalfLayout hl = mini_half_layout(local);
     if ((int64_t)hl.total > half_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_gather_entries: workspace does not match the table");
     const unsigned nb = 1u << (local->log2_slots - local->log2_bucket_slots);
     hipLaunchKernelGGL(mini_gather_entries_kernel, dim3(nb), dim3(BLOCK), 0, (hipStream_t)stream,
                        (const unsigned long long *)((const char *)half_ws + hl.ent_off), local->log2_bucket_slots, (const long long *)fill,
-                       (const long long *)dst_elem, (unsigned long long *)out);
+                       (const long long *)dst_elem, (unsigned long long *)out, (unsigned long long)out_elems, status);
     return check_launch("pg_mini_gather_entries");
 }
 

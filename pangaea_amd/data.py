@@ -59,8 +59,10 @@ class Data(Dataset):
         logging.info("calculate sampling weights")
         if _is_device_counts(abd) and _is_device_counts(tnf) and abd.device == self.device and tnf.device == self.device:
             # the count matrices as the feature kernels leave them: one fused pass each
-            self.abd_dev, w = _normalize_counts(abd, True)
-            self.weights = w.cpu().numpy() if abd.shape[1] else np.zeros(abd.shape[0], dtype=np.float64)
+            # (the weights stay on the device until somebody reads ``weights``: the encode of a batch does not, and a copy here
+            # would make the host wait for every kernel enqueued so far)
+            self.abd_dev, self._weights_dev = _normalize_counts(abd, True)
+            self._weights = None if abd.shape[1] else np.zeros(abd.shape[0], dtype=np.float64)
             logging.info("normalize data")
             self.tnf_dev, _ = _normalize_counts(tnf, False)
         else:
@@ -69,14 +71,25 @@ class Data(Dataset):
                 m = nabd.max(dim=1).values
             else:
                 m = nabd.new_zeros(0)
-            self.weights = (m * m).cpu().numpy().astype(np.float64)
+            self._weights_dev = m * m
+            self._weights = None
             logging.info("normalize data")
             self.abd_dev = nabd.to(torch.float32)
             self.tnf_dev = _l1_rows(_as_device_tensor(tnf, self.device)).to(torch.float32)
         self._abd = self._tnf = None
         logging.info("preprocessing completed")
 
-    # host views, materialised on first use (the reference keeps numpy float32 matrices here)
+    # host views, materialised on first use (the reference keeps numpy float32 matrices and the float64 weights here)
+    @property
+    def weights(self) -> np.ndarray:
+        if self._weights is None:
+            self._weights = self._weights_dev.cpu().numpy().astype(np.float64)
+        return self._weights
+
+    @weights.setter
+    def weights(self, value) -> None:
+        self._weights = np.asarray(value, dtype=np.float64)
+
     @property
     def abd(self) -> np.ndarray:
         if self._abd is None:

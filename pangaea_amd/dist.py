@@ -625,7 +625,7 @@ class MiniSharded:
         stream_ptr = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(L.pg_mini_gather_entries(loc.desc(), loc._half_ws.data_ptr(), loc._half_ws.numel(), fill.data_ptr(), elem.data_ptr(),
-                                                send.data_ptr(), stream_ptr))
+                                                send.data_ptr(), send.numel(), loc.status.data_ptr(), stream_ptr))
         recv = torch.empty(world * cap1, dtype=torch.int64, device=dev)
         _all_to_all_flat(recv, send, group)
         mine = (cuts[me], cuts[me + 1])
@@ -644,12 +644,27 @@ class MiniSharded:
         self.local.lookup_half(self._bins, self._elem)
         self._bins = self._elem = None
 
-    def any_full(self) -> bool:
-        """did a bucket run full on ANY rank (the rank's own LDS table, or an owner's merged one)?  The same answer everywhere."""
-        flag = (((self.local.status[:1] | self.union.status[:1]) & 1) != 0).to(torch.int32)
-        flag = _staged(flag, self.group)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        return int(flag.item()) != 0
+    def status_bits(self) -> int:
+        """the PG_STATUS_* bits any rank's kernels raised (the rank's own count / lookup half, or an owner's merge): the SAME word
+        everywhere -- one all-reduce (MAX) over the bits, taken apart"""
+        st = (self.local.status[:1] | self.union.status[:1]).to(torch.int64)
+        bits = ((st >> torch.arange(4, device=st.device)) & 1).to(torch.int32)
+        bits = _staged(bits, self.group)
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
+        return int(sum(int(b) << i for i, b in enumerate(bits.tolist())))
+
+    def any_full(self, bits: int | None = None) -> bool:
+        """did a bucket run full on ANY rank (the rank's own LDS table, or an owner's merged one)?  The same answer everywhere.
+        Anything else the kernels reported (a plan that does not describe the stream: nothing was counted; a store outside a
+        buffer in the checked build) is raised -- on every rank -- instead of being taken for a result."""
+        from . import _lib
+        bits = self.status_bits() if bits is None else bits
+        if bits & _lib.STATUS_BOUNDS:
+            raise RuntimeError("a kernel of the checked build was about to store outside its buffer (PG_STATUS_BOUNDS) on some rank: the results are incomplete")
+        if bits & _lib.STATUS_PLAN_MISMATCH:
+            self.local._mini_plan = None
+            raise RuntimeError("the partition plan did not describe the stream on some rank (PG_STATUS_PLAN_MISMATCH): nothing was counted")
+        return bool(bits & (_lib.STATUS_TABLE_FULL | _lib.STATUS_OVERFLOW_LIST))
 
     def check_status(self) -> None:
         from . import _lib
@@ -682,8 +697,19 @@ def features_sharded_mini(stream: ReadStream, plan, k: int, k_tnf: int | None, w
     loc = torch.tensor([int(1.1 * local)], dtype=torch.int64)
     loc = loc.to(stream.device) if dist.get_backend(group) == "nccl" else loc
     dist.all_reduce(loc, op=dist.ReduceOp.MAX, group=group)
+    from . import _lib
     log2_u, lb_u, lb_l = MiniSharded.geometry(total, int(loc.item()))
+
+    def key_partitioned():
+        # a union that the super-k-mer geometry cannot hold (more than 2^16 buckets of 2^14 slots): the key-partitioned exchange,
+        # on every rank -- the estimates behind this decision were all-reduced, so it is the same everywhere
+        table = count_kmers_sharded(stream, k, rows=plan, group=group)
+        tnf, abd = kmer.features(stream, plan, k_tnf=k_tnf, table=table, window=window, vsize=vsize)
+        return tnf, abd, None
+
     for attempt in range(max_tries):
+        if log2_u - lb_u > _lib.MINI_MAX_LOG2_BUCKETS:
+            return key_partitioned()
         ms = MiniSharded(k, stream.device, log2_u, lb_l, window, vsize, group, union_log2_bucket=lb_u)
         ms.count(stream, plan, check=False)
         if not ms.any_full():
@@ -692,6 +718,5 @@ def features_sharded_mini(stream: ReadStream, plan, k: int, k_tnf: int | None, w
         del ms
         lb_l = min(lb_l + 1, lb_u)
         log2_u += 1
-        lb_u = min(14, lb_u + 1)
-    from . import _lib
+        lb_u = min(_lib.BUCKET_MAX_LOG2_SLOTS, lb_u + 1)
     raise _lib.PangaeaError(_lib.PG_ETABLEFULL, "the sharded super-k-mer tables stayed full")

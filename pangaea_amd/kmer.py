@@ -61,6 +61,8 @@ class KmerTable:
         self._mini_next = None           # (key, plan workspace, event, rows) of a plan computed ahead on a side stream
         self._mini_spare = None          # the plan workspace that is neither in use nor being filled
         self._mini_rec_ws = None
+        self._mini_sized_for = None      # (n_words, geometry) the record / slot workspaces were sized for (with slack)
+        self._mini_optimistic = None     # the arguments of a count that ran on them without reading its plan's counts
         self._half = None                # (fill, n_words, rows, window, vsize) between count_half and lookup_half (N > 1 ranks)
         self._half_ws = None
         self._merge_ws = None            # the provisional words of the merged lookups (fixed slots per record)
@@ -369,14 +371,24 @@ class KmerTable:
         held = (stream.codes, table_plane)               # (kept with the plan: see _plan_key)
         with torch.cuda.device(self.device):
             if (self._mini_plan is None or self._mini_plan[0] != key) and self._mini_next is not None and self._mini_next[0] == key:
-                # a plan computed ahead (``prefetch_plan``): the count waits for it on the device; its record count is read here
+                # a plan computed ahead (``prefetch_plan``): the count waits for it ON THE DEVICE.  Its record counts size the
+                # record and slot workspaces -- but where workspaces of a batch of the same size exist already (a stream of batches),
+                # they are used as they are and the host does not wait for the plan at all: the kernels themselves refuse a plan that
+                # names more records than the buffers hold (PG_STATUS_PLAN_MISMATCH, nothing is written), and ``check_status`` /
+                # the check below then count again with workspaces of the right size.  The counts stay on the device until
+                # somebody asks (``plan_counts``).
                 _, ws, event, _ = self._mini_next[:4]
                 torch.cuda.current_stream(self.device).wait_event(event)
-                event.synchronize()
                 if self._mini_plan is not None:
                     self._mini_spare = self._mini_plan[1]
-                head = ws[:24].view(torch.int64).cpu()                     # (records, -, records of more than four k-mers)
-                self._mini_plan = (key, ws, int(head[0]), keep, held, int(head[2]))
+                sized_for = getattr(self, "_mini_sized_for", None)
+                if (sized_for == (n_words, self.log2_slots, self.log2_bucket) and self._mini_rec_ws is not None
+                        and os.environ.get("PG_PLAN_HOST_SYNC", "0") in ("", "0")):
+                    self._mini_plan = (key, ws, None, keep, held, None)
+                else:
+                    event.synchronize()
+                    head = ws[:24].view(torch.int64).cpu()                 # (records, -, records of more than four k-mers)
+                    self._mini_plan = (key, ws, int(head[0]), keep, held, int(head[2]))
                 self._mini_next = None
             if self._mini_plan is None or self._mini_plan[0] != key:
                 need = _lib.check(L.pg_mini_plan_bytes(n_words, self.desc()))
@@ -392,10 +404,15 @@ class KmerTable:
                     self._mini_spare = self._mini_plan[1]
                 self._mini_plan = (key, ws, n_records, keep, held, int(head[2]))
             _, plan_ws, n_records = self._mini_plan[:3]
-            need = _lib.check(L.pg_mini_records_bytes(n_records, self.desc()))
-            if self._mini_rec_ws is None or self._mini_rec_ws.numel() != need:
-                self._mini_rec_ws = None
-                self._mini_rec_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            optimistic = n_records is None          # (workspaces of the previous batch of this size, the plan's counts unread)
+            # (3 % of slack on the counts: the next batch of the same size then finds room without asking)
+            slack = (lambda n: n + n // 32 + 4096)
+            if not optimistic:
+                need = _lib.check(L.pg_mini_records_bytes(slack(n_records), self.desc()))
+                if self._mini_rec_ws is None or self._mini_rec_ws.numel() < need or self._mini_rec_ws.numel() > 2 * need:
+                    self._mini_rec_ws = None
+                    self._mini_rec_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._mini_sized_for = (n_words, self.log2_slots, self.log2_bucket)
             window, vsize, sws_ptr, sws_n = 0, 0, None, 0
             if fuse:
                 window, vsize = int(emit[0]), int(emit[1])
@@ -409,10 +426,16 @@ class KmerTable:
                 # the merged form of the lookups (PG_MINI_MERGE=0: word-wise): its provisional words lie in fixed slots per record,
                 # sized from the plan's record counts (records, and records of more than four k-mers: 1st and 3rd word of the plan
                 # workspace); the library falls back to the word-wise form where the merged one does not apply
-                need = _lib.check(L.pg_mini_merge_words(n_words, n_records, self._mini_plan[5], self.desc()))
-                if getattr(self, "_merge_ws", None) is None or self._merge_ws.numel() < need:
-                    self._merge_ws = None
-                    self._merge_ws = torch.empty(need, dtype=torch.int32, device=self.device)
+                if not optimistic or getattr(self, "_merge_ws", None) is None:
+                    if optimistic:                                         # (no slot buffer yet: the counts are needed after all)
+                        n_records, n_long = self.plan_counts()
+                        optimistic = False
+                    else:
+                        n_long = self._mini_plan[5]
+                    need = _lib.check(L.pg_mini_merge_words(n_words, slack(n_records), min(slack(n_long), slack(n_records)), self.desc()))
+                    if getattr(self, "_merge_ws", None) is None or self._merge_ws.numel() < need:
+                        self._merge_ws = None
+                        self._merge_ws = torch.empty(need, dtype=torch.int32, device=self.device)
                 mws_ptr, mws_n = self._merge_ws.data_ptr(), self._merge_ws.numel()
             if half:
                 if not fuse:
@@ -434,9 +457,20 @@ class KmerTable:
         self._empty = False
         self._records = (keep, n_words) if fuse and not half else None
         self._emitted = (window, vsize) if fuse and not half else None
+        self._mini_optimistic = (stream, word_begin, word_end, rows, emit, half) if optimistic else None
         if check:
             self.check_status()
         return self
+
+    def plan_counts(self) -> tuple:
+        """(records, records of more than four k-mers) of the partition plan in use -- read from the device on first use (a plan
+        picked up without a host wait keeps them there)"""
+        key, ws, n_records, keep, held, n_long = self._mini_plan
+        if n_records is None:
+            head = ws[:24].view(torch.int64).cpu()
+            n_records, n_long = int(head[0]), int(head[2])
+            self._mini_plan = (key, ws, n_records, keep, held, n_long)
+        return n_records, n_long
 
     def lookup_half(self, bins: torch.Tensor, bin_elem: torch.Tensor) -> None:
         """N > 1 ranks: finish a ``count_half`` -- ``bins`` (int16 view of what the bucket owners sent back: bin + 1 of every entry in
@@ -538,6 +572,7 @@ class KmerTable:
         self._workspace = self._shuffle_ws = self._mini_rec_ws = self._mini_spare = None
         self._merge_ws = self._half_ws = None
         self._mini_plan = self._mini_next = None
+        self._mini_sized_for = self._mini_optimistic = None
         self._records = self._emitted = self._half = None
         if self.data.is_cuda:
             torch.cuda.empty_cache()
@@ -550,6 +585,20 @@ class KmerTable:
         if st & _lib.STATUS_BOUNDS:
             raise RuntimeError("a kernel of the checked build was about to store outside its buffer (PG_STATUS_BOUNDS): the results are incomplete")
         if st & _lib.STATUS_PLAN_MISMATCH:
+            again = getattr(self, "_mini_optimistic", None)
+            if again is not None and self._mini_plan is not None:
+                # the count ran on the previous batch's workspaces without waiting for its plan's record counts, and this batch has
+                # more records than they hold: nothing was written -- read the counts, size the workspaces, count again
+                self._mini_optimistic = None
+                stream, word_begin, word_end, rows, emit, half = again
+                self.status.zero_()
+                self.plan_counts()
+                self._empty = True
+                if half:
+                    self.count_half(stream, rows, emit, check=False)
+                else:
+                    self.count(stream, word_begin, word_end, check=False, rows=rows, emit=emit)
+                return self.check_status()
             self._mini_plan = None
             raise RuntimeError("the partition plan did not describe this stream (PG_STATUS_PLAN_MISMATCH): nothing was counted")
         if st != 0:

@@ -562,3 +562,19 @@ def test_super_kmer_form_saturating_counts_on_two_ranks(tmp_path):
 def test_super_kmer_form_over_a_one_rank_rccl_group(tmp_path):
     """the same exchange with RCCL's collectives (a one-GPU box holds a one-rank group): all-gather of the fills, both all-to-alls"""
     _check_mini_sharded(tmp_path, 1, backend="nccl")
+
+
+@pytest.mark.gpu
+def test_super_kmer_form_through_the_checked_build():
+    """the N-rank kernels (count half's entries and occupancy, entry gather, owner merge and bins, lookup half) with every global
+    store checked against its buffer (PANGAEA_LIB=checked: a wrong index sets PG_STATUS_BOUNDS, which MiniSharded raises on every
+    rank) -- two ranks sharing the GPU and the one-rank RCCL group"""
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    env = dict(os.environ, PANGAEA_LIB="checked")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_dist_gloo.py"),
+                        "-k", "(super_kmer_form_on_several_ranks and 2) or one_rank_rccl or saturating_counts"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout
