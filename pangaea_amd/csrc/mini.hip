@@ -340,10 +340,20 @@ __device__ __forceinline__ void scan_digits_blk(const uint32_t *cnt, uint32_t *s
 }
 
 // ---- A1': stream -> regions
+// What a round stages in LDS is not the records but a 4-byte REFERENCE per record, region-sorted -- which lane's word it was cut
+// from, where it ends, its bucket -- next to the lanes' words and masks; the record itself (32 characters, length, row) is put
+// together by the copy-out thread that stores it.  The lane that segmented the word would have to do that in 32 predicated
+// blocks, one per position a record may end at, every one of them issued for the whole wavefront although a word has six or
+// seven records: the assembly cost 32 x ~30 vector instructions per word, in the copy-out it costs ~40 per RECORD at full lane
+// occupancy (the first pass: 6.9 -> see DESIGN.md), and the stage shrinks from 13 to 4 bytes per record.
+constexpr int REF_E_SHIFT = 16, REF_LANE_SHIFT = 21;               // ref = lane << 21 | e << 16 | bucket
+static_assert(PG_MINI_MAX_LOG2_BUCKETS <= REF_E_SHIFT && S1_BLOCK <= (1 << (32 - REF_LANE_SHIFT)), "fields of a stage reference");
 template <int N1> struct Scatter1Lds {                              // N1 regions: 256, or 512 for a table of 2^16 buckets
-    uint64_t bases[STAGE_CAP];
-    uint32_t meta[STAGE_CAP];
-    typename std::conditional<(N1 > 256), uint16_t, uint8_t>::type dig[STAGE_CAP];
+    uint32_t ref[STAGE_CAP];
+    uint64_t cw[S1_BLOCK], pw[S1_BLOCK];                            // the lanes' words and the words before them
+    uint32_t nonk[S1_BLOCK];                                        // positions that end a record or end no k-mer at all
+    uint32_t ok_row[S1_BLOCK];                                      // k-mer ends that count for rows
+    uint32_t starts[S1_BLOCK], ends[S1_BLOCK], r0[S1_BLOCK];        // RowBits of the lane (r0: bit 31 = inside0)
     uint32_t cnt[N1];
     uint32_t start[N1 + 1];
     unsigned long long gbase[N1];
@@ -378,11 +388,11 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         const int64_t w = word_begin + round * ROUND_WORDS + threadIdx.x;
         if (word_begin + round * ROUND_WORDS >= word_end) break;    // (uniform)
         if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
-        lds_sync();
+        lds_sync();                                                 // (also: the previous round's copy-out has read the lanes' words)
         uint32_t dr[32];                                            // bucket << 16 | rank inside the region
         uint32_t has = 0;
         LaneWord lw;
-        lw.ok = 0;
+        lw.ok = 0; lw.ok_row = 0; lw.x.cw = lw.x.pw = 0;
         if (w < word_end) lw = load_lane_word(codes, valid, strict, w, k);
         RowBits rb;
         rb.starts = rb.ends = rb.r0 = 0; rb.inside0 = false;
@@ -393,6 +403,16 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 has |= 1u << e;
             });
         }
+        // what the copy-out needs of this lane's word: a record's length and row follow from where it ends -- it starts behind the
+        // previous record's end or behind the last position that ends no valid k-mer, whichever is later; its k-mers share one
+        // row (that of its last character)
+        L.cw[threadIdx.x] = lw.x.cw;
+        L.pw[threadIdx.x] = lw.x.pw;
+        L.nonk[threadIdx.x] = has | ~lw.ok;
+        L.ok_row[threadIdx.x] = lw.ok_row;
+        L.starts[threadIdx.x] = rb.starts;
+        L.ends[threadIdx.x] = rb.ends;
+        L.r0[threadIdx.x] = rb.r0 | (rb.inside0 ? 0x80000000u : 0u);
         lds_sync();
         scan_digits<N1, true>(L.cnt, L.start, L.wave_tot);
         const uint32_t total = L.start[N1];
@@ -400,9 +420,6 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         const int n_win = total <= (uint32_t)STAGE_CAP ? 1 : 4;
         for (int win = 0; win < n_win; ++win) {
             const uint32_t wmask = n_win == 1 ? 0xffffffffu : (0xffu << (8 * win));
-            // (opaque to the optimiser: otherwise everything the placement derives from the word -- 32 shifted copies of it -- is
-            // hoisted out of this loop and spilled)
-            asm volatile("" : "+v"(lw.x.cw), "+v"(lw.x.pw), "+v"(has));
             if (n_win > 1) {                                        // rank again, this window's records only
                 lds_sync();
                 if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
@@ -420,37 +437,62 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 L.cur[threadIdx.x] += c;
             }
             {
-                // a record's length and row follow from where it ends: it starts behind the previous record's end or behind the
-                // last position that ends no valid k-mer, whichever is later; its k-mers share one row (that of its last character)
+                const uint32_t mine = (uint32_t)threadIdx.x << REF_LANE_SHIFT;
 #pragma unroll
                 for (int e = 0; e < 32; ++e) {
                     if ((has & wmask) >> e & 1u) {
-                        const uint32_t b = dr[e] >> 16, d = b >> bits2;
-                        const uint32_t at = L.start[d] + (dr[e] & 0xffffu);
-                        const uint32_t below = e ? ((has | ~lw.ok) & ((1u << e) - 1u)) : 0u;     // ends / non-k-mers before e
-                        const int n = below ? e - (31 - __clz((int)below)) : e + 1;
-                        const uint32_t row = (lw.ok_row >> e) & 1u ? rb.at(e) : MINI_ROW_NONE;
-                        // the 32 characters ending at position e of the word
-                        L.bases[at] = e == 31 ? lw.x.cw : (lw.x.cw << (2 * (31 - e))) | (lw.x.pw >> (2 * (e + 1)));
-                        L.meta[at] = (row << META_ROW_SHIFT) | ((uint32_t)(n - 1) << META_D2_BITS) | (b & d2mask);
-                        L.dig[at] = (decltype(L.dig[0] + 0))d;
+                        const uint32_t b = dr[e] >> 16;
+                        L.ref[L.start[b >> bits2] + (dr[e] & 0xffffu)] = mine | ((uint32_t)e << REF_E_SHIFT) | b;
                     }
                 }
             }
             lds_sync();
             const uint32_t tot = L.start[N1];
-            for (uint32_t i = threadIdx.x; i < tot; i += S1_BLOCK) {
-                // (a record beyond the buffers is dropped: cannot happen with the plan of THIS stream -- the offsets are exact --,
-                // and the plan of another one is reported below)
-                const unsigned long long g = L.gbase[L.dig[i]] + i;
-                if (g < rec_cap)
-                {
-                    out_bases[g] = L.bases[i];
-                    out_meta[g] = L.meta[i];
+            // copy-out: thread i puts record i of the region-sorted round together and stores it, two records at a time (their LDS
+            // reads in flight together)
+            for (uint32_t i0 = 0; i0 < tot; i0 += 2 * S1_BLOCK) {
+                uint32_t rf[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t i = i0 + u * S1_BLOCK + threadIdx.x;
+                    rf[u] = L.ref[i < tot ? i : 0u];                 // (tot > 0 here: ref[0] is a record)
+                }
+                uint64_t cwv[2], pwv[2];
+                uint32_t nonk[2], okr[2], st[2], en[2], r0v[2];
+                unsigned long long gb[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t ln = rf[u] >> REF_LANE_SHIFT;
+                    cwv[u] = L.cw[ln]; pwv[u] = L.pw[ln];
+                    nonk[u] = L.nonk[ln]; okr[u] = L.ok_row[ln];
+                    st[u] = L.starts[ln]; en[u] = L.ends[ln]; r0v[u] = L.r0[ln];
+                    gb[u] = L.gbase[(rf[u] & 0xffffu) >> bits2];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t i = i0 + u * S1_BLOCK + threadIdx.x;
+                    const uint32_t e = (rf[u] >> REF_E_SHIFT) & 31u, b = rf[u] & 0xffffu;
+                    const uint32_t below = nonk[u] & ((1u << e) - 1u);                       // ends / non-k-mers before e
+                    const uint32_t n = below ? e - (31u - (uint32_t)__clz((int)below)) : e + 1u;
+                    uint32_t row = MINI_ROW_NONE;
+                    if ((okr[u] >> e) & 1u) {                                                // (RowBits::at)
+                        const uint32_t upto = e == 31u ? 0xffffffffu : (2u << e) - 1u;
+                        const int sc = __popc(st[u] & upto), ec = __popc(en[u] & upto);
+                        const int in0 = (int)(r0v[u] >> 31);
+                        if (in0 + sc - ec > 0) row = (r0v[u] & 0x7fffffffu) + (uint32_t)sc - (in0 ? 0u : 1u);
+                    }
+                    // the 32 characters ending at position e of the word
+                    const uint64_t rec = e == 31u ? cwv[u] : (cwv[u] << (2u * (31u - e))) | (pwv[u] >> (2u * (e + 1u)));
+                    const unsigned long long g = gb[u] + i;
+                    // (a record beyond the buffers is dropped: cannot happen with the plan of THIS stream -- the offsets are exact --,
+                    // and the plan of another one is reported below)
+                    if (i < tot && g < rec_cap) {
+                        out_bases[g] = rec;
+                        out_meta[g] = (row << META_ROW_SHIFT) | ((n - 1u) << META_D2_BITS) | (b & d2mask);
+                    }
                 }
             }
         }
-        lds_sync();
     }
     // every region's run of this chunk must end where the plan put the next chunk's: a plan that was computed for other reads
     // (KmerTable ties its cached plans to the stream; this is the backstop) shows here, and the count is void
