@@ -289,7 +289,7 @@ __global__ void mini_total_kernel(const unsigned long long *__restrict__ off, in
 
 // exclusive scan of cnt[0..N) -> start[0..N] by the first N / 64 wavefronts (N = 128 or 256); every lane of the workgroup calls
 template <int N, bool LDS_ONLY = false>
-__device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start, uint32_t *wave_tot)
+__device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start, uint32_t *wave_tot, uint32_t *start_copy = nullptr)
 {
     auto sync = [] { if (LDS_ONLY) lds_sync(); else __syncthreads(); };
     uint32_t v = 0, incl = 0;
@@ -308,6 +308,7 @@ __device__ __forceinline__ void scan_digits(const uint32_t *cnt, uint32_t *start
         uint32_t before = 0;
         for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += wave_tot[wv];
         start[threadIdx.x] = before + incl - v;
+        if (start_copy) start_copy[threadIdx.x] = before + incl - v;
         if (threadIdx.x == N - 1) start[N] = before + incl;
     }
     sync();
@@ -356,6 +357,7 @@ template <int N1> struct Scatter1Lds {                              // N1 region
     uint32_t starts[S1_BLOCK], ends[S1_BLOCK], r0[S1_BLOCK];        // RowBits of the lane (r0: bit 31 = inside0)
     uint32_t cnt[N1];
     uint32_t start[N1 + 1];
+    uint32_t fill[N1 + 64];                                         // start[], counted up as the references are placed (+ a dummy per lane)
     unsigned long long gbase[N1];
     unsigned long long cur[N1];                                     // running write offsets of this chunk, per region
     uint32_t wave_tot[N1 / 64];
@@ -389,7 +391,10 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         if (word_begin + round * ROUND_WORDS >= word_end) break;    // (uniform)
         if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
         lds_sync();                                                 // (also: the previous round's copy-out has read the lanes' words)
-        uint32_t dr[32];                                            // bucket << 16 | rank inside the region
+        // the bucket of the record that ends at position e.  The segmentation only COUNTS the records per region (LDS adds without
+        // return: nothing waits for them); places in the stage are handed out after the scan, 32 returning adds in flight at once
+        // (a returning add inside the segmentation was followed by a wait for the LDS, once per position)
+        uint32_t dr[32];                                            // (written where a record ends)
         uint32_t has = 0;
         LaneWord lw;
         lw.ok = 0; lw.ok_row = 0; lw.x.cw = lw.x.pw = 0;
@@ -399,7 +404,8 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         if (lw.ok) {
             rb.init(row_start, row_end, n_rows, row_start ? round_row[round] : 0, w << 5);
             mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int e, int, uint32_t b) {
-                dr[e] = (b << 16) | atomicAdd(&L.cnt[b >> bits2], 1u);
+                __hip_atomic_fetch_add(&L.cnt[b >> bits2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                dr[e] = b;
                 has |= 1u << e;
             });
         }
@@ -414,21 +420,21 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         L.ends[threadIdx.x] = rb.ends;
         L.r0[threadIdx.x] = rb.r0 | (rb.inside0 ? 0x80000000u : 0u);
         lds_sync();
-        scan_digits<N1, true>(L.cnt, L.start, L.wave_tot);
+        scan_digits<N1, true>(L.cnt, L.start, L.wave_tot, L.fill);
         const uint32_t total = L.start[N1];
         // a round has at most 32 x 512 records; 8 positions x 512 lanes always fit the stage.  Nearly every round fits whole.
         const int n_win = total <= (uint32_t)STAGE_CAP ? 1 : 4;
         for (int win = 0; win < n_win; ++win) {
             const uint32_t wmask = n_win == 1 ? 0xffffffffu : (0xffu << (8 * win));
-            if (n_win > 1) {                                        // rank again, this window's records only
+            if (n_win > 1) {                                        // count again, this window's records only
                 lds_sync();
                 if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
                 lds_sync();
 #pragma unroll
                 for (int e = 0; e < 32; ++e)
-                    if ((has & wmask) >> e & 1u) dr[e] = (dr[e] & 0xffff0000u) | atomicAdd(&L.cnt[dr[e] >> (16 + bits2)], 1u);
+                    if ((has & wmask) >> e & 1u) __hip_atomic_fetch_add(&L.cnt[dr[e] >> bits2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 lds_sync();
-                scan_digits<N1, true>(L.cnt, L.start, L.wave_tot);
+                scan_digits<N1, true>(L.cnt, L.start, L.wave_tot, L.fill);
             }
             // gbase[d] = (where the region's run goes) - (where it starts in the stage): the copy-out adds the stage position
             if (threadIdx.x < N1) {
@@ -437,13 +443,28 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 L.cur[threadIdx.x] += c;
             }
             {
+                // straight-line, four positions at a time: every lane issues every add (a position that ends no record adds 0
+                // to some counter), one wait, then the predicated writes
                 const uint32_t mine = (uint32_t)threadIdx.x << REF_LANE_SHIFT;
+                const uint32_t live = has & wmask;
+                // (dr[e] is only written where a record ends; the reads below are selected away everywhere else, and the values pass
+                // through an empty asm so that the compiler sees defined ones on every path)
 #pragma unroll
-                for (int e = 0; e < 32; ++e) {
-                    if ((has & wmask) >> e & 1u) {
-                        const uint32_t b = dr[e] >> 16;
-                        L.ref[L.start[b >> bits2] + (dr[e] & 0xffffu)] = mine | ((uint32_t)e << REF_E_SHIFT) | b;
+                for (int e = 0; e < 32; ++e) asm volatile("" : "+v"(dr[e]));
+#pragma unroll
+                for (int e0 = 0; e0 < 32; e0 += 4) {
+                    uint32_t pos[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // (a position that ends no record adds 0 to a counter of the lane's own behind the regions': the same
+                        // counter for everybody would serialise the wavefront's adds)
+                        const bool is = (live >> (e0 + q)) & 1u;
+                        const uint32_t at = is ? (dr[e0 + q] >> bits2) & (uint32_t)(N1 - 1) : (uint32_t)N1 + (threadIdx.x & 63u);
+                        pos[q] = __hip_atomic_fetch_add(&L.fill[at], is ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((live >> (e0 + q)) & 1u) L.ref[pos[q]] = mine | ((uint32_t)(e0 + q) << REF_E_SHIFT) | dr[e0 + q];
                 }
             }
             lds_sync();
