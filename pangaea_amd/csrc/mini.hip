@@ -105,13 +105,20 @@ struct RowBits {
     }
 };
 
-// emit(e, n, bucket): one record of n k-mers ending at characters e - n + 1 .. e of the word.  `cuts`: positions where the row
-// changes; ok_row: k-mer ends that count for rows (a record never mixes the two kinds)
+// The segmentation in two steps that the plan kernel and the scatter kernel share (they see the same records by construction):
+//   mini_minimizers   per_pos(p, mv) for p = 0 .. 31 (p a compile-time constant at every call): mv = the minimizer value of the
+//                     k-mer that ends at character p of the word;
+//   mini_record_ends  from the lane's validity masks and the mask of positions whose minimizer value equals their predecessor's:
+//                     the positions where a record ENDS.  Pure bit arithmetic on 32-bit masks: until round 4 the record logic
+//                     ran position by position (a counter, four comparisons, a predicated block per position that the whole
+//                     wavefront issued although a word has six or seven records).
+// A record's bucket is mini_bucket(mv of its last k-mer) -- all its k-mers share the value --, its length and row follow from where
+// it ends (the callers keep the bucket of EVERY position in an LDS column of the lane and walk over the set bits of the end mask).
 // DELAY (k > 21): the minimizer of a k-mer is taken over its central W M-mers only (pg_device.hpp: mini_window), i.e. the
 // window that ends `off` characters before the k-mer does -- the window minimum passes through a delay line of `off` <= 5 steps.
 constexpr int MINI_MAX_OFF = 5;
-template <int W, bool DELAY, int M, class Emit>
-__device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_t ok_row, uint32_t cuts, int k, int off, int bits, int cap, Emit &&emit)
+template <int W, bool DELAY, int M, class PerPos>
+__device__ __forceinline__ void mini_minimizers(const Word &x, int off, PerPos &&per_pos)
 {
     constexpr uint32_t MMASK = (1u << (2 * M)) - 1u;
     uint32_t win[W];                                            // win[0] = newest hashed canonical M-mer
@@ -152,23 +159,38 @@ __device__ __forceinline__ void mini_segment(const Word &x, uint32_t ok, uint32_
     };
 #pragma unroll
     for (int c = 32 - PRE; c < 32; ++c) step(c);
-    // a k-mer may continue the open record if it is valid, of the same kind (row-counting or not) as its predecessor and
-    // no row boundary lies at its last character -- and if it has the same minimizer (its bucket follows from that: the bucket
-    // is computed once per record, not per character)
-    const uint32_t same = ok & (ok << 1) & ~(ok_row ^ (ok_row << 1)) & ~cuts;
-    int n = 0;                                                  // k-mers of the open record (minimizer value cur_mv)
-    uint32_t cur_mv = 0;
 #pragma unroll
-    for (int p = 0; p < 32; ++p) {
-        const uint32_t mv = step(32 + p);
-        const bool v = (ok >> p) & 1u;
-        // the open record ends at p - 1 unless this k-mer continues it (a record cannot end before the word starts)
-        const bool cont = ((same >> p) & 1u) && n > 0 && mv == cur_mv && n < cap;
-        if (p > 0 && n > 0 && !cont) emit(p > 0 ? p - 1 : 0, n, mini_bucket(cur_mv, bits));
-        n = cont ? n + 1 : (v ? 1 : 0);
-        cur_mv = mv;
+    for (int p = 0; p < 32; ++p) per_pos(p, step(32 + p));
+}
+
+// bit p of the result: bits p - n + 1 .. p of m are all set (1 <= n <= 32)
+__device__ __forceinline__ uint32_t runs32(uint32_t m, int n)
+{
+    uint32_t r = m;
+    int len = 1;
+    while (2 * len <= n) { r &= r << len; len *= 2; }
+    if (len < n) r &= r << (n - len);
+    return r;
+}
+
+// Where the records of a word end.  ok / ok_row: positions that end a valid k-mer (for the table / for the rows), cuts: positions
+// where the row changes, eq: positions whose minimizer value equals that of the position before, cap: k-mers per record at most.
+// A k-mer CONTINUES the open record if it and its predecessor are valid and of the same kind (row-counting or not), no row boundary
+// lies at its last character and the minimizer value is the same (records never cross words: position 0 continues nothing) -- and
+// if the record has room: of `cap` continuations in a row the last one starts a new record instead (lowest first, as a counter
+// running over the positions would have it; rare -- a minimizer covers at most W = cap k-mers unless the same hashed M-mer recurs).
+__device__ __forceinline__ uint32_t mini_record_ends(uint32_t ok, uint32_t ok_row, uint32_t cuts, uint32_t eq, int cap)
+{
+    uint32_t cont = ok & (ok << 1) & ~(ok_row ^ (ok_row << 1)) & ~cuts & eq;
+    if (cap <= 1) cont = 0;
+    else {
+        uint32_t over = runs32(cont, cap);
+        while (over) {                                          // (cont has a run of `cap` bits: the record would hold cap + 1 k-mers)
+            cont &= ~(over & (0u - over));
+            over = runs32(cont, cap);
+        }
     }
-    if (n > 0) emit(31, n, mini_bucket(cur_mv, bits));
+    return ok & ~(cont >> 1);                                   // a record ends where the next position does not continue it
 }
 
 // what a lane needs to segment word w: the word, its valid k-mer ends under the counting rule and under the rows' strict rule
@@ -205,6 +227,7 @@ __global__ __launch_bounds__(BLOCK) void mini_plan_kernel(const uint64_t *__rest
 {
     __shared__ uint32_t coarse[1 << MINI_MAX_BITS1];
     __shared__ uint32_t n_long_here;                             // records of more than SHORT_MAX k-mers in this chunk
+    __shared__ uint16_t col[32 * BLOCK];                         // the bucket of every position of the lane's word (a column per lane)
     const int n_dig = 1 << (bits - bits2);
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         for (int i = threadIdx.x; i < (1 << MINI_MAX_BITS1); i += BLOCK) coarse[i] = 0;
@@ -218,12 +241,23 @@ __global__ __launch_bounds__(BLOCK) void mini_plan_kernel(const uint64_t *__rest
             if (lw.ok == 0) continue;
             RowBits rb;
             rb.init(row_start, row_end, n_rows, row_start ? round_row[wi / ROUND_WORDS] : 0, w << 5);
-            uint32_t longs = 0;
-            mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int, int n, uint32_t b) {
-                atomicAdd(&coarse[b >> bits2], 1u);
-                longs += n > PG_SHORT_MAX_ ? 1u : 0u;
+            uint32_t eq = 0, prev = 0;
+            mini_minimizers<W, DELAY, M>(lw.x, woff, [&](int p, uint32_t mv) {
+                eq |= mv == prev ? 1u << p : 0u;
+                prev = mv;
+                col[p * BLOCK + threadIdx.x] = (uint16_t)mini_bucket(mv, bits);
             });
-            if (longs) atomicAdd(&n_long_here, longs);
+            const uint32_t has = mini_record_ends(lw.ok, lw.ok_row, rb.cuts(), eq, cap);
+            // (the column is the lane's own: no barrier between its writes and these reads)
+            for (uint32_t m = has; m; m &= m - 1u)
+                atomicAdd(&coarse[(uint32_t)col[(uint32_t)__builtin_ctz(m) * BLOCK + threadIdx.x] >> bits2], 1u);
+            // records of more than SHORT_MAX k-mers: ends with SHORT_MAX positions in front of them that neither end a record nor
+            // fail to end a k-mer
+            const uint32_t nonk = has | ~lw.ok;
+            uint32_t lg = has & ~((1u << PG_SHORT_MAX_) - 1u);
+#pragma unroll
+            for (int q = 1; q <= PG_SHORT_MAX_; ++q) lg &= ~(nonk << q);
+            if (lg) atomicAdd(&n_long_here, (uint32_t)__popc(lg));
         }
         __syncthreads();
         if (threadIdx.x == 0 && n_long_here) atomicAdd(class_totals, (unsigned long long)n_long_here);     // header[2]: long records of the stream
@@ -351,13 +385,14 @@ constexpr int REF_E_SHIFT = 16, REF_LANE_SHIFT = 21;               // ref = lane
 static_assert(PG_MINI_MAX_LOG2_BUCKETS <= REF_E_SHIFT && S1_BLOCK <= (1 << (32 - REF_LANE_SHIFT)), "fields of a stage reference");
 template <int N1> struct Scatter1Lds {                              // N1 regions: 256, or 512 for a table of 2^16 buckets
     uint32_t ref[STAGE_CAP];
+    uint16_t col[32 * S1_BLOCK];                                    // the bucket of every position of the lanes' words (a column per lane)
     uint64_t cw[S1_BLOCK], pw[S1_BLOCK];                            // the lanes' words and the words before them
     uint32_t nonk[S1_BLOCK];                                        // positions that end a record or end no k-mer at all
     uint32_t ok_row[S1_BLOCK];                                      // k-mer ends that count for rows
     uint32_t starts[S1_BLOCK], ends[S1_BLOCK], r0[S1_BLOCK];        // RowBits of the lane (r0: bit 31 = inside0)
     uint32_t cnt[N1];
     uint32_t start[N1 + 1];
-    uint32_t fill[N1 + 64];                                         // start[], counted up as the references are placed (+ a dummy per lane)
+    uint32_t fill[N1];                                              // start[], counted up as the references are placed
     unsigned long long gbase[N1];
     unsigned long long cur[N1];                                     // running write offsets of this chunk, per region
     uint32_t wave_tot[N1 / 64];
@@ -391,23 +426,26 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
         if (word_begin + round * ROUND_WORDS >= word_end) break;    // (uniform)
         if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
         lds_sync();                                                 // (also: the previous round's copy-out has read the lanes' words)
-        // the bucket of the record that ends at position e.  The segmentation only COUNTS the records per region (LDS adds without
-        // return: nothing waits for them); places in the stage are handed out after the scan, 32 returning adds in flight at once
-        // (a returning add inside the segmentation was followed by a wait for the LDS, once per position)
-        uint32_t dr[32];                                            // (written where a record ends)
+        // The lane's word -> the bucket of every position (an LDS column of the lane's own) and the mask of the positions where a
+        // record ends; then the records are COUNTED per region, one LDS add without return per set bit (nothing waits for it).
         uint32_t has = 0;
         LaneWord lw;
         lw.ok = 0; lw.ok_row = 0; lw.x.cw = lw.x.pw = 0;
         if (w < word_end) lw = load_lane_word(codes, valid, strict, w, k);
         RowBits rb;
         rb.starts = rb.ends = rb.r0 = 0; rb.inside0 = false;
+        uint16_t *const mycol = L.col + threadIdx.x;
         if (lw.ok) {
             rb.init(row_start, row_end, n_rows, row_start ? round_row[round] : 0, w << 5);
-            mini_segment<W, DELAY, M>(lw.x, lw.ok, lw.ok_row, rb.cuts(), k, woff, bits, cap, [&](int e, int, uint32_t b) {
-                __hip_atomic_fetch_add(&L.cnt[b >> bits2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                dr[e] = b;
-                has |= 1u << e;
+            uint32_t eq = 0, prev = 0;
+            mini_minimizers<W, DELAY, M>(lw.x, woff, [&](int p, uint32_t mv) {
+                eq |= mv == prev ? 1u << p : 0u;
+                prev = mv;
+                mycol[p * S1_BLOCK] = (uint16_t)mini_bucket(mv, bits);
             });
+            has = mini_record_ends(lw.ok, lw.ok_row, rb.cuts(), eq, cap);
+            for (uint32_t m = has; m; m &= m - 1u)
+                __hip_atomic_fetch_add(&L.cnt[(uint32_t)mycol[(uint32_t)__builtin_ctz(m) * S1_BLOCK] >> bits2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         // what the copy-out needs of this lane's word: a record's length and row follow from where it ends -- it starts behind the
         // previous record's end or behind the last position that ends no valid k-mer, whichever is later; its k-mers share one
@@ -430,9 +468,8 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 lds_sync();
                 if (threadIdx.x < N1) L.cnt[threadIdx.x] = 0;
                 lds_sync();
-#pragma unroll
-                for (int e = 0; e < 32; ++e)
-                    if ((has & wmask) >> e & 1u) __hip_atomic_fetch_add(&L.cnt[dr[e] >> bits2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (uint32_t m = has & wmask; m; m &= m - 1u)
+                    __hip_atomic_fetch_add(&L.cnt[(uint32_t)mycol[(uint32_t)__builtin_ctz(m) * S1_BLOCK] >> bits2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 lds_sync();
                 scan_digits<N1, true>(L.cnt, L.start, L.wave_tot, L.fill);
             }
@@ -443,28 +480,21 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                 L.cur[threadIdx.x] += c;
             }
             {
-                // straight-line, four positions at a time: every lane issues every add (a position that ends no record adds 0
-                // to some counter), one wait, then the predicated writes
+                // the lane's records, two per turn: their buckets out of the column, their places in the stage from the regions'
+                // fill counters (a returning add each, both in flight together), the references written
                 const uint32_t mine = (uint32_t)threadIdx.x << REF_LANE_SHIFT;
-                const uint32_t live = has & wmask;
-                // (dr[e] is only written where a record ends; the reads below are selected away everywhere else, and the values pass
-                // through an empty asm so that the compiler sees defined ones on every path)
-#pragma unroll
-                for (int e = 0; e < 32; ++e) asm volatile("" : "+v"(dr[e]));
-#pragma unroll
-                for (int e0 = 0; e0 < 32; e0 += 4) {
-                    uint32_t pos[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        // (a position that ends no record adds 0 to a counter of the lane's own behind the regions': the same
-                        // counter for everybody would serialise the wavefront's adds)
-                        const bool is = (live >> (e0 + q)) & 1u;
-                        const uint32_t at = is ? (dr[e0 + q] >> bits2) & (uint32_t)(N1 - 1) : (uint32_t)N1 + (threadIdx.x & 63u);
-                        pos[q] = __hip_atomic_fetch_add(&L.fill[at], is ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if ((live >> (e0 + q)) & 1u) L.ref[pos[q]] = mine | ((uint32_t)(e0 + q) << REF_E_SHIFT) | dr[e0 + q];
+                uint32_t m = has & wmask;
+                while (m) {
+                    const uint32_t e0 = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    const bool two = m != 0u;
+                    const uint32_t e1 = two ? (uint32_t)__builtin_ctz(m) : e0;
+                    m &= m - 1u;                                    // (0 stays 0)
+                    const uint32_t b0 = mycol[e0 * S1_BLOCK], b1 = mycol[e1 * S1_BLOCK];
+                    const uint32_t p0 = __hip_atomic_fetch_add(&L.fill[b0 >> bits2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t p1 = __hip_atomic_fetch_add(&L.fill[b1 >> bits2], two ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    L.ref[p0] = mine | (e0 << REF_E_SHIFT) | b0;
+                    if (two) L.ref[p1] = mine | (e1 << REF_E_SHIFT) | b1;
                 }
             }
             lds_sync();

@@ -164,10 +164,14 @@ __device__ __forceinline__ uint32_t mhash(uint32_t x)
 {
     return __umul24(x ^ 0x5E3779u, 0xC2B2AFu);
 }
-// bucket of a minimizer value (the value itself is biased towards small numbers: mix once more, take the top bits)
+// bucket of a minimizer value.  The value is a minimum -- its HIGH bits are biased towards 0 --, but its low 24 bits are a
+// bijection of the minimizer M-mer's own low 24 bits (mhash: a product with an odd constant), as uniform as the M-mers are: one
+// more 24-bit product mixes them upwards and the top bits of its low dword are the bucket.  (v_mul_u32_u24 takes the low 24 bits of
+// its operands by itself and issues at full rate; the 32-bit product this replaces, v_mul_lo_u32, at a quarter of it -- and since
+// round 4 the bucket of EVERY position of the stream is computed, not one per record.)
 __device__ __forceinline__ uint32_t mini_bucket(uint32_t minv, int bits)
 {
-    return bits ? (minv * 0xC2B2AE3Du) >> (32 - bits) : 0u;
+    return bits ? (uint32_t)__umul24(minv, 0x9E3779u) >> (32 - bits) : 0u;       // (HIP declares __umul24 as returning int)
 }
 __device__ __forceinline__ uint32_t swap_pairs32(uint32_t x) { return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
 // order of the 32 two-bit characters of a word reversed
