@@ -140,7 +140,11 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
         t0 = t = time.perf_counter()
         # (pg_ingest_fastq_device: the parser threads copy finished pieces to the GPU while the others parse on; the shift of the
         # pieces into place is a kernel.  PANGAEA_INGEST_ON_HOST=1: host ingest, then one copy)
+        # (as feature.compute_features does: the pipeline's scratch is allocated by a helper thread while the host threads parse)
+        warm = kmer.prewarm_workspaces(dev, int(os.path.getsize(path) / 690 * 1.03) + 1, K_ABD, VSIZE)
         s = ReadStream.from_fastq(path, device=dev)
+        if warm is not None:
+            warm.join()
         torch.cuda.synchronize()
         lap["ingest+h2d"] = time.perf_counter() - t; t = time.perf_counter()
         regs = kmer.distinct_sketch(s, K_ABD)                 # (the sizing pass runs on the GPU while the host builds the rows)
@@ -156,17 +160,20 @@ def e2e_leg(stream, cfg, n_pairs: int, vae, dev) -> dict:
         lap["normalise+encode"] = time.perf_counter() - t
         return time.perf_counter() - t0, lap, tuple(mu.shape)
 
-    run(warm)                                           # first-call costs (code objects, allocator) stay out of the figure
+    run(warm)                                           # first-call costs of the PROCESS (code objects, streams) stay out of the figure
+    torch.cuda.empty_cache()                            # ... but not the allocations: the first pass below starts without cached blocks
     passes = [run(fq) for _ in range(2)]
-    total, lap, shape = min(passes, key=lambda r: r[0])
+    total, lap, shape = passes[0]                       # pangaea.py extracts features ONCE per data set: the first pass is the figure
     for f in (fq, warm):
         os.remove(f)
     os.rmdir(tmp)
     threads = min(32, len(os.sched_getaffinity(0)))
     return {"value": n / total, "unit": "pairs/s", "pairs": n, "fastq_bytes": size, "host_threads": threads,
-            "first_pass": n / passes[0][0], "seconds": {k: round(v, 4) for k, v in lap.items()}, "mu_shape": list(shape),
-            "what": "plain interleaved FASTQ file (page cache) -> ingest with the H2D copy of finished pieces under the parse -> table sizing + allocation + plan + count/lookups -> rows -> "
-                    "normalise -> encode, one GPU; value = the faster of two passes, first_pass = the first of them"}
+            "first_pass": n / passes[0][0], "best_of_two": n / min(p[0] for p in passes),
+            "seconds": {k: round(v, 4) for k, v in lap.items()}, "mu_shape": list(shape),
+            "what": "plain interleaved FASTQ file (page cache) -> ingest with the H2D copy of finished pieces under the parse (the pipeline's scratch allocated by a helper "
+                    "thread meanwhile) -> table sizing + allocation + plan + count/lookups -> rows -> normalise -> encode, one GPU; value = first_pass = the FIRST pass over "
+                    "the file with an empty allocator cache (what one Feature call costs), best_of_two = the faster of two passes"}
 
 
 def spawn_ranks(n: int) -> int:

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 7   /* 7: pg_build_flags (what kind of build a loaded library is), pg_mini_gather_entries names its buffer's size;
+#define PG_ABI_VERSION 7   /* 7: pg_build_flags (what kind of build a loaded library is), pg_mini_gather_entries names its buffer's size,
+                                 pg_mini_shuffle_bytes_merged;
                               6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
                               5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
                               4: pg_mini_records_bytes takes the table, status bits;
@@ -387,6 +388,10 @@ int pg_mini_plan(const uint64_t *codes, const uint32_t *valid, int64_t word_begi
                  const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *stream);
 int64_t pg_mini_records_bytes(int64_t n_records, const pg_table *t);
 int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vsize);
+/* the same for a caller that passes merge_ws to pg_mini_count: where the merged lookups apply (the library's own rule: the slot
+ * form, fewer than 2^20 rows, row and bin in 28 bits) and the row groups take one scatter pass, the row shuffle's buffer of
+ * provisional words is not part of the layout -- half the bytes (12 GB less per 10 M read pairs) */
+int64_t pg_mini_shuffle_bytes_merged(int64_t n_words, int64_t n_rows, int vsize, const pg_table *t);
 /* merge_ws (may be NULL: the word-wise lookups): pg_mini_merge_words() 4-byte words of device memory for the MERGED form of the
  * lookups (the default; PG_MINI_MERGE=0 in the environment or a NULL buffer: word-wise) -- the k-mers of a record that share row
  * and bin travel as one word with a count; the provisional data are the k-mers' 2-byte slot numbers in fixed places per record,

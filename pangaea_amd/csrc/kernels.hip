@@ -1796,7 +1796,9 @@ struct ShufflePlan {
     size_t emit_off, caps_off, goff_off, gcur1_off, gcur2_off, dhist_off, words_e_off, words_a_off, words_b_off, total;
 };
 
-int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, ShufflePlan *p, int one_pass_bits = WIDE_FAN_BITS)
+// no_input (callers that keep their provisional data elsewhere -- the merged lookups of mini.hip): when one scatter pass suffices the
+// first word buffer is not needed at all (12 GB per 10 M read pairs that were allocated and never touched)
+int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, ShufflePlan *p, int one_pass_bits = WIDE_FAN_BITS, int no_input = 0)
 {
     if (vsize < 1 || vsize > PG_SHUFFLE_MAX_VSIZE)
         return pg_fail(PG_EINVAL, "the shuffle path needs 1 <= vector size <= %d (got %d)", PG_SHUFFLE_MAX_VSIZE, vsize);
@@ -1822,7 +1824,7 @@ int plan_shuffle(int64_t cap, int64_t n_rows, int vsize, int64_t n_buckets, Shuf
     p->gcur2_off = take((size_t)p->n_groups_padded * 8);
     p->dhist_off = o;
     (void)n_buckets;
-    p->words_e_off = take((size_t)cap * 4);                              // emitted by the lookup pass, bucket order
+    p->words_e_off = take(no_input && p->gb2 == 0 ? 0 : (size_t)cap * 4);   // emitted by the lookup pass, bucket order
     p->words_a_off = take((size_t)cap * 4);                              // after the first row pass
     p->words_b_off = p->gb2 ? p->words_e_off : p->words_a_off;           // the second row pass reuses the first buffer
     p->total = o;
@@ -2253,10 +2255,10 @@ static int shuffle_tail(const ShufflePlan &sp, const unsigned long long *in_begi
 
 // for the other translation units (pg_internal.h): where the lookup pass of another pipeline leaves its words, and the
 // row shuffle that finishes them
-int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out, int one_pass_bits)
+int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out, int one_pass_bits, int no_input)
 {
     ShufflePlan sp;
-    int rc = plan_shuffle(cap, n_rows, vsize, 0, &sp, one_pass_bits);
+    int rc = plan_shuffle(cap, n_rows, vsize, 0, &sp, one_pass_bits, no_input);
     if (rc) return rc;
     out->vbits = sp.vbits;
     out->emit_off = sp.emit_off;
@@ -2457,10 +2459,10 @@ int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize, int on
 }
 
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
-                                pg_shuffle_ctx *ctx, int one_pass_bits)
+                                pg_shuffle_ctx *ctx, int one_pass_bits, int no_input)
 {
     ShufflePlan sp;
-    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits);
+    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits, no_input);
     if (rc) return rc;
     if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
     char *ws = (char *)workspace;
@@ -2479,10 +2481,10 @@ int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, voi
 }
 
 int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
-                               int word_form, int one_pass_bits)
+                               int word_form, int one_pass_bits, int no_input)
 {
     ShufflePlan sp;
-    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits);
+    int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits, no_input);
     if (rc) return rc;
     if ((int64_t)sp.total > workspace_bytes) return pg_fail(PG_EINVAL, "row shuffle: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)sp.total);
     if (rows->n_rows == 0) return PG_OK;

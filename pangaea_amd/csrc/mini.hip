@@ -1913,6 +1913,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_lookup_half_kernel(const unsigned
                                                                 int log2_bucket, int vbits, const uint32_t *__restrict__ prov, ShufArgs sh, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (*status & PG_STATUS_OVERFLOW_LIST) return;               // (the exchange did not take place: dist.MiniSharded.exchange; no bins to read)
     const uint32_t n_slots = 1u << log2_bucket, smask = n_slots - 1u;
     const uint32_t n_occ = n_slots >= 64u ? n_slots >> 6 : 1u;
     const uint32_t np_all = (uint32_t)kwords[blockIdx.x];
@@ -1964,6 +1965,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_lookup_half_merge_kernel(const un
                                                                       const uint32_t *__restrict__ meta, ShufArgs sh, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (*status & PG_STATUS_OVERFLOW_LIST) return;               // (the exchange did not take place: dist.MiniSharded.exchange; no bins to read)
     const uint32_t n_slots = 1u << log2_bucket, smask = n_slots - 1u;
     const uint32_t n_occ = n_slots >= 64u ? n_slots >> 6 : 1u;
     const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
@@ -2184,6 +2186,20 @@ extern "C" int64_t pg_mini_shuffle_bytes(int64_t n_words, int64_t n_rows, int vs
     return (int64_t)(sl.total > sl1.total ? sl.total : sl1.total);
 }
 
+// the same for a caller that brings the merged lookups' slot buffer (pg_mini_merge_words): where that form applies and the row
+// groups take one scatter pass, the provisional-word buffer of the row shuffle is not part of the layout (half the bytes)
+extern "C" int64_t pg_mini_shuffle_bytes_merged(int64_t n_words, int64_t n_rows, int vsize, const pg_table *t)
+{
+    int rc = check_mini(t, "pg_mini_shuffle_bytes_merged");
+    if (rc) return rc;
+    if (n_words < 0 || n_rows < 0) return pg_fail(PG_EINVAL, "negative size");
+    pg_rows r{nullptr, nullptr, n_rows, nullptr};
+    if (!mini_merge_form(t, &r, vsize)) return pg_mini_shuffle_bytes(n_words, n_rows, vsize);
+    pg_shuffle_layout sl;
+    if ((rc = pg_internal_shuffle_layout(n_words * 32, n_rows, vsize, &sl, MINI_ONE_PASS_BITS, 1))) return rc;
+    return (int64_t)sl.total;
+}
+
 // the first-pass kernels are instantiated per window length (registers of the rolling minimum); k > 21 runs the delayed
 // central window of 8 or 9 M-mers (mini_window)
 #define PG_MINI_DISPATCH_W(K_, CALL)                                                                                        \
@@ -2321,7 +2337,8 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
         return pg_fail(PG_EHIP, "pg_mini_count: memset failed");
     pg_shuffle_layout sl{0, 0, 0, 0, 0};
     if (window > 0) {
-        if ((rc = pg_internal_shuffle_layout((word_end - word_begin) * 32, rows->n_rows, vsize, &sl, mini_slots_form(t, rows) ? MINI_ONE_PASS_BITS : PG_SHUFFLE_ONE_PASS_BITS)))
+        if ((rc = pg_internal_shuffle_layout((word_end - word_begin) * 32, rows->n_rows, vsize, &sl, mini_slots_form(t, rows) ? MINI_ONE_PASS_BITS : PG_SHUFFLE_ONE_PASS_BITS,
+                                             merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize) ? 1 : 0)))
             return rc;
         if ((int64_t)sl.total > shuffle_ws_bytes || (reinterpret_cast<uintptr_t>(shuffle_ws) & 255) != 0)
             return pg_fail(PG_EINVAL, "pg_mini_count: shuffle workspace of %lld bytes (256-byte aligned), %lld needed", (long long)shuffle_ws_bytes, (long long)sl.total);
@@ -2391,7 +2408,7 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     if (slots_form) {
         // the count kernel scatters its words into the row shuffle's group regions itself: offsets and cursors must be ready
         pg_shuffle_ctx ctx;
-        if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS))) return rc;
+        if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS, merge ? 1 : 0))) return rc;
         sh = ShufArgs{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, merge ? 0 : ctx.narrow, ctx.words_cap};
         words_a = ctx.words_in;                          // the provisional words wait in the shuffle's input buffer
         const size_t lookup_lds = merge ? (half_block ? MergeLds<512, 1024>::END : sh.gb1 > 10 ? MergeLds<BIG_BLOCK, 2048>::END : MergeLds<BIG_BLOCK, 1024>::END)
@@ -2570,9 +2587,9 @@ extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, c
     if (!p.bits2) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: needs more than 256 buckets");
     // the row shuffle's regions: offsets and cursors as the count half's launch prepared them (same layout call)
     pg_shuffle_ctx ctx;
-    if ((rc = pg_internal_shuffle_prepare(n_words_counted * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS))) return rc;
-    if (ctx.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: %d first-pass digits of the row shuffle", ctx.gb1);
     const bool merge = merge_ws && merge_ws_words > 0 && mini_merge_form(local, rows, vsize);         // (as the count half decided)
+    if ((rc = pg_internal_shuffle_prepare(n_words_counted * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS, merge ? 1 : 0))) return rc;
+    if (ctx.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_lookup_half: %d first-pass digits of the row shuffle", ctx.gb1);
     const ShufArgs sh{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, merge ? 0 : ctx.narrow, ctx.words_cap};
     const unsigned nb = 1u << p.bits;
     const auto *occ = (const unsigned long long *)((const char *)half_ws + hl.occ_off);
@@ -2641,7 +2658,7 @@ extern "C" int pg_mini_abundance_from_emitted(const pg_table *t, const pg_rows *
         return pg_internal_shuffle_finish(n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream,
                                           mini_merge_form(t, rows, vsize) ? PG_SHUFFLE_WORDS_COUNTED
                                           : pg_internal_shuffle_is_narrow(n_words_counted * 32, rows->n_rows, vsize, MINI_ONE_PASS_BITS) ? PG_SHUFFLE_WORDS_NARROW
-                                          : PG_SHUFFLE_WORDS_PLAIN, MINI_ONE_PASS_BITS);
+                                          : PG_SHUFFLE_WORDS_PLAIN, MINI_ONE_PASS_BITS, mini_merge_form(t, rows, vsize) ? 1 : 0);
     const auto *wbeg = (const unsigned long long *)((const char *)plan_ws + p.wbeg_off);
     return pg_internal_shuffle_rows(wbeg, 1 << p.bits, n_words_counted * 32, rows, vsize, abd_out, shuffle_ws, shuffle_ws_bytes, stream);
 }

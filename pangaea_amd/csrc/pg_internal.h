@@ -29,7 +29,9 @@ struct pg_shuffle_layout {
 // one_pass_bits: up to 2^one_pass_bits row groups the first scatter is the only one (PG_SHUFFLE_ONE_PASS_BITS = what the scatter kernels of
 // kernels.hip manage; a lookup pass that scatters by itself may manage more and must then name the same number in every call)
 #define PG_SHUFFLE_ONE_PASS_BITS 10
-int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
+// no_input: the caller keeps its provisional data elsewhere (the merged lookups): with one scatter pass the first word buffer is
+// left out of the layout (every call on one workspace must say the same)
+int pg_internal_shuffle_layout(int64_t cap, int64_t n_rows, int vsize, pg_shuffle_layout *out, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS, int no_input = 0);
 // a lookup pass that scatters its (row, bin) words by row group itself (mini.hip): prepare fills `ctx` and clears the cursors;
 // the pass puts a word whose first digit is d = (word >> dshift) & (2^gb1 - 1) at words_out[goff[d << gb2] + (atomicAdd on
 // gcur1[d])]; finish runs what is left (second pass for more than 2^one_pass_bits row groups, row histograms).
@@ -52,9 +54,9 @@ struct pg_shuffle_ctx {
 #define PG_SHUFFLE_COUNT_SHIFT 28
 int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);       // what prepare will put into ctx->narrow
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
-                                pg_shuffle_ctx *ctx, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
+                                pg_shuffle_ctx *ctx, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS, int no_input = 0);
 int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
-                               int word_form, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);
+                               int word_form, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS, int no_input = 0);
 int pg_internal_shuffle_rows(const unsigned long long *in_begin, int nb, int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out,
                              void *workspace, int64_t workspace_bytes, void *stream);
 

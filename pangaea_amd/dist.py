@@ -592,8 +592,19 @@ class MiniSharded:
         self.exchange()
         self.lookup_half()
         if check:
-            self.check_status()
+            bits = self.status_bits()
+            if bits & self._overflow_bit():
+                # the parts of this batch did not fit the size kept from an earlier one (``exchange``): ask again, count again
+                self._cap1 = None
+                self.local.status.zero_(); self.union.status.zero_()
+                return self.count(stream, plan, check=True)
+            self.check_status(bits)
         return self
+
+    @staticmethod
+    def _overflow_bit() -> int:
+        from . import _lib
+        return _lib.STATUS_OVERFLOW_LIST
 
     def count_half(self, stream: ReadStream, plan) -> None:
         """plan -> first and second scatter pass -> the bucket workgroups' count half (this rank's reads only)"""
@@ -602,7 +613,13 @@ class MiniSharded:
 
     def exchange(self) -> None:
         """entries -> owners (all-to-all, 8 bytes per distinct k-mer of this rank) -> merged inside LDS by the owners, which keep the
-        slices of the global table -> the bins of exactly the entries received, in order, back (all-to-all, 2 bytes each)"""
+        slices of the global table -> the bins of exactly the entries received, in order, back (all-to-all, 2 bytes each).
+
+        The collectives move equal parts, padded to ``cap1`` entries per (sender, owner).  The FIRST exchange of an object reads
+        the longest part from the device (a host wait) and keeps it with 3 % of slack; every later one reuses that size without
+        asking -- no host wait inside a step of a stream of batches.  A batch whose longest part does not fit is not exchanged at
+        all (the fills are zeroed on the device, PG_STATUS_OVERFLOW_LIST is raised in the status word, the lookup half returns at
+        once): ``count``/``check_status`` see the bit, forget the size and the count is done again."""
         from . import _lib
         group = self.group
         world, me = dist.get_world_size(group), dist.get_rank(group)
@@ -611,16 +628,36 @@ class MiniSharded:
         nb = loc.n_buckets
         dev = fill.device
         L = _lib.load()
+        cuts = [nb * o // world for o in range(world + 1)]
+        const = getattr(self, "_exchange_const", None)
+        if const is None or const[0] != (nb, world, str(dev)):
+            # (what depends on the geometry alone: built once, not copied to the device in every step)
+            cut_idx = torch.tensor(cuts, device=dev, dtype=torch.int64)
+            which = torch.bucketize(torch.arange(nb, device=dev), cut_idx[1:-1].contiguous(), right=True)
+            const = self._exchange_const = ((nb, world, str(dev)), cut_idx, which)
+        _, cut_idx, which = const
         fills = torch.empty((world, nb), dtype=torch.int64, device=dev)
         _all_gather_flat(fills.view(-1), fill, group)
-        seg = torch.zeros((world, nb + 1), dtype=torch.int64, device=dev)
-        seg[:, 1:] = torch.cumsum(fills, dim=1)
-        cuts = [nb * o // world for o in range(world + 1)]
-        at = seg[:, cuts]                                                            # [part, world + 1]
-        sizes = at[:, 1:] - at[:, :-1]                                               # [part, owner]
-        cap1 = max(8, (int(sizes.max().item()) + 7) // 8 * 8)                        # host sync: buffer size (the step's only one)
-        which = torch.bucketize(torch.arange(nb, device=dev), torch.tensor(cuts[1:-1], device=dev, dtype=torch.int64), right=True)
-        elem = (which * cap1 + seg[me, :-1] - at[me][which]).contiguous()            # where bucket b's entries (and, later, bins) lie
+
+        def parts(f):
+            seg = torch.zeros((world, nb + 1), dtype=torch.int64, device=dev)
+            seg[:, 1:] = torch.cumsum(f, dim=1)
+            at = seg.index_select(1, cut_idx)                                        # [part, world + 1]
+            return seg, at, at[:, 1:] - at[:, :-1]                                   # sizes: [part, owner]
+
+        seg, at, sizes = parts(fills)
+        cap1 = getattr(self, "_cap1", None)
+        if cap1 is None:
+            longest = int(sizes.max().item())                                        # host wait: once per object (or after an overflow)
+            cap1 = self._cap1 = max(8, (longest + longest // 32 + 7) // 8 * 8)
+        else:
+            # the same for every rank (the fills are all-gathered): too long a part -> nothing is exchanged, everybody raises the bit
+            fits = (sizes.max() <= cap1)
+            loc.status[0] |= (~fits).to(loc.status.dtype) * _lib.STATUS_OVERFLOW_LIST
+            fills = fills * fits.to(fills.dtype)
+            fill = fill * fits.to(fill.dtype)
+            seg, at, sizes = parts(fills)
+        elem = (which * cap1 + seg[me, :-1] - at[me].index_select(0, which)).contiguous()   # where bucket b's entries (and, later, bins) lie
         send = torch.empty(world * cap1, dtype=torch.int64, device=dev)
         stream_ptr = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -664,11 +701,15 @@ class MiniSharded:
         if bits & _lib.STATUS_PLAN_MISMATCH:
             self.local._mini_plan = None
             raise RuntimeError("the partition plan did not describe the stream on some rank (PG_STATUS_PLAN_MISMATCH): nothing was counted")
-        return bool(bits & (_lib.STATUS_TABLE_FULL | _lib.STATUS_OVERFLOW_LIST))
+        if bits & _lib.STATUS_OVERFLOW_LIST:
+            self._cap1 = None
+            raise RuntimeError("a part of the exchange was longer than the size kept from an earlier batch (PG_STATUS_OVERFLOW_LIST): nothing was "
+                               "exchanged -- count again (MiniSharded.count(check=True) does)")
+        return bool(bits & _lib.STATUS_TABLE_FULL)
 
-    def check_status(self) -> None:
+    def check_status(self, bits: int | None = None) -> None:
         from . import _lib
-        if self.any_full():
+        if self.any_full(bits):
             raise _lib.PangaeaError(_lib.PG_ETABLEFULL, "a bucket of the local or of the merged table is full")
 
     def owned_items(self):

@@ -130,10 +130,21 @@ def compute_features(reads1: str, reads2: str | None, k: int, k_tnf: int, window
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     world = torch.distributed.get_world_size() if pdist.is_distributed() else 1
+    from . import kmer as _kmer
+    # the scratch of the counting pipeline is allocated while the host threads parse (hipMalloc of tens of GB is most of what a
+    # FIRST pass over a data set costs besides its kernels): sizes from the file size, ~690 bytes of plain FASTQ per 150 bp pair
+    warm = None
+    if want_abd and table is None and not any(str(p).endswith(".gz") for p in (reads1, reads2) if p):
+        try:
+            fbytes = sum(os.path.getsize(p) for p in (reads1, reads2) if p)
+            warm = _kmer.prewarm_workspaces(device, int(fbytes / 690 / world * 1.03) + 1, k, vsize)
+        except OSError:
+            warm = None
     stream = _ingest(reads1, reads2, world, stream_cache, device).to(device)
+    if warm is not None:
+        warm.join()
     # one rank: the table's sizing pass (a HyperLogLog sketch of the distinct k-mers) is launched first and runs on the GPU while
     # the host assembles the rows
-    from . import kmer as _kmer
     sketch = None
     if world == 1 and want_abd and table is None and _kmer.KmerTable.default_kind(k) != "dense":
         sketch = _kmer.distinct_sketch(stream, k, lowercase_is_base=lowercase_is_base)

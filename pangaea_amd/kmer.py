@@ -416,7 +416,10 @@ class KmerTable:
             window, vsize, sws_ptr, sws_n = 0, 0, None, 0
             if fuse:
                 window, vsize = int(emit[0]), int(emit[1])
-                need = _lib.check(L.pg_mini_shuffle_bytes(n_words, keep.n_rows, vsize))
+                # (with the merged lookups the provisional data live in their own buffer below: the row shuffle's layout is smaller)
+                merging = os.environ.get("PG_MINI_MERGE", "1") not in ("", "0")
+                need = _lib.check(L.pg_mini_shuffle_bytes_merged(n_words, keep.n_rows, vsize, self.desc()) if merging
+                                  else L.pg_mini_shuffle_bytes(n_words, keep.n_rows, vsize))
                 if self._shuffle_ws is None or self._shuffle_ws.numel() < need:
                     self._shuffle_ws = None
                     self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -940,6 +943,56 @@ def count_kmers(stream: ReadStream, k: int, kind: str | None = None, distinct_hi
                 lb = 0
             del table
             table = KmerTable.with_slots(k, stream.device, log2, lb)
+
+
+# ---------------------------------------------------------------------------------------- workspaces ahead of the data
+
+def prewarm_workspaces(device, n_pairs: int, k: int, vsize: int, read_len: int = 150):
+    """Start the allocation of the scratch buffers that the super-k-mer pipeline will ask for, on a helper thread, and return the
+    thread (``join()`` it before counting; a data set that turns out larger simply allocates again).
+
+    What a FIRST pass over a data set costs besides its kernels is mostly ``hipMalloc``: record buffers, slot buffer and the row
+    shuffle's words are tens of GB at BASELINE sizes (38 GB per 10 M read pairs), their sizes follow from the number of read pairs
+    within a few percent, and the ingest -- host threads parsing FASTQ -- leaves the GPU's driver idle meanwhile.  The buffers
+    are allocated through torch's caching allocator and given straight back to it: the later requests (same thread or not, same
+    stream) are served from those blocks (a larger block is split).  ``pangaea.py`` extracts features once per data set
+    (/root/reference/src/pangaea.py:70), so the first pass IS the user's pass.  Only for 13 <= k <= 31 (the pipeline that
+    needs the buffers); PANGAEA_PREWARM=0 turns it off."""
+    import threading
+    if not (_lib.MINI_MIN_K <= k <= _lib.WIDE_MAX_K) or n_pairs <= 0 or os.environ.get("PANGAEA_PREWARM", "1") in ("", "0"):
+        return None
+    device = torch.device(device)
+    if device.type != "cuda":
+        return None
+    L = _lib.load()
+    n_words = (n_pairs * 2 * (read_len + 1) + 31) // 32
+    n_words = (n_words + _lib.WORD_ALIGN - 1) // _lib.WORD_ALIGN * _lib.WORD_ALIGN
+    m = 13 if k >= 16 else 11                        # (pg_device.hpp: mini_m)
+    w = min(k - m + 1, 9)
+    records = int(n_words * (32.0 / ((w + 1) / 2.0) + 1.0) * 0.9)     # (k = 21: 6.7 per word; measured 6.45)
+    kind = _lib.TABLE_MINI if k <= _lib.HASH_MAX_K else _lib.TABLE_MINI_WIDE
+    lb = _lib.BUCKET_MAX_LOG2_SLOTS if k <= _lib.HASH_MAX_K else _lib.MINI_WIDE_MAX_LOG2_BUCKET_SLOTS
+    desc = _lib.pg_table(kind, k, lb + 15, lb, None)
+    n_rows = max(1, n_pairs // 100)
+    sizes = []
+    try:
+        sizes.append(_lib.check(L.pg_mini_records_bytes(records, C.byref(desc))))
+        sizes.append(_lib.check(L.pg_mini_shuffle_bytes_merged(n_words, n_rows, vsize, C.byref(desc))))
+        sizes.append(4 * _lib.check(L.pg_mini_merge_words(n_words, records, records // 2, C.byref(desc))))
+    except _lib.PangaeaError:
+        return None
+
+    def work():
+        try:
+            with torch.cuda.device(device):
+                held = [torch.empty(int(b), dtype=torch.uint8, device=device) for b in sizes]
+                del held
+        except RuntimeError:                         # (out of memory: the pipeline will say so itself, with its real sizes)
+            pass
+
+    th = threading.Thread(target=work, name="pangaea-prewarm", daemon=True)
+    th.start()
+    return th
 
 
 # ---------------------------------------------------------------------------------------- TNF columns

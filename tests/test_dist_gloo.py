@@ -499,6 +499,14 @@ def _mini_sharded_worker(rank, world, port, outdir, backend, saturate):
         ms.count(part, plan)
         _, abd2 = kmer.features(part, plan, k_tnf=None, table=ms.local, window=10, vsize=400)
         assert torch.equal(abd2, abd)
+        # the exchange keeps the part size of the first batch and does not ask the device again: a batch that does not fit it is
+        # not exchanged, the status word says so on every rank, and count() sizes and counts again
+        kept = ms._cap1
+        ms._cap1 = 8
+        ms.count(part, plan)
+        assert ms._cap1 == kept
+        _, abd3 = kmer.features(part, plan, k_tnf=None, table=ms.local, window=10, vsize=400)
+        assert torch.equal(abd3, abd)
     finally:
         dist.destroy_process_group()
 
