@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define PG_ABI_VERSION 7   /* 7: pg_build_flags (what kind of build a loaded library is), pg_mini_gather_entries names its buffer's size,
-                                 pg_mini_shuffle_bytes_merged;
+                                 pg_mini_shuffle_bytes_merged, a stream counted in pieces (pg_mini_count_piece / pg_mini_lookup_*);
                               6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
                               5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
                               4: pg_mini_records_bytes takes the table, status bits;
@@ -397,6 +397,27 @@ int64_t pg_mini_shuffle_bytes_merged(int64_t n_words, int64_t n_rows, int vsize,
  * and bin travel as one word with a count; the provisional data are the k-mers' 2-byte slot numbers in fixed places per record,
  * sized from the plan's record counts (the plan workspace's first 8-byte word: records; third: records of more than 4 k-mers). */
 int64_t pg_mini_merge_words(int64_t n_words, int64_t n_records, int64_t n_long_records, const pg_table *t);
+
+/* ---- a stream counted in PIECES (one GPU, packed mini tables, the merged lookups): the scratch of pg_mini_count grows with the
+ * stream (about 3.4 KB per 150 bp read pair); a stream too large for one piece is counted word range by word range.  The reference
+ * streams one barcode group at a time in O(group) memory (count_tnf.cpp:257-271) and needs the finished jellyfish table before the
+ * first lookup (count_kmer.cpp:139-170); here every piece is planned, partitioned and counted INTO the table's buckets (the bucket's
+ * slice is loaded into LDS, counted on, written back: slots keep their places), leaving only its 2-byte provisional slots and the
+ * meta words of its records behind; when the table is final the pieces' slots are looked up in it:
+ *   pg_mini_plan(codes, valid, w0, w1, ...)      the piece's plan (its own plan_ws, kept until the lookups)
+ *   pg_mini_count_piece(... first ...)          plan_ws, rec_ws, merge_ws of THIS piece; first != 0 for the first piece of a fresh table
+ *   (keep: plan_ws, merge_ws and the second meta plane of rec_ws -- records x 4 bytes -- of every piece)
+ *   pg_mini_lookup_begin(t, rows, n_words_total, vsize, shuffle_ws, ...)   once; shuffle_ws: pg_mini_shuffle_bytes_merged(n_words_total, ...)
+ *   pg_mini_lookup_piece(...)                   per piece, any order
+ *   pg_mini_abundance_from_emitted(t, rows, vsize, abd, <a plan_ws of pg_mini_plan_bytes(n_words_total)>, ..., n_words_total, shuffle_ws, ...)
+ * rows: the rows of the WHOLE stream (their positions are absolute). */
+int pg_mini_count_piece(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                        const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                        int window, int vsize, void *merge_ws, int64_t merge_ws_words, int first, uint32_t *status, void *stream);
+int pg_mini_lookup_begin(const pg_table *t, const pg_rows *rows, int64_t n_words_total, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *stream);
+int pg_mini_lookup_piece(const pg_table *t, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_piece,
+                         const uint32_t *meta, int64_t n_words_total, int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes,
+                         const void *merge_ws, uint32_t *status, void *stream);
 int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
                   const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
                   int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *merge_ws, int64_t merge_ws_words,

@@ -139,6 +139,9 @@ def load() -> C.CDLL:
         "pg_mini_shuffle_bytes_merged": (i64, [i64, i64, i32, tp]),
         "pg_mini_count": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, vp, i64, i32, i32, vp, i64, vp, i64, vp, vp]),
         "pg_mini_merge_words": (i64, [i64, i64, i64, tp]),
+        "pg_mini_count_piece": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, vp, i64, i32, i32, vp, i64, i32, vp, vp]),
+        "pg_mini_lookup_begin": (i32, [tp, rp, i64, i32, vp, i64, vp]),
+        "pg_mini_lookup_piece": (i32, [tp, rp, vp, i64, i64, vp, i64, i32, i32, vp, i64, vp, vp, vp]),
         "pg_mini_half_bytes": (i64, [tp]),
         "pg_mini_count_half": (i32, [vp, vp, i64, i64, tp, rp, vp, i64, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp]),
         "pg_mini_gather_entries": (i32, [tp, vp, i64, vp, vp, vp, i64, vp, vp]),
@@ -174,7 +177,7 @@ EXPORTS = ["pg_abi_version", "pg_build_flags", "pg_last_error", "pg_device_count
            "pg_pack_ascii", "pg_pack_ascii_lower", "pg_plan_segments", "pg_tnf_ncols", "pg_tnf_colmap", "pg_kmer_count", "pg_kmer_distinct_sketch", "pg_kmer_count_workspace_bytes",
            "pg_kmer_count_bucketed", "pg_kmer_merge", "pg_kmer_merge_bucketed", "pg_kmer_rebuild_bucketed", "pg_kmer_rebuild_bucketed_range", "pg_table_bucket_fill", "pg_kmer_count_deferred", "pg_deferred_gather", "pg_deferred_gather_planes", "pg_kmer_rebuild_planes_range", "pg_table_bucket_fill_range", "pg_table_compact_planes_range", "pg_table_compact", "pg_kmer_merge_wide", "pg_abundance_workspace_bytes",
            "pg_abundance_from_records", "pg_abundance_from_emitted", "pg_kmer_count_bucketed_emit",
-           "pg_mini_plan_bytes", "pg_mini_plan", "pg_mini_records_bytes", "pg_mini_shuffle_bytes", "pg_mini_shuffle_bytes_merged", "pg_mini_merge_words", "pg_mini_count", "pg_mini_half_bytes", "pg_mini_count_half", "pg_mini_gather_entries", "pg_mini_merge_bins", "pg_mini_lookup_half", "pg_mini_wait_first_pass", "pg_mini_abundance_from_emitted",
+           "pg_mini_plan_bytes", "pg_mini_plan", "pg_mini_records_bytes", "pg_mini_shuffle_bytes", "pg_mini_shuffle_bytes_merged", "pg_mini_merge_words", "pg_mini_count_piece", "pg_mini_lookup_begin", "pg_mini_lookup_piece", "pg_mini_count", "pg_mini_half_bytes", "pg_mini_count_half", "pg_mini_gather_entries", "pg_mini_merge_bins", "pg_mini_lookup_half", "pg_mini_wait_first_pass", "pg_mini_abundance_from_emitted",
            "pg_features", "pg_normalize_rows", "pg_write_csv_gz", "pg_extract_reads"]
 
 

@@ -2459,7 +2459,7 @@ int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize, int on
 }
 
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
-                                pg_shuffle_ctx *ctx, int one_pass_bits, int no_input)
+                                pg_shuffle_ctx *ctx, int one_pass_bits, int no_input, int ctx_only)
 {
     ShufflePlan sp;
     int rc = plan_shuffle(cap, rows->n_rows, vsize, 0, &sp, one_pass_bits, no_input);
@@ -2476,7 +2476,7 @@ int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, voi
     ctx->dshift = sp.vbits + GROUP_ROWS_LOG2 + sp.gb2;
     ctx->narrow = pg_internal_shuffle_is_narrow(cap, rows->n_rows, vsize, one_pass_bits);
     ctx->words_cap = (unsigned long long)cap;
-    if (rows->n_rows == 0) return PG_OK;
+    if (rows->n_rows == 0 || ctx_only) return PG_OK;             // (ctx_only: offsets and cursors are in use already -- a further launch into them)
     return shuffle_prepare(sp, rows, ws, (hipStream_t)stream);
 }
 

@@ -1209,11 +1209,17 @@ __device__ __forceinline__ void merged_lookup(const MergeCtx &c)
 //   * what the lookup half needs to find the bucket's provisional words (merged form: slots) again: where they start (`wbeg`)
 //     (`ring_cnt`: the singles of the merged form's first layout; always 0 since the general insert writes into fixed places).
 // mini_lookup_half_kernel finishes the bucket once the owner has answered with the bins of exactly these entries, in order.
+// PIECES (one GPU, a stream counted in several word ranges because its scratch would not fit in one piece: pg_mini_count_piece):
+// the same count half, but on the TABLE's own buckets -- the bucket's slice is loaded into LDS first (accum = 2; the first piece
+// starts from an empty table: accum = 1), counted on, and written back; the slots keep their places from piece to piece (nothing
+// ever leaves a slot), so the provisional slots of every piece stay valid until mini_lookup_slice_merge_kernel has looked them up
+// in the final table.
 struct HalfArgs {
     unsigned long long *ent;                                     // bucket b: entries from b << log2 bucket slots
     unsigned long long *occ;                                     // bucket b: max(1, bucket slots / 64) words from b * that
     long long *fill;                                             // [buckets]
     uint32_t *ring_cnt;                                          // [buckets]
+    int accum;                                                   // 0: N-rank count half; 1, 2: a piece (see above)
 };
 template <int CAP, bool SLOTS, bool WIDE, int BLK, int DIG, bool MERGE = false, bool HALF = false>
 __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ meta,
@@ -1223,7 +1229,7 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
                                                                uint32_t window, uint32_t vsize, int vbits, uint32_t *__restrict__ words,
                                                                uint32_t *__restrict__ prov, unsigned long long *__restrict__ word_cursor,
                                                                unsigned long long *__restrict__ wbeg, unsigned long long *__restrict__ emit_end,
-                                                               ShufArgs sh, MergeArgs mg, unsigned long long rec_cap, uint32_t *status, HalfArgs hv = HalfArgs{nullptr, nullptr, nullptr, nullptr})
+                                                               ShufArgs sh, MergeArgs mg, unsigned long long rec_cap, uint32_t *status, HalfArgs hv = HalfArgs{nullptr, nullptr, nullptr, nullptr, 0})
 {
     static_assert(!MERGE || SLOTS, "merged words are a form of the slot lookups");
     static_assert(!HALF || (SLOTS && !WIDE), "the count half is a form of the slot lookups on packed slots");
@@ -1276,7 +1282,11 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #define PG_STAMP(K) do { } while (0)
 #define PG_WLAP(K) do { } while (0)
 #endif
-    for (uint32_t i = threadIdx.x; i < tab_units; i += BLK) tab[i] = 0ull;
+    if (HALF && hv.accum == 2) {                                 // (a later piece: the bucket as the pieces before left it)
+        for (uint32_t i = threadIdx.x; i < tab_units; i += BLK) tab[i] = i < n_slots ? (unsigned long long)slice[i] : 0ull;
+    } else {
+        for (uint32_t i = threadIdx.x; i < tab_units; i += BLK) tab[i] = 0ull;
+    }
     if (threadIdx.x == 0) { emitted = 0; emitted_ring = 0; n_lookups = 0; }
     if (emit_slots) {
         // every occurrence that lies in a row leaves exactly one word: the bucket's word range is claimed before the first word is
@@ -1558,6 +1568,18 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
         if (lane == 0 && mine) atomicAdd(&n_lookups, mine);
     }
     __syncthreads();
+    if (HALF && hv.accum) {
+        // a piece: the slice back (counts clamped: the adds stop at SAT, the overshoot of concurrent ones is cut here)
+        const uint64_t slice0 = (uint64_t)blockIdx.x << t.log2_bucket;
+        for (uint32_t i = threadIdx.x; i < n_slots; i += BLK) {
+            const unsigned long long v = tab[i];
+            uint32_t c = (uint32_t)(v & HASH_CMASK);
+            if (c > HASH_SAT) c = HASH_SAT;
+            gstore(t.slots, slice0 + i, 1ull << t.log2_slots, v ? (v & ~(unsigned long long)HASH_CMASK) | c : 0ull, status);
+        }
+        if (threadIdx.x == 0) wbeg[blockIdx.x] = wbase;
+        return;
+    }
     if (HALF) {
         // the bucket's occupied slots, in slot order: a bitmap of the occupancy (64 consecutive slots = the lanes of one wavefront:
         // a ballot), ranks from the popcounts of its words, the entries written to consecutive places (coalesced).  The LDS table
@@ -2007,6 +2029,36 @@ __global__ __launch_bounds__(BLK, 4) void mini_lookup_half_merge_kernel(const un
     merged_lookup<CAP, BLK, DIG>(mc);
 }
 
+// PIECES: the lookups of ONE piece's provisional slots in the final table -- the bucket's slice becomes its 2-byte bins in LDS
+// (as the fused kernel makes them), then merged_lookup on the piece's slots and the kept meta words of its records
+template <int CAP, int BLK, int DIG>
+__global__ __launch_bounds__(BLK, 4) void mini_lookup_slice_merge_kernel(const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ n_short,
+                                                                       const unsigned long long *__restrict__ wbeg, MiniView t, uint32_t window, uint32_t vsize,
+                                                                       int vbits, const uint32_t *__restrict__ mprov, const uint32_t *__restrict__ meta,
+                                                                       ShufArgs sh, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t n_slots = 1u << t.log2_bucket, smask = n_slots - 1u;
+    const int64_t r0 = (int64_t)off[blockIdx.x], r1 = (int64_t)off[blockIdx.x + 1];
+    if (r1 == r0) return;                                        // (uniform: the piece has no record of this bucket)
+    const int64_t rs = n_short && CAP > SHORT_MAX ? r0 + (int64_t)n_short[blockIdx.x] : r0;
+    uint16_t *bins16 = reinterpret_cast<uint16_t *>(lds);
+    const uint64_t *slice = t.slots + ((uint64_t)blockIdx.x << t.log2_bucket);
+    const float rcp_window = 1.0f / (float)window;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += BLK) {
+        const unsigned long long v = slice[i];
+        const uint32_t bin = div_uniform((uint32_t)(v & HASH_CMASK), window, rcp_window);
+        bins16[i] = (uint16_t)(v && bin < vsize ? bin : 0xffffu);        // (merged_lookup reads the bin itself, 0xffff = none)
+    }
+    __syncthreads();
+    MergeCtx mc;
+    mc.lds = lds; mc.smask = smask; mc.vbits = vbits; mc.sh = sh; mc.status = status;
+    mc.prov_b = mprov + wbeg[blockIdx.x];
+    mc.meta_s = meta + r0; mc.meta_l = meta + rs; mc.n_s = (uint32_t)(rs - r0); mc.n_l = (uint32_t)(r1 - rs);
+    mc.dbg = nullptr;
+    merged_lookup<CAP, BLK, DIG>(mc);
+}
+
 // ---- workspace of the plan: header | region_tot | region_off | off | hist | cur2 | cur2l | kwords | wbeg | round_row | chunk table
 struct MiniPlan {
     int bits, bits1, bits2;
@@ -2301,9 +2353,10 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     if ((rc = check_mini_rows(rows, "pg_mini_count"))) return rc;
     const bool with_rows = rows && rows->n_rows > 0;
     if (window < 0 || vsize < 0 || (window > 0) != (vsize > 0)) return pg_fail(PG_EINVAL, "pg_mini_count: window %d / vector size %d", window, vsize);
+    const bool piece = half && half->accum;                      // (pg_mini_count_piece: no lookups in this launch, no row shuffle)
     if (window > 0) {
         if (!with_rows) return pg_fail(PG_EINVAL, "pg_mini_count: the lookup pass needs rows");
-        if (!shuffle_ws) return pg_fail(PG_EINVAL, "pg_mini_count: null shuffle workspace");
+        if (!shuffle_ws && !piece) return pg_fail(PG_EINVAL, "pg_mini_count: null shuffle workspace");
         if (vsize > PG_SHUFFLE_MAX_VSIZE || (t->kind == PG_TABLE_MINI && (int64_t)window * vsize > (int64_t)PG_HASH_COUNT_SAT))
             return pg_fail(PG_EINVAL, "pg_mini_count: window %d x vector size %d outside the exact range of the table", window, vsize);
     }
@@ -2336,7 +2389,7 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     if (hipMemsetAsync(hist, 0, p.wbeg_off - p.hist_off, s) != hipSuccess || hipMemsetAsync(header + 1, 0, 8, s) != hipSuccess)
         return pg_fail(PG_EHIP, "pg_mini_count: memset failed");
     pg_shuffle_layout sl{0, 0, 0, 0, 0};
-    if (window > 0) {
+    if (window > 0 && !piece) {
         if ((rc = pg_internal_shuffle_layout((word_end - word_begin) * 32, rows->n_rows, vsize, &sl, mini_slots_form(t, rows) ? MINI_ONE_PASS_BITS : PG_SHUFFLE_ONE_PASS_BITS,
                                              merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize) ? 1 : 0)))
             return rc;
@@ -2387,8 +2440,8 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     const bool slots_form = window > 0 && mini_slots_form(t, rows);
     // (the classes are sorted apart by the second scatter pass: without it -- at most 256 buckets -- every record counts as long)
     const unsigned long long *n_short = p.bits2 && mini_cap(t->k) > SHORT_MAX ? (const unsigned long long *)cur2 : (const unsigned long long *)nullptr;
-    uint32_t *words_e = window ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr;
-    uint32_t *words_a = window ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
+    uint32_t *words_e = window && !piece ? (uint32_t *)((char *)shuffle_ws + sl.words_e_off) : (uint32_t *)nullptr;
+    uint32_t *words_a = window && !piece ? (uint32_t *)((char *)shuffle_ws + sl.words_a_off) : (uint32_t *)nullptr;
     ShufArgs sh{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0ull};
     const MergeArgs mg{(uint32_t *)merge_ws, (unsigned long long)(merge_ws ? merge_ws_words : 0)};
     const bool merge = window > 0 && merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize);
@@ -2396,7 +2449,8 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     if (half && (wide || !(window > 0 && mini_slots_form(t, rows))))
         return pg_fail(PG_EINVAL, "pg_mini_count_half: needs packed slots (k <= %d), rows and fewer than 2^(32 - log2 bucket slots) of them", PG_HASH_MAX_K);
     if (half && !p.bits2) return pg_fail(PG_EINVAL, "pg_mini_count_half: needs more than 256 buckets");
-    const HalfArgs hv = half ? *half : HalfArgs{nullptr, nullptr, nullptr, nullptr};
+    if (piece && !merge) return pg_fail(PG_EINVAL, "pg_mini_count_piece: needs the merged lookups (fewer than 2^20 rows, their slot buffer given)");
+    const HalfArgs hv = half ? *half : HalfArgs{nullptr, nullptr, nullptr, nullptr, 0};
     size_t count_lds = slice_lds;
     // Buckets of at most 2^13 8-byte slots (64 KiB): 512-thread workgroups, TWO per CU -- one can be in its count loop (VALU, waits)
     // while the other is in its lookup phase (LDS throughput).  PG_COUNT_BLOCK=1024: the one-workgroup form for such tables too.
@@ -2405,7 +2459,7 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     // (the count half does no lookups: the row-group digits do not matter to its geometry)
     const bool half_block = !wide && window > 0 && mini_slots_form(t, rows) && t->log2_bucket_slots <= 13 && (!many_groups || half) && !(blk_env && atoi(blk_env) == 1024);
     if (half_block) count_lds = table_lds + (size_t)(512 / 64) * RING * 12;
-    if (slots_form) {
+    if (slots_form && !piece) {
         // the count kernel scatters its words into the row shuffle's group regions itself: offsets and cursors must be ready
         pg_shuffle_ctx ctx;
         if ((rc = pg_internal_shuffle_prepare((word_end - word_begin) * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS, merge ? 1 : 0))) return rc;
@@ -2416,7 +2470,7 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
         if (sh.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_count: %d first-pass digits of the row shuffle", sh.gb1);
         if (count_lds < lookup_lds && !half) count_lds = lookup_lds;
     }
-    unsigned long long *emit_end = window ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
+    unsigned long long *emit_end = window && !piece ? (unsigned long long *)((char *)shuffle_ws + sl.emit_off) : (unsigned long long *)nullptr;
 #define PG_MINI_LAUNCH_COUNT__(CAP_, SLOTS_, WIDE_, BLK_, DIG_, MERGE_, HALF_, LDS_)                                         \
     do {                                                                                                                    \
         if ((rc = raise_lds_limit((const void *)(mini_count_kernel<CAP_, SLOTS_, WIDE_, BLK_, DIG_, MERGE_, HALF_>), LDS_, "pg_mini_count"))) return rc; \
@@ -2468,6 +2522,81 @@ extern "C" int pg_mini_count(const uint64_t *codes, const uint32_t *valid, int64
 {
     return mini_count_impl(codes, valid, word_begin, word_end, t, rows, plan_ws, plan_ws_bytes, rec_ws, rec_ws_bytes, window, vsize, shuffle_ws,
                            shuffle_ws_bytes, status, stream, nullptr, merge_ws, merge_ws_words);
+}
+
+// ---- a stream counted in pieces (one GPU; see HalfArgs / mini_lookup_slice_merge_kernel)
+extern "C" int pg_mini_count_piece(const uint64_t *codes, const uint32_t *valid, int64_t word_begin, int64_t word_end, const pg_table *t,
+                                   const pg_rows *rows, void *plan_ws, int64_t plan_ws_bytes, void *rec_ws, int64_t rec_ws_bytes,
+                                   int window, int vsize, void *merge_ws, int64_t merge_ws_words, int first, uint32_t *status, void *stream)
+{
+    int rc = check_mini(t, "pg_mini_count_piece");
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_MINI) return pg_fail(PG_EINVAL, "pg_mini_count_piece: packed mini tables (13 <= k <= %d)", PG_HASH_MAX_K);
+    if (window < 1 || vsize < 1 || !merge_ws) return pg_fail(PG_EINVAL, "pg_mini_count_piece: needs the abundance parameters and the slot buffer");
+    const HalfArgs hv{nullptr, nullptr, nullptr, nullptr, first ? 1 : 2};
+    return mini_count_impl(codes, valid, word_begin, word_end, t, rows, plan_ws, plan_ws_bytes, rec_ws, rec_ws_bytes, window, vsize, nullptr, 0,
+                           status, stream, &hv, merge_ws, merge_ws_words);
+}
+
+// offsets and cursors of the row shuffle for the words of ALL pieces (n_words_total: the words of the whole stream); once, before the
+// first pg_mini_lookup_piece
+extern "C" int pg_mini_lookup_begin(const pg_table *t, const pg_rows *rows, int64_t n_words_total, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes, void *stream)
+{
+    int rc = check_mini(t, "pg_mini_lookup_begin");
+    if (rc) return rc;
+    if (!rows || !shuffle_ws || (rc = check_mini_rows(rows, "pg_mini_lookup_begin"))) return rc ? rc : pg_fail(PG_EINVAL, "pg_mini_lookup_begin: null argument");
+    if (!mini_merge_form(t, rows, vsize)) return pg_fail(PG_EINVAL, "pg_mini_lookup_begin: the merged lookups do not apply to these rows");
+    pg_shuffle_ctx ctx;
+    return pg_internal_shuffle_prepare(n_words_total * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS, 1);
+}
+
+// the lookups of one piece: plan_ws = the piece's plan workspace as pg_mini_count_piece left it (n_words_piece words), meta = the
+// kept meta words of its bucket-ordered records (the second meta plane of its record workspace, n_records of them), merge_ws its
+// slot buffer; the words go to the row shuffle's regions behind those of the pieces before.  pg_mini_abundance_from_emitted (with
+// n_words_total) then writes the rows.
+extern "C" int pg_mini_lookup_piece(const pg_table *t, const pg_rows *rows, const void *plan_ws, int64_t plan_ws_bytes, int64_t n_words_piece,
+                                    const uint32_t *meta, int64_t n_words_total, int window, int vsize, void *shuffle_ws, int64_t shuffle_ws_bytes,
+                                    const void *merge_ws, uint32_t *status, void *stream)
+{
+    int rc = check_mini(t, "pg_mini_lookup_piece");
+    if (rc) return rc;
+    if (t->kind != PG_TABLE_MINI || !rows || !plan_ws || !meta || !shuffle_ws || !merge_ws || !status || window < 1 || vsize < 1)
+        return pg_fail(PG_EINVAL, "pg_mini_lookup_piece: bad argument");
+    if ((rc = check_mini_rows(rows, "pg_mini_lookup_piece"))) return rc;
+    if (!mini_merge_form(t, rows, vsize)) return pg_fail(PG_EINVAL, "pg_mini_lookup_piece: the merged lookups do not apply to these rows");
+    MiniPlan p;
+    plan_mini(t, n_words_piece, &p);
+    if ((int64_t)p.total > plan_ws_bytes) return pg_fail(PG_EINVAL, "pg_mini_lookup_piece: plan workspace does not match n_words_piece");
+    if (!p.bits2) return pg_fail(PG_EINVAL, "pg_mini_lookup_piece: needs more than 256 buckets");
+    pg_shuffle_ctx ctx;
+    if ((rc = pg_internal_shuffle_prepare(n_words_total * 32, rows, vsize, shuffle_ws, shuffle_ws_bytes, stream, &ctx, MINI_ONE_PASS_BITS, 1, 1))) return rc;
+    if (ctx.gb1 > MINI_ONE_PASS_BITS) return pg_fail(PG_EINVAL, "pg_mini_lookup_piece: %d first-pass digits of the row shuffle", ctx.gb1);
+    const ShufArgs sh{ctx.goff, ctx.gcur1, ctx.words_out, ctx.gb1, ctx.gb2, ctx.dshift, 0, ctx.words_cap};
+    const char *ws = (const char *)plan_ws;
+    const auto *off = (const unsigned long long *)(ws + p.off_off);
+    const auto *cur2 = (const unsigned long long *)(ws + p.cur2_off);
+    const auto *wbeg = (const unsigned long long *)(ws + p.wbeg_off);
+    const int cap_k = mini_cap(t->k);
+    const unsigned long long *n_short = cap_k > SHORT_MAX ? cur2 : (const unsigned long long *)nullptr;
+    const unsigned nb = 1u << p.bits;
+    hipStream_t s = (hipStream_t)stream;
+#define PG_LOOKUP_SLICE_M(CAP_, DIG_)                                                                                       \
+    do {                                                                                                                    \
+        const size_t lds_ = MergeLds<BIG_BLOCK, DIG_>::END;                                                                 \
+        if ((rc = raise_lds_limit((const void *)(mini_lookup_slice_merge_kernel<CAP_, BIG_BLOCK, DIG_>), lds_, "pg_mini_lookup_piece"))) return rc; \
+        hipLaunchKernelGGL((mini_lookup_slice_merge_kernel<CAP_, BIG_BLOCK, DIG_>), dim3(nb), dim3(BIG_BLOCK), lds_, s, off, n_short, wbeg, mini_view(t), \
+                           (uint32_t)window, (uint32_t)vsize, ctx.vbits, (const uint32_t *)merge_ws, meta, sh, status);     \
+    } while (0)
+#define PG_LOOKUP_SLICE_MC(CAP_) do { if (ctx.gb1 > 10) PG_LOOKUP_SLICE_M(CAP_, 2048); else PG_LOOKUP_SLICE_M(CAP_, 1024); } while (0)
+    switch (cap_k) {
+    case 1: case 2: case 3: case 4: PG_LOOKUP_SLICE_MC(4); break;
+    case 5: case 6: PG_LOOKUP_SLICE_MC(6); break;
+    case 7: case 8: PG_LOOKUP_SLICE_MC(8); break;
+    default: PG_LOOKUP_SLICE_MC(9); break;
+    }
+#undef PG_LOOKUP_SLICE_MC
+#undef PG_LOOKUP_SLICE_M
+    return check_launch("pg_mini_lookup_piece");
 }
 
 // dwords of the merged form's provisional buffer (pg_mini_count's merge_ws): a halfword per k-mer slot of every batch of 64
@@ -2527,7 +2656,7 @@ extern "C" int pg_mini_count_half(const uint64_t *codes, const uint32_t *valid, 
     if ((int64_t)hl.total > half_ws_bytes || (reinterpret_cast<uintptr_t>(half_ws) & 255) != 0)
         return pg_fail(PG_EINVAL, "pg_mini_count_half: workspace of %lld bytes (256-byte aligned), %lld needed", (long long)half_ws_bytes, (long long)hl.total);
     char *hw = (char *)half_ws;
-    const HalfArgs hv{(unsigned long long *)(hw + hl.ent_off), (unsigned long long *)(hw + hl.occ_off), (long long *)fill, (uint32_t *)(hw + hl.ring_off)};
+    const HalfArgs hv{(unsigned long long *)(hw + hl.ent_off), (unsigned long long *)(hw + hl.occ_off), (long long *)fill, (uint32_t *)(hw + hl.ring_off), 0};
     return mini_count_impl(codes, valid, word_begin, word_end, local, rows, plan_ws, plan_ws_bytes, rec_ws, rec_ws_bytes, window, vsize, shuffle_ws,
                            shuffle_ws_bytes, status, stream, &hv, merge_ws, merge_ws_words);
 }

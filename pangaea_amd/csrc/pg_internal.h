@@ -54,7 +54,7 @@ struct pg_shuffle_ctx {
 #define PG_SHUFFLE_COUNT_SHIFT 28
 int pg_internal_shuffle_is_narrow(int64_t cap, int64_t n_rows, int vsize, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS);       // what prepare will put into ctx->narrow
 int pg_internal_shuffle_prepare(int64_t cap, const pg_rows *rows, int vsize, void *workspace, int64_t workspace_bytes, void *stream,
-                                pg_shuffle_ctx *ctx, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS, int no_input = 0);
+                                pg_shuffle_ctx *ctx, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS, int no_input = 0, int ctx_only = 0);
 int pg_internal_shuffle_finish(int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out, void *workspace, int64_t workspace_bytes, void *stream,
                                int word_form, int one_pass_bits = PG_SHUFFLE_ONE_PASS_BITS, int no_input = 0);
 int pg_internal_shuffle_rows(const unsigned long long *in_begin, int nb, int64_t cap, const pg_rows *rows, int vsize, int32_t *abd_out,

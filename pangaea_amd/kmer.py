@@ -63,6 +63,7 @@ class KmerTable:
         self._mini_rec_ws = None
         self._mini_sized_for = None      # (n_words, geometry) the record / slot workspaces were sized for (with slack)
         self._mini_optimistic = None     # the arguments of a count that ran on them without reading its plan's counts
+        self._mini_pieces = 1            # word ranges the last count of a mini table was done in (``_count_mini_pieces``)
         self._half = None                # (fill, n_words, rows, window, vsize) between count_half and lookup_half (N > 1 ranks)
         self._half_ws = None
         self._merge_ws = None            # the provisional words of the merged lookups (fixed slots per record)
@@ -367,6 +368,11 @@ class KmerTable:
             raise ValueError("mini tables need sorted, disjoint, non-empty rows (at most 2^21 - 2 of them)")
         fuse = (emit is not None and keep is not None and n_words > 0 and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1
                 and (self.kind == "miniw" or emit[0] * emit[1] <= _lib.HASH_COUNT_SAT))
+        # a stream whose scratch would not fit in one piece (about 3.4 KB per 150 bp read pair; PANGAEA_MINI_PIECE_WORDS forces a
+        # piece size) is counted word range by word range into the same table, its lookups done when the table is final
+        piece_words = self._piece_words(n_words, fuse and not half)
+        if piece_words is not None:
+            return self._count_mini_pieces(stream, word_begin, word_end, table_plane, keep, rows_arg, emit, piece_words, check)
         key = self._plan_key(stream.codes, table_plane, word_begin, word_end, keep, lenient, self.log2_slots, self.log2_bucket)
         held = (stream.codes, table_plane)               # (kept with the plan: see _plan_key)
         with torch.cuda.device(self.device):
@@ -458,9 +464,90 @@ class KmerTable:
                                            plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
                                            window, vsize, sws_ptr, sws_n, mws_ptr, mws_n, self.status.data_ptr(), _stream_ptr(self.device)))
         self._empty = False
+        self._mini_pieces = 1
         self._records = (keep, n_words) if fuse and not half else None
         self._emitted = (window, vsize) if fuse and not half else None
         self._mini_optimistic = (stream, word_begin, word_end, rows, emit, half) if optimistic else None
+        if check:
+            self.check_status()
+        return self
+
+    # bytes of scratch per word of the stream (32 characters): record workspace (two planes of 12-byte records, ~6.7 records per
+    # word at k = 21), 2-byte slots of the merged lookups, the row shuffle's word regions (4 bytes per character)
+    _PIECE_BYTES_PER_WORD = (24 * 7, 12 * 7, 4 * 32)
+
+    def _piece_words(self, n_words: int, applicable: bool):
+        """None (one piece, the usual path) or the number of words per piece"""
+        forced = os.environ.get("PANGAEA_MINI_PIECE_WORDS")
+        if not applicable or self.kind != "mini" or self.n_buckets <= 256 or os.environ.get("PG_MINI_MERGE", "1") in ("", "0"):
+            return None                                          # (the pieces' kernels: packed slots, both scatter passes, the merged lookups)
+        if forced:
+            w = max(_lib.WORD_ALIGN, int(forced) // _lib.WORD_ALIGN * _lib.WORD_ALIGN)
+            return w if w < n_words else None
+        rec, slots, words = self._PIECE_BYTES_PER_WORD
+        free, _ = torch.cuda.mem_get_info(self.device)
+        free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)      # (cached blocks count as free)
+        budget = 0.85 * free
+        if (rec + slots + words) * n_words <= budget:
+            return None
+        room = budget - (slots + words + 4 * 7) * n_words          # what stays per word whatever the piece size (slots, kept meta, words)
+        if room <= rec * 4 * _lib.WORD_ALIGN:
+            return None                                          # (not even in pieces: the one-piece path reports the allocation that fails)
+        return max(_lib.WORD_ALIGN, int(room / rec) // _lib.WORD_ALIGN * _lib.WORD_ALIGN)
+
+    def _count_mini_pieces(self, stream, word_begin, word_end, table_plane, keep, rows_arg, emit, piece_words, check):
+        """``_count_mini`` for a stream counted in word ranges of ``piece_words`` (include/pangaea_feat.h: pg_mini_count_piece):
+        every piece -> its plan, both scatter passes, the count INTO the table's buckets (slots keep their places), its 2-byte
+        provisional slots and its records' meta words kept; then the lookups of every piece in the final table, into the row
+        shuffle's regions of the whole stream.  Afterwards the table is what one count would have made it (``features`` reads
+        the rows from the shuffled words as usual)."""
+        L = _lib.load()
+        valid_ptr = table_plane.data_ptr()
+        window, vsize = int(emit[0]), int(emit[1])
+        n_words = word_end - word_begin
+        ranges = [(w0, min(word_end, w0 + piece_words)) for w0 in range(word_begin, word_end, piece_words)]
+        slack = (lambda n: n + n // 32 + 4096)
+        kept = []
+        sp = _stream_ptr(self.device)
+        with torch.cuda.device(self.device):
+            rec_ws = None
+            for idx, (w0, w1) in enumerate(ranges):
+                need = _lib.check(L.pg_mini_plan_bytes(w1 - w0, self.desc()))
+                plan_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _lib.check(L.pg_mini_plan(stream.codes.data_ptr(), valid_ptr, w0, w1, self.desc(), rows_arg(keep), plan_ws.data_ptr(), plan_ws.numel(), sp))
+                head = plan_ws[:24].view(torch.int64).cpu()                 # (host wait, once per piece: records, -, long records)
+                n_records, n_long = int(head[0]), int(head[2])
+                need = _lib.check(L.pg_mini_records_bytes(slack(n_records), self.desc()))
+                if rec_ws is None or rec_ws.numel() < need:
+                    rec_ws = None
+                    rec_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                need = _lib.check(L.pg_mini_merge_words(w1 - w0, n_records, n_long, self.desc()))
+                merge_ws = torch.empty(need, dtype=torch.int32, device=self.device)
+                _lib.check(L.pg_mini_count_piece(stream.codes.data_ptr(), valid_ptr, w0, w1, self.desc(), rows_arg(keep), plan_ws.data_ptr(), plan_ws.numel(),
+                                                 rec_ws.data_ptr(), rec_ws.numel(), window, vsize, merge_ws.data_ptr(), merge_ws.numel(),
+                                                 1 if idx == 0 else 0, self.status.data_ptr(), sp))
+                # the bucket-ordered records' meta words (lengths, rows): the second meta plane of [bases A | bases B | meta A | meta B]
+                cap = rec_ws.numel() // 24 // 256 * 256
+                meta = rec_ws[20 * cap: 20 * cap + 4 * n_records].view(torch.int32).clone()
+                kept.append((plan_ws, merge_ws, meta, w1 - w0))
+            rec_ws = None
+            need = _lib.check(L.pg_mini_shuffle_bytes_merged(n_words, keep.n_rows, vsize, self.desc()))
+            if self._shuffle_ws is None or self._shuffle_ws.numel() < need:
+                self._shuffle_ws = None
+                self._shuffle_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            sws = self._shuffle_ws
+            _lib.check(L.pg_mini_lookup_begin(self.desc(), rows_arg(keep), n_words, vsize, sws.data_ptr(), sws.numel(), sp))
+            for plan_ws, merge_ws, meta, nw in kept:
+                _lib.check(L.pg_mini_lookup_piece(self.desc(), rows_arg(keep), plan_ws.data_ptr(), plan_ws.numel(), nw, meta.data_ptr(), n_words, window, vsize,
+                                                  sws.data_ptr(), sws.numel(), merge_ws.data_ptr(), self.status.data_ptr(), sp))
+            # (``abundance_from_records`` hands a plan workspace of the whole range to pg_mini_abundance_from_emitted, which only checks its size)
+            whole = torch.empty(_lib.check(L.pg_mini_plan_bytes(n_words, self.desc())), dtype=torch.uint8, device=self.device)
+        self._mini_plan = (("pieces", len(ranges)), whole, sum(int(m.numel()) for _, _, m, _ in kept), keep, (stream.codes, table_plane), 0)
+        self._mini_pieces = len(ranges)
+        self._mini_optimistic = None
+        self._empty = False
+        self._records = (keep, n_words)
+        self._emitted = (window, vsize)
         if check:
             self.check_status()
         return self

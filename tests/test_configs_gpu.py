@@ -153,6 +153,59 @@ def test_config3_one_gpu_share_two_pass_row_shuffle():
         assert np.array_equal(tnf[r].cpu().numpy(), oracle.tnf_row(seq, 4))
 
 
+def test_fifty_million_pairs_on_one_gpu_counted_in_pieces(monkeypatch, capsys):
+    """more pairs than one GPU's share of any BASELINE configuration: 50 M pairs / 250 k barcodes on ONE GPU.  The stream still
+    fits in one piece here (about 3.4 KB of scratch per pair), so both forms run: one count, and the same stream counted in two
+    word ranges into the same table (``PANGAEA_MINI_PIECE_WORDS``; beyond about 70 M pairs ``KmerTable`` does that by itself).
+    Same rows either way, table total = the valid 21-mers of the stream, spot rows against the oracle's exact counts; the pieces'
+    rate stays within a quarter of the one-piece rate (the two printed; DESIGN.md has the measured figures)."""
+    import time
+    cfg = synth.SynthConfig(n_pairs=50_000_000, n_barcodes=250_000, seed=4242)
+    s = synth.generate(cfg, device=DEV, chunk_pairs=1 << 17, with_names=False)
+    rows = s.rows(2000)
+    assert len(rows) == 250_000
+    plan = kmer.Plan(rows, DEV)
+    n21 = _kmer_ends(s.valid, 21)
+
+    def timed(table_maker):
+        # (twice: the first pass allocates ~170 GB through hipMalloc, seconds of it; the second finds the blocks in torch's cache)
+        for again in (False, True):
+            t = tnf = abd = None
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            t = table_maker()
+            tnf, abd = kmer.features(s, plan, k_tnf=4, table=t, window=10, vsize=400)
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t0
+        return t, tnf, abd, sec
+
+    one, tnf, abd, sec_one = timed(lambda: kmer.count_kmers(s, 21, rows=plan, emit=(10, 400)))
+    assert one.kind == "mini" and one._mini_pieces == 1
+    geometry = (one.log2_slots, one.log2_bucket)
+    assert int((one.compact() & ((1 << 22) - 1)).sum().item()) == n21
+    peak_one = torch.cuda.max_memory_allocated(DEV)
+    one.release_workspaces()
+    del one
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats(DEV)
+    # (first call of the pieces' kernels on a small stream: their code objects load here, not inside the timed count)
+    small = synth.generate(synth.SynthConfig(n_pairs=40_000, n_barcodes=200, seed=1), device=DEV)
+    monkeypatch.setenv("PANGAEA_MINI_PIECE_WORDS", str(256 * 256))
+    warm = kmer.KmerTable.mini_with_slots(21, DEV, 24, 12).count(small, rows=kmer.Plan(small.rows(2000), DEV), emit=(10, 400))
+    assert warm._mini_pieces > 1
+    del warm, small
+    monkeypatch.setenv("PANGAEA_MINI_PIECE_WORDS", str(s.n_words // 2 // 256 * 256 + 256))
+    t, tnf_p, abd_p, sec_pieces = timed(lambda: kmer.KmerTable.mini_with_slots(21, DEV, *geometry).count(s, rows=plan, emit=(10, 400)))
+    assert t.kind == "mini" and t._mini_pieces == 2
+    assert torch.equal(abd_p, abd) and torch.equal(tnf_p, tnf)
+    assert int((t.compact() & ((1 << 22) - 1)).sum().item()) == n21
+    peak_pieces = torch.cuda.max_memory_allocated(DEV)
+    with capsys.disabled():
+        print(f"\n50 M pairs on one GPU: one piece {sec_one:.3f} s (peak {peak_one / 2**30:.0f} GiB), two pieces {sec_pieces:.3f} s "
+              f"(peak {peak_pieces / 2**30:.0f} GiB): {50 / sec_one:.0f} vs {50 / sec_pieces:.0f} M pairs/s")
+    assert sec_pieces <= 1.25 * sec_one
+    text = _text(s)
+    _spot_rows_equal_oracle(s, rows, text, tnf_p, abd_p, [0, 131_072, 249_999])
+
+
 def _args(tmp_path, **kw):
     d = dict(reads1="", reads2="", interleaved_reads="", output=str(tmp_path / "out"), min_length=2000, kmer=21,
              tnf_kmer=4, window_size=10, vector_size=400, threads=8)

@@ -409,6 +409,54 @@ def test_merged_runs_equal_the_word_wise_lookups(sub_rate, coverage_genomes, win
         assert np.array_equal(ref[r].cpu().numpy(), oracle.abd_row(text[rows.start[r]:rows.end[r]], 21, otab, window, 400))
 
 
+@pytest.mark.parametrize("k,log2_slots,lb,piece_words,n_pairs,saturate", [
+    (21, 24, 12, 300 * 256, 40_000, False),      # five pieces, the last one short; 4096 buckets
+    (21, 26, 14, 1 << 20, 200_000, False),       # two pieces of 2^14-slot buckets (the bench's geometry, 1024-thread workgroups)
+    (15, 23, 10, 128 * 256, 15_000, False),      # Pangaea's default k, 11-mer minimizers
+    (21, 24, 13, 64 * 256, 0, True),             # counts that reach the saturation value across pieces, a tandem repeat
+])
+def test_a_stream_counted_in_pieces_equals_one_count(k, log2_slots, lb, piece_words, n_pairs, saturate, monkeypatch):
+    """a stream whose scratch does not fit in one piece is counted word range by word range INTO the same table (the bucket's slice
+    goes back into LDS, slots keep their places), every piece leaving its provisional slots behind; the lookups of all pieces run when
+    the table is final (pg_mini_count_piece / pg_mini_lookup_piece; PANGAEA_MINI_PIECE_WORDS forces the piece size).  Same table and
+    same rows as ONE count of the stream, and as the oracle; first through the checked build (test below)."""
+    if saturate:
+        rng = np.random.RandomState(5)
+        rnd = bytes(rng.choice(list(b"ACGT"), size=90_000).astype(np.uint8))
+        s = ReadStream.from_runs([("a", b"A" * 2_200_000 + b"N" + b"T" * 1_100_040 + b"N"), ("b", b"ACG" * 40_000 + b"N"), ("c", rnd + b"N")], device=DEV)
+        rows = s.rows(0)
+    else:
+        cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=max(8, n_pairs // 150), n_genomes=3, genome_len=80_000, fragment=20_000,
+                                sub_rate=0.01, n_rate=0.1, seed=77 + k)
+        s = synth.generate(cfg, device=DEV)
+        rows = s.rows(2000)
+    plan = kmer.Plan(rows, DEV)
+    one = kmer.KmerTable.mini_with_slots(k, DEV, log2_slots, lb).count(s, rows=plan, emit=(10, 400))
+    assert one._mini_pieces == 1
+    _, want = kmer.features(s, plan, k_tnf=None, table=one, window=10, vsize=400)
+    monkeypatch.setenv("PANGAEA_MINI_PIECE_WORDS", str(piece_words))
+    t = kmer.KmerTable.mini_with_slots(k, DEV, log2_slots, lb)
+    t.data.fill_(0x7FFF_FFFF_FFFF)                       # (a fresh table is never cleared: the first piece must not read it)
+    t.count(s, rows=plan, emit=(10, 400))
+    assert t._mini_pieces == -(-s.n_words // piece_words) >= 2 and t.kind == "mini"
+    _, abd = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)            # from the shuffled words of all pieces
+    assert torch.equal(abd, want) and int(abd.sum()) > 0
+    assert _same_items(t.items(), one.items())
+    _, abd_l = kmer.features(s, rows, k_tnf=None, table=t, window=10, vsize=400)          # by lookups in the table the pieces built
+    assert torch.equal(abd_l, want)
+    text = s.decode()
+    otab = oracle.Table(k, threads=4).count(text)
+    oc, on = otab.items()
+    assert _same_items(t.items(), (oc, np.minimum(on, 1 << 21)))
+    if saturate:
+        assert int(t.items()[1].max()) == 1 << 21
+    for r in range(0, len(rows), max(1, len(rows) // 6)):
+        assert np.array_equal(abd[r].cpu().numpy(), oracle.abd_row(text[rows.start[r]:rows.end[r]], k, otab, 10, 400))
+    t.reset().count(s, rows=plan, emit=(10, 400))        # again with the same object: the same rows
+    _, abd2 = kmer.features(s, plan, k_tnf=None, table=t, window=10, vsize=400)
+    assert torch.equal(abd2, want)
+
+
 def test_super_kmer_kernels_through_the_checked_build():
     """the same library built with -DPG_CHECKED (every global store of the super-k-mer kernels checks its index against the
     capacity of the buffer it writes into; PG_STATUS_BOUNDS instead of a memory fault): the oracle cases of this file run
@@ -430,7 +478,7 @@ def _checked_pass(merge):
     from .conftest import ROOT
     env = dict(os.environ, PANGAEA_LIB="checked", PG_MINI_MERGE=merge)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_mini_gpu.py"),
-                        "-k", "against_oracle or merged_runs or general_lookup or its_own_record or one_pass_row_shuffle or low_complexity"],
+                        "-k", "against_oracle or merged_runs or general_lookup or its_own_record or one_pass_row_shuffle or low_complexity or counted_in_pieces"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
