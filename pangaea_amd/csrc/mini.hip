@@ -393,10 +393,14 @@ template <int N1> struct Scatter1Lds {                              // N1 region
     uint32_t cnt[N1];
     uint32_t start[N1 + 1];
     uint32_t fill[N1];                                              // start[], counted up as the references are placed
-    unsigned long long gbase[N1];
+    // (512 regions: the array would push the structure 40 bytes over half of the CU's 160 KiB -- one workgroup per CU instead of
+    // two; there the copy-out derives the value from cur[] and start[])
+    unsigned long long gbase[N1 > 256 ? 1 : N1];
     unsigned long long cur[N1];                                     // running write offsets of this chunk, per region
     uint32_t wave_tot[N1 / 64];
 };
+
+static_assert(2 * sizeof(Scatter1Lds<256>) <= 160 * 1024 && 2 * sizeof(Scatter1Lds<512>) <= 160 * 1024, "two first-pass workgroups share a CU's LDS");
 
 template <int W, bool DELAY, int M, int N1>
 __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
@@ -476,8 +480,8 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
             // gbase[d] = (where the region's run goes) - (where it starts in the stage): the copy-out adds the stage position
             if (threadIdx.x < N1) {
                 const uint32_t c = L.start[threadIdx.x + 1] - L.start[threadIdx.x];
-                L.gbase[threadIdx.x] = L.cur[threadIdx.x] - L.start[threadIdx.x];
-                L.cur[threadIdx.x] += c;
+                if constexpr (N1 <= 256) L.gbase[threadIdx.x] = L.cur[threadIdx.x] - L.start[threadIdx.x];
+                L.cur[threadIdx.x] += c;                            // (= gbase + start[d + 1])
             }
             {
                 // the lane's records, two per turn: their buckets out of the column, their places in the stage from the regions'
@@ -517,7 +521,9 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
                     cwv[u] = L.cw[ln]; pwv[u] = L.pw[ln];
                     nonk[u] = L.nonk[ln]; okr[u] = L.ok_row[ln];
                     st[u] = L.starts[ln]; en[u] = L.ends[ln]; r0v[u] = L.r0[ln];
-                    gb[u] = L.gbase[(rf[u] & 0xffffu) >> bits2];
+                    const uint32_t d = (rf[u] & 0xffffu) >> bits2;
+                    if constexpr (N1 <= 256) gb[u] = L.gbase[d];
+                    else gb[u] = L.cur[d] - L.start[d + 1];
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
