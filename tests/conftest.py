@@ -18,7 +18,7 @@ def pytest_configure(config):
 # then the stages around the path, the multi-process cases, and the bench's own contract (subprocesses, timings) LAST -- so that
 # a failure in the periphery can never keep a parity test from running (round 3: a timing assertion in the alphabetically first
 # GPU file stopped the driver's whole suite).  Files not listed keep their place between the listed ones and the last two.
-_FILE_ORDER = ["test_oracle_golden", "test_abi_host", "test_binwriter",
+_FILE_ORDER = ["test_oracle_golden", "test_abi_host", "test_binwriter", "test_segment_masks",
                "test_gpu_parity", "test_mini_gpu", "test_configs_gpu",
                "test_vae_data", "test_clustering", "test_feature_cli_gpu", "test_ingest_gpu", "test_pipeline_gpu",
                "test_integration_doc"]

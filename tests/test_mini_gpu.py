@@ -420,6 +420,9 @@ def test_a_stream_counted_in_pieces_equals_one_count(k, log2_slots, lb, piece_wo
     goes back into LDS, slots keep their places), every piece leaving its provisional slots behind; the lookups of all pieces run when
     the table is final (pg_mini_count_piece / pg_mini_lookup_piece; PANGAEA_MINI_PIECE_WORDS forces the piece size).  Same table and
     same rows as ONE count of the stream, and as the oracle; first through the checked build (test below)."""
+    import os
+    if os.environ.get("PG_MINI_MERGE", "1") in ("", "0"):
+        pytest.skip("the pieces keep the merged lookups' 2-byte slots: no word-wise form")
     if saturate:
         rng = np.random.RandomState(5)
         rnd = bytes(rng.choice(list(b"ACGT"), size=90_000).astype(np.uint8))
