@@ -160,8 +160,10 @@ def test_fifty_million_pairs_on_one_gpu_counted_in_pieces(monkeypatch, capsys):
     Same rows either way, table total = the valid 21-mers of the stream, spot rows against the oracle's exact counts; the pieces'
     rate stays within a quarter of the one-piece rate (the two printed; DESIGN.md has the measured figures)."""
     import time
+    t_start = time.perf_counter()
     cfg = synth.SynthConfig(n_pairs=50_000_000, n_barcodes=250_000, seed=4242)
     s = synth.generate(cfg, device=DEV, chunk_pairs=1 << 17, with_names=False)
+    torch.cuda.synchronize(); t_gen = time.perf_counter()
     rows = s.rows(2000)
     assert len(rows) == 250_000
     plan = kmer.Plan(rows, DEV)
@@ -202,8 +204,12 @@ def test_fifty_million_pairs_on_one_gpu_counted_in_pieces(monkeypatch, capsys):
         print(f"\n50 M pairs on one GPU: one piece {sec_one:.3f} s (peak {peak_one / 2**30:.0f} GiB), two pieces {sec_pieces:.3f} s "
               f"(peak {peak_pieces / 2**30:.0f} GiB): {50 / sec_one:.0f} vs {50 / sec_pieces:.0f} M pairs/s")
     assert sec_pieces <= 1.25 * sec_one
+    t_gpu = time.perf_counter()
     text = _text(s)
+    t_text = time.perf_counter()
     _spot_rows_equal_oracle(s, rows, text, tnf_p, abd_p, [0, 131_072, 249_999])
+    with capsys.disabled():
+        print(f"(test phases: generate {t_gen - t_start:.0f} s, counts {t_gpu - t_gen:.0f} s, decode {t_text - t_gpu:.0f} s, oracle {time.perf_counter() - t_text:.0f} s)")
 
 
 def _args(tmp_path, **kw):
