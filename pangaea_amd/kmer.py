@@ -453,7 +453,9 @@ class KmerTable:
                 if getattr(self, "_half_ws", None) is None or self._half_ws.numel() != need:
                     self._half_ws = None
                     self._half_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                fill = torch.empty(self.n_buckets, dtype=torch.int64, device=self.device)
+                # (zeroed: a count half that refuses its plan -- PG_STATUS_PLAN_MISMATCH -- writes nothing, and the exchange sizes its
+                # buffers from these numbers before anybody has looked at the status word)
+                fill = torch.zeros(self.n_buckets, dtype=torch.int64, device=self.device)
                 _lib.check(L.pg_mini_count_half(stream.codes.data_ptr(), valid_ptr, word_begin, word_end, self.desc(), rows_arg(keep),
                                                 plan_ws.data_ptr(), plan_ws.numel(), self._mini_rec_ws.data_ptr(), self._mini_rec_ws.numel(),
                                                 window, vsize, sws_ptr, sws_n, mws_ptr, mws_n, self._half_ws.data_ptr(), self._half_ws.numel(),
