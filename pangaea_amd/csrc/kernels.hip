@@ -548,7 +548,11 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
     __shared__ ScatterLds<FAN_BITS> L;
     const int n_dig = 1 << dbits;
     const uint32_t dmask = (uint32_t)n_dig - 1u;
-    const int64_t region = blockIdx.x / tiles_x;
+    // (all workgroups of a region on ONE of the eight XCDs, which take workgroups round-robin by index: the runs its tiles append
+    // to a destination are completed in that XCD's L2 -- see mini_scatter2_kernel.  Flat destinations are shared by all regions.)
+    const unsigned n_regions = gridDim.x / (unsigned)tiles_x;
+    const bool by_xcd = !flat && n_regions % 8u == 0u;
+    const int64_t region = by_xcd ? (int64_t)(blockIdx.x % 8u) + 8 * (int64_t)((blockIdx.x / 8u) / (unsigned)tiles_x) : (int64_t)(blockIdx.x / tiles_x);
     const int64_t base_index = flat ? 0 : (region << dbits);
     const int64_t r0 = (int64_t)in_begin[region << in_shift];
     const int64_t r1 = in_cnt ? r0 + (int64_t)in_cnt[region] : (int64_t)in_end[region << in_shift];
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_records_kernel(const REC *__res
         if (DIG == DIG_HASH) return (uint32_t)(((uint64_t)r & REC_KEY_MASK) >> dshift) & dmask;
         return ((uint32_t)r >> dshift) & dmask;
     };
-    for (int64_t tile = blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
+    for (int64_t tile = by_xcd ? (blockIdx.x / 8u) % (unsigned)tiles_x : blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
         for (int i = threadIdx.x; i < n_dig; i += BLOCK) L.cnt()[i] = 0;
         lds_sync();
         const int64_t t0 = r0 + tile * TILE1;
