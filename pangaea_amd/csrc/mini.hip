@@ -1244,6 +1244,9 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 {
     static_assert(!MERGE || SLOTS, "merged words are a form of the slot lookups");
     static_assert(!HALF || (SLOTS && !WIDE), "the count half is a form of the slot lookups on packed slots");
+#ifdef PG_MINI_GAPS                                              // (variant build for tools/wg_gaps.py: when a workgroup began and ended, and where)
+    const unsigned long long gap_t0 = __builtin_amdgcn_s_memtime();
+#endif
     // (the plan this launch was given describes another stream: its record count does not fit the record buffers -- nothing is
     // touched, bit 2 of the status word says so; KmerTable ties its cached plans to the stream, this is the backstop)
     if (word_cursor[-1] > rec_cap || (*status & PG_STATUS_PLAN_MISMATCH)) {     // (... or the first pass found the plan to be another stream's)
@@ -1698,6 +1701,16 @@ __global__ __launch_bounds__(BLK, 4) void mini_count_kernel(const uint64_t *__re
 #endif
             merged_lookup<CAP, BLK, DIG>(mc);
             PG_STAMP(3);
+#ifdef PG_MINI_GAPS
+            __syncthreads();
+            if (threadIdx.x == 0 && n_short) {             // (n_short: there was a second pass, `bases` is buffer B)
+                unsigned long long *gap = (unsigned long long *)(bases - rec_cap) + 4ull * blockIdx.x;     // (the first pass's buffer: dead by now)
+                gap[0] = gap_t0;
+                gap[1] = __builtin_amdgcn_s_memtime();
+                gap[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);    // HW_ID, XCC_ID
+                gap[3] = (unsigned long long)(r1 - r0);
+            }
+#endif
             return;
         }
         {
