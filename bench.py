@@ -241,9 +241,12 @@ def main():
             dist.init_process_group(args.backend)
 
     from pangaea_amd import dist as pdist
-    from pangaea_amd import kmer, synth
+    from pangaea_amd import kmer, runtime, synth
     from pangaea_amd.data import Data
     from pangaea_amd.models.VAENET import VAENET
+
+    # once per PROCESS, as Feature does when a call begins (under its ingest): the GEMM library's initialisation, on a helper thread
+    runtime.warm_blas(dev)
 
     n_bc = args.barcodes or max(1, args.pairs // 200)
     cfg = synth.SynthConfig(n_pairs=args.pairs, n_barcodes=n_bc, read_len=READ_LEN, seed=2022, first_pair=rank * args.pairs)

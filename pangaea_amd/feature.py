@@ -25,7 +25,7 @@ import numpy as np
 import pandas as pd
 import torch
 
-from . import _lib, dist as pdist
+from . import _lib, dist as pdist, runtime as _runtime
 from .kmer import KmerTable, Plan, count_kmers, features, tnf_ncols
 from .reads import ReadStream
 
@@ -252,6 +252,10 @@ class Feature:
     # ------------------------------------------------------------------ the reference's public methods
 
     def extract_features(self):
+        # (the network comes next, pangaea.py:70,90: its GEMM library initialises under the ingest -- see runtime.warm_blas; the
+        # count_tnf / count_kmer tools, which end with the matrices, do not ask for it)
+        if torch.cuda.is_available():
+            _runtime.warm_blas(getattr(self.args, "device", None) or torch.device("cuda", torch.cuda.current_device()))
         if self.world > 1:
             return self._extract_features_sharded()
         readnames1, abundance = self.run_jellyfish()

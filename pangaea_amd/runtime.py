@@ -9,6 +9,7 @@ import logging
 import os
 import subprocess
 import sys
+import threading
 
 import numpy as np
 import torch
@@ -84,3 +85,32 @@ def init_all(seed, threads, logfile, level, outdir, file_log: bool = True) -> No
         sink.setFormatter(layout)
         log.addHandler(sink)
     log.info("pangaea (MI355X feature path) starting, output in %s", outdir)
+
+
+def warm_blas(device, widths=(536, 512, 512, 32), rows: int = 4096):
+    """Start the GEMM library's one-time initialisation for ``device`` on a helper thread and return the thread (or None without
+    a GPU).  The first matrix product of a process loads hipBLASLt/rocBLAS and their kernel tables: 190 ms on an MI355X box
+    with a warm page cache, several times that on a fresh one -- more than the whole feature pass over 10 M read pairs takes,
+    and until round 4 it sat in front of the first encode.  The reference's flow is features first, network afterwards
+    (/root/reference/src/pangaea.py:70,90): the initialisation runs under the ingest instead.  ``widths`` are the layer widths
+    of the encoder the products are warmed for (VAENET: tnf + abundance columns -> 512 -> 512 -> latent); PANGAEA_WARM_BLAS=0
+    turns it off."""
+    device = torch.device(device)
+    if device.type != "cuda" or os.environ.get("PANGAEA_WARM_BLAS", "1") in ("", "0"):
+        return None
+
+    def work():
+        try:
+            with torch.cuda.device(device), torch.no_grad():
+                x = torch.zeros((rows, widths[0]), dtype=torch.float32, device=device)
+                for a, b in zip(widths[:-1], widths[1:]):
+                    x = torch.nn.functional.linear(x, torch.zeros((b, a), dtype=torch.float32, device=device), torch.zeros(b, dtype=torch.float32, device=device))
+                torch.cuda.current_stream(device).synchronize()
+        except RuntimeError as err:                              # (the real product will report what is wrong, in its own place)
+            logging.debug("warm_blas: %s", err)
+
+    # (not a daemon: a process that ends while the library is still initialising would kill the thread inside the driver --
+    # glibc aborts on the mutex it holds; the interpreter waits for the thread instead)
+    t = threading.Thread(target=work, name="pangaea-warm-blas", daemon=False)
+    t.start()
+    return t

@@ -208,3 +208,23 @@ def test_device_sampling_has_the_reference_distribution_and_numpy_mode_its_seque
     got = np.concatenate([np.asarray(b["bc"]) for b in weighted_batches(D(), 512, num_samples=300, replacement=False)])
     np.random.seed(8)
     assert list(got) == list(np.random.choice(range(n), size=300, p=w / w.sum(), replace=False))
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_blas_warm_up_is_a_no_op_without_a_gpu_and_a_thread_with_one(device, monkeypatch):
+    """runtime.warm_blas: the GEMM library's one-time initialisation on a helper thread (nothing to do on the CPU; switched off by
+    PANGAEA_WARM_BLAS=0); an encode that runs beside it or behind it gives the same latents"""
+    from pangaea_amd import runtime
+    assert runtime.warm_blas("cpu") is None
+    monkeypatch.setenv("PANGAEA_WARM_BLAS", "0")
+    assert runtime.warm_blas(device) is None
+    monkeypatch.delenv("PANGAEA_WARM_BLAS")
+    t = runtime.warm_blas(device)
+    if torch.device(device).type != "cuda":
+        assert t is None
+        return
+    x = torch.ones((64, 536), device=device)
+    w = torch.full((512, 536), 0.5, device=device)
+    y = torch.nn.functional.linear(x, w)                 # (beside the helper thread)
+    t.join()
+    assert not t.is_alive() and torch.equal(y, torch.nn.functional.linear(x, w)) and float(y[0, 0]) == 268.0
