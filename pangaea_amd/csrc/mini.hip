@@ -559,7 +559,8 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
     }
 }
 
-// ---- A2': region -> buckets.  Region = blockIdx.x / tiles_x, its records are [off[region << bits2], off[(region + 1) << bits2]);
+// ---- A2': region -> buckets.  tiles_x workgroups per region (all of them on one XCD, see below), its records are
+// [off[region << bits2], off[(region + 1) << bits2]);
 // digit = the low bits2 bits of meta (+ 128 for a LONG record: more than short_max k-mers).  Inside its bucket's range
 // [off[b], off[b + 1]) the short records fill from the front (cursor[b]) and the long ones from the back (cursor_l[b]): the
 // bucket workgroups treat a record in as many unrolled steps as its class can have k-mers, so sorting the two classes apart
