@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 7   /* 7: pg_build_flags (what kind of build a loaded library is), pg_mini_gather_entries names its buffer's size,
+#define PG_ABI_VERSION 8   /* 8: pg_inflate_to_memfd (gzip input for the ingest with the device copy inside);
+                              7: pg_build_flags (what kind of build a loaded library is), pg_mini_gather_entries names its buffer's size,
                                  pg_mini_shuffle_bytes_merged, a stream counted in pieces (pg_mini_count_piece / pg_mini_lookup_*);
                               6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
                               5: pg_mini_count takes the merged lookups' word buffer (pg_mini_merge_words), the multi-rank half entries;
@@ -104,6 +105,13 @@ int pg_ingest_fastq_shard(const char *path, int part, int n_parts, const int64_t
  * again after pg_ingest_place.  *out stays NULL with status PG_OK when the input is not an uncompressed file: the caller then
  * uses pg_ingest_fastq and copies the arrays itself.  The stream is identical to pg_ingest_fastq's for every piece size. */
 int64_t pg_ingest_staging_words(int64_t file_bytes);
+/* gzip input for the device ingest (feature.py:76-91 reads *.gz through `pigz -dc`: one inflate stream): the file is inflated
+ * into an anonymous in-memory file, as pg_ingest_fastq does for its threaded parse; *fd_out is then a descriptor that
+ * "/proc/self/fd/<fd>" names for pg_ingest_fastq_device (*bytes_out = the size of the text, for pg_ingest_staging_words) and
+ * that the caller closes.  *fd_out = -1 with status PG_OK: not a gzip file, or its text does not fit the memory this process
+ * may park it in (PG_INFLATE_MAX_BYTES; half of what is available by default) -- the caller takes pg_ingest_fastq, which
+ * then streams it. */
+int pg_inflate_to_memfd(const char *path, int *fd_out, int64_t *bytes_out);
 int pg_ingest_fastq_device(const char *path, int part, int n_parts, const int64_t *newlines_before, int64_t file_bytes,
                            uint64_t *staging_codes, uint32_t *staging_valid, int64_t staging_words, pg_reads **out);
 int pg_ingest_place(const pg_reads *r, uint64_t *staging_codes, const uint32_t *staging_valid, int64_t staging_words,

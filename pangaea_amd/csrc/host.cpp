@@ -1575,6 +1575,23 @@ int pg_internal_ingest_to_sink(const char *path, int part, int n_parts, const in
     return PG_OK;
 }
 
+extern "C" int pg_inflate_to_memfd(const char *path, int *fd_out, int64_t *bytes_out)
+{
+    if (!path || !fd_out || !bytes_out) return pg_fail(PG_EINVAL, "pg_inflate_to_memfd: null argument");
+    *fd_out = -1; *bytes_out = 0;
+    int fd; size_t size = 0; bool plain;
+    int rc = open_plain(path, fd, size, plain);
+    if (rc) return rc;
+    close(fd);
+    if (plain) return PG_OK;
+    int m = -1; size_t text = 0;
+    if ((rc = inflate_to_memfd(path, m, text, inflate_budget(1)))) return rc;
+    if (m < 0) return PG_OK;
+    *fd_out = m;
+    *bytes_out = (int64_t)text;
+    return PG_OK;
+}
+
 int64_t pg_internal_reads_pieces(const pg_reads *r, const int64_t **soff, const int64_t **cstart)
 {
     if (!r || r->piece_cstart.empty()) return -1;

@@ -143,17 +143,36 @@ class ReadStream:
     @classmethod
     def _ingest_to_device(cls, L, reads: str, part: int, n_parts: int, before, device) -> "ReadStream | None":
         """``pg_ingest_fastq_device``: the parser threads copy finished pieces to the GPU while the others parse on, the shift
-        into place is a kernel, no host copy of the stream exists.  None when the input is not an uncompressed file (or
+        into place is a kernel, no host copy of the stream exists.  gzip input is inflated into an in-memory file first.  None
+        when the input cannot go this way (a gzip shard, a gzip file whose text does not fit in memory, or
         ``PANGAEA_INGEST_ON_HOST=1``): the caller takes the host ingest and copies."""
         if os.environ.get("PANGAEA_INGEST_ON_HOST", "0") not in ("", "0"):
             return None
+        memfd = -1
         try:
             with open(reads, "rb") as f:
-                if f.read(2) == b"\x1f\x8b":
-                    return None
+                gz = f.read(2) == b"\x1f\x8b"
             size = os.path.getsize(reads)
         except OSError:
             return None                                      # (the host ingest reports it)
+        if gz:
+            # one inflate stream into an in-memory file (what pg_ingest_fastq does for its threaded parse), then the same
+            # pieces, copies and placement as for a plain file; a shard of a gzip file would inflate all of it on every rank
+            if n_parts > 1:
+                return None
+            fd, text = C.c_int(-1), C.c_int64(0)
+            _lib.check(L.pg_inflate_to_memfd(reads.encode(), C.byref(fd), C.byref(text)))
+            if fd.value < 0:
+                return None                                  # (does not fit in memory: the host ingest streams it)
+            memfd, size, reads = fd.value, int(text.value), f"/proc/self/fd/{fd.value}"
+        try:
+            return cls._ingest_plain_to_device(L, reads, part, n_parts, before, device, size)
+        finally:
+            if memfd >= 0:
+                os.close(memfd)
+
+    @classmethod
+    def _ingest_plain_to_device(cls, L, reads: str, part: int, n_parts: int, before, device, size: int) -> "ReadStream | None":
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(device):

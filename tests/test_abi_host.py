@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, f"declared in pangaea_feat.h but not exported: {missing}"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.load().pg_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.load().pg_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_in_tree_library_is_the_product_build():
@@ -484,3 +484,32 @@ def test_parallel_paired_ingest_equals_serial(tmp_path):
         os.environ.pop("PG_INGEST_BLOCK", None)
     rd = oracle.Reads(p1, p2)
     assert ref.run_names == rd.names and ref.n_pairs == rd.n_pairs
+
+
+def test_gzip_text_parked_in_memory_is_the_text(tmp_path, monkeypatch):
+    """pg_inflate_to_memfd (what the device ingest reads gzip input through): the descriptor holds the inflated bytes of a
+    one- and a two-member file; a plain file and a text beyond the budget give no descriptor and no error"""
+    import ctypes as C
+    import gzip
+    L = _lib.load()
+    text = b"".join(b"@r%d BX:Z:ACGT-1\nACGTNACGT\n+\nIIIIIIIII\n" % i for i in range(5000))
+    cases = {"one.gz": gzip.compress(text), "two.gz": gzip.compress(text[:70000]) + gzip.compress(text[70000:]), "plain.fq": text}
+    for name, data in cases.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        fd, size = C.c_int(-7), C.c_int64(-7)
+        _lib.check(L.pg_inflate_to_memfd(path.encode(), C.byref(fd), C.byref(size)))
+        if name == "plain.fq":
+            assert fd.value == -1 and size.value == 0
+            continue
+        assert fd.value >= 0 and size.value == len(text)
+        try:
+            assert open(f"/proc/self/fd/{fd.value}", "rb").read() == text
+        finally:
+            os.close(fd.value)
+    monkeypatch.setenv("PG_INFLATE_MAX_BYTES", "4096")
+    fd, size = C.c_int(-7), C.c_int64(-7)
+    _lib.check(L.pg_inflate_to_memfd(str(tmp_path / "one.gz").encode(), C.byref(fd), C.byref(size)))
+    assert fd.value == -1 and size.value == 0
+    with pytest.raises(RuntimeError):
+        _lib.check(L.pg_inflate_to_memfd(str(tmp_path / "missing.gz").encode(), C.byref(fd), C.byref(size)))

@@ -145,7 +145,7 @@ def test_device_ingest_of_degenerate_and_other_inputs(tmp_path, knobs):
                 os.environ.pop("PG_INGEST_PIECE", None)
             _same(ReadStream.from_fastq(path, device=DEV), want)
     os.environ.pop("PG_INGEST_PIECE", None)
-    # gzip input is not cut by bytes: the host ingest runs and the arrays are copied, same result
+    # gzip input: inflated into an in-memory file, then the same pieces and copies (test_gzip_input_... below)
     gz = str(tmp_path / "two.fq.gz")
     with gzip.open(gz, "wb") as f:
         f.write(cases["two.fq"].encode())
@@ -163,3 +163,43 @@ def test_device_ingest_of_degenerate_and_other_inputs(tmp_path, knobs):
     h = C.c_void_p()
     rc = L.pg_ingest_fastq_device(path.encode(), 0, 1, None, os.path.getsize(path), C.c_void_p(small.data_ptr()), C.c_void_p(small.data_ptr()), 8, C.byref(h))
     assert rc == -1 and not h
+
+
+def test_gzip_input_goes_through_the_device_ingest(tmp_path, knobs, monkeypatch):
+    """feature.py:76-91 reads *.gz through one `pigz -dc` stream; here the text is inflated into an in-memory file
+    (pg_inflate_to_memfd) and then takes the same pieces, copies and placement kernel as a plain file -- the golden gzip input,
+    a multi-member gzip file and a larger synthetic one, against the host ingest; a text that may not be parked in memory
+    (PG_INFLATE_MAX_BYTES) falls back to the host ingest, with the same stream"""
+    L = knobs
+    calls = []
+    real = ReadStream._ingest_plain_to_device.__func__
+    monkeypatch.setattr(ReadStream, "_ingest_plain_to_device", classmethod(lambda cls, L_, reads, *a: (calls.append(reads), real(cls, L_, reads, *a))[1]))
+    golden = os.path.join(GOLDEN, "polya.fq.gz")
+    big = str(tmp_path / "big.fq.gz")
+    cfg = synth.SynthConfig(n_pairs=3000, n_barcodes=40, n_genomes=2, genome_len=20_000, fragment=2_000, n_rate=0.1, seed=5)
+    plain = str(tmp_path / "big.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, plain)
+    text = open(plain, "rb").read()
+    with gzip.open(big, "wb") as f:
+        f.write(text)
+    members = str(tmp_path / "members.fq.gz")              # two gzip members back to back (what `cat a.gz b.gz` makes)
+    cut = text.index(b"\n@", len(text) // 2) + 1
+    open(members, "wb").write(gzip.compress(text[:cut]) + gzip.compress(text[cut:]))
+    for path in (golden, big, members):
+        for threads, piece in ((1, None), (4, "4096")):
+            L.pg_set_ingest_threads(threads)
+            if piece:
+                os.environ["PG_INGEST_PIECE"] = piece
+            else:
+                os.environ.pop("PG_INGEST_PIECE", None)
+            n = len(calls)
+            got = ReadStream.from_fastq(path, device=DEV)
+            assert len(calls) == n + 1 and calls[-1].startswith("/proc/self/fd/")
+            _same(got, ReadStream.from_fastq(path))
+    _same(ReadStream.from_fastq(members, device=DEV), ReadStream.from_fastq(plain))
+    os.environ.pop("PG_INGEST_PIECE", None)
+    assert not [f for f in os.listdir("/proc/self/fd") if os.path.realpath(f"/proc/self/fd/{f}").startswith("/memfd:pg_inflate")]     # descriptors closed
+    monkeypatch.setenv("PG_INFLATE_MAX_BYTES", "1000")
+    n = len(calls)
+    _same(ReadStream.from_fastq(big, device=DEV), ReadStream.from_fastq(plain))
+    assert len(calls) == n
