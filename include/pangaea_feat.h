@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 8   /* 8: pg_inflate_to_memfd (gzip input for the ingest with the device copy inside);
+#define PG_ABI_VERSION 9   /* 9: pg_ingest_fastq_pair_device / pg_ingest_place_pair (-1 / -2 input with the device copy inside);
+                              8: pg_inflate_to_memfd (gzip input for the ingest with the device copy inside);
                               7: pg_build_flags (what kind of build a loaded library is), pg_mini_gather_entries names its buffer's size,
                                  pg_mini_shuffle_bytes_merged, a stream counted in pieces (pg_mini_count_piece / pg_mini_lookup_*);
                               6: pg_ingest_fastq_device / pg_ingest_place (ingest with the device copy inside);
@@ -116,6 +117,21 @@ int pg_ingest_fastq_device(const char *path, int part, int n_parts, const int64_
                            uint64_t *staging_codes, uint32_t *staging_valid, int64_t staging_words, pg_reads **out);
 int pg_ingest_place(const pg_reads *r, uint64_t *staging_codes, const uint32_t *staging_valid, int64_t staging_words,
                     uint64_t *codes, uint32_t *valid, int64_t n_words, void *stream);
+/* The same for -1 / -2 input (count_tnf.cpp:174-231, the paired loop: a pair whose names or barcodes differ is skipped, its reads
+ * follow the last run; feature.py:76-83: bases of a quality below '?' are not bases to jellyfish -- the low-quality plane):
+ * R1 is cut into pieces of PG_INGEST_PIECE bytes, a thread that has paired and packed the records of a piece (and found the
+ * same records in R2) copies its local streams -- codes, validity, low quality -- into the three device STAGING arrays while
+ * the others go on, and pg_ingest_place_pair shifts the pieces into place: codes, valid and -- if pg_reads_staged_lowq --
+ * lowq[n_words] (pg_reads_lowq of such a handle is NULL: the plane exists on the device only).  staging_words >=
+ * pg_ingest_pair_staging_words(bytes of R1, bytes of R2).  *out stays NULL with status PG_OK when the two are not
+ * uncompressed files (gzip: pg_inflate_to_memfd first): the caller then uses pg_ingest_fastq.  Same stream, runs and counters
+ * as pg_ingest_fastq(r1, r2) for every piece size and thread count. */
+int64_t pg_ingest_pair_staging_words(int64_t r1_bytes, int64_t r2_bytes);
+int pg_ingest_fastq_pair_device(const char *r1, const char *r2, int64_t r1_bytes, int64_t r2_bytes, uint64_t *staging_codes,
+                                uint32_t *staging_valid, uint32_t *staging_lowq, int64_t staging_words, pg_reads **out);
+int pg_reads_staged_lowq(const pg_reads *r);
+int pg_ingest_place_pair(const pg_reads *r, uint64_t *staging_codes, const uint32_t *staging_valid, const uint32_t *staging_lowq,
+                         int64_t staging_words, uint64_t *codes, uint32_t *valid, uint32_t *lowq, int64_t n_words, void *stream);
 void pg_reads_free(pg_reads *r);
 int64_t pg_reads_n_chars(const pg_reads *r);
 int64_t pg_reads_n_words(const pg_reads *r); /* padded word count of codes[] and valid[] */

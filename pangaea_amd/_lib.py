@@ -32,7 +32,7 @@ HASH_COUNT_SAT = 1 << 21
 TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
-ABI_VERSION = 8
+ABI_VERSION = 9
 MINI_MIN_K, MINI_MAX_LOG2_BUCKETS, MINI_MAX_ROWS, MINI_WIDE_MAX_LOG2_BUCKET_SLOTS = 13, 16, (1 << 21) - 2, 13
 SHUFFLE_MAX_VSIZE = 512
 DEFERRED_MAX_GROUP_LOG2 = 3
@@ -90,6 +90,10 @@ def load() -> C.CDLL:
         "pg_inflate_to_memfd": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(i64)]),
         "pg_ingest_fastq_device": (i32, [cp, i32, i32, C.POINTER(i64), i64, vp, vp, i64, C.POINTER(vp)]),
         "pg_ingest_place": (i32, [vp, vp, vp, i64, vp, vp, i64, vp]),
+        "pg_ingest_pair_staging_words": (i64, [i64, i64]),
+        "pg_ingest_fastq_pair_device": (i32, [C.c_char_p, C.c_char_p, i64, i64, vp, vp, vp, i64, C.POINTER(vp)]),
+        "pg_reads_staged_lowq": (i32, [vp]),
+        "pg_ingest_place_pair": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, i64, vp]),
         "pg_set_ingest_threads": (None, [i32]),
         "pg_reads_free": (None, [vp]),
         "pg_reads_n_chars": (i64, [vp]),
@@ -171,7 +175,7 @@ def load() -> C.CDLL:
     return L
 
 
-EXPORTS = ["pg_abi_version", "pg_build_flags", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_fastq_count_newlines", "pg_ingest_fastq_shard", "pg_ingest_staging_words", "pg_inflate_to_memfd", "pg_ingest_fastq_device", "pg_ingest_place",
+EXPORTS = ["pg_abi_version", "pg_build_flags", "pg_last_error", "pg_device_count", "pg_ingest_fastq", "pg_fastq_count_newlines", "pg_ingest_fastq_shard", "pg_ingest_staging_words", "pg_inflate_to_memfd", "pg_ingest_fastq_device", "pg_ingest_place", "pg_ingest_pair_staging_words", "pg_ingest_fastq_pair_device", "pg_reads_staged_lowq", "pg_ingest_place_pair",
            "pg_set_ingest_threads", "pg_reads_free", "pg_reads_n_chars",
            "pg_reads_n_words", "pg_reads_n_pairs", "pg_reads_n_unpaired", "pg_reads_n_runs", "pg_reads_codes",
            "pg_reads_valid", "pg_reads_lower", "pg_reads_lowq", "pg_reads_run_off", "pg_reads_run_name", "pg_reads_run_names", "pg_reads_mode", "pg_reads_rows", "pg_words_for",

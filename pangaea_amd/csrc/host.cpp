@@ -284,6 +284,7 @@ struct pg_reads {
     // pg_ingest_fastq_device: no host arrays; piece p's packed characters lie at word piece_soff[p] of the staging arrays and
     // belong at characters [piece_cstart[p], piece_cstart[p + 1]) of the stream
     std::vector<int64_t> piece_soff, piece_cstart;
+    bool staged_lowq = false;                    // (... of paired input: the staging arrays hold a low-quality plane to place as well)
 
     pg_reads() = default;
     pg_reads(const pg_reads &) = delete;
@@ -773,7 +774,7 @@ int ingest_interleaved_range(int fd, size_t A, size_t B, const char *path, pg_re
             const int64_t nw = (int64_t)st.codes.size();
             o.soff = staged.fetch_add(nw, std::memory_order_relaxed);
             if (nw == 0) return;
-            int rc = o.soff + nw <= sink->capacity_words ? sink->copy(sink->ctx, worker, o.soff, st.codes.data(), st.valid.data(), nw) : PG_EINVAL;
+            int rc = o.soff + nw <= sink->capacity_words ? sink->copy(sink->ctx, worker, o.soff, st.codes.data(), st.valid.data(), nullptr, nw) : PG_EINVAL;
             if (rc) { int zero = 0; sink_rc.compare_exchange_strong(zero, rc); }
         }
     });
@@ -948,6 +949,7 @@ struct PairSink {                 // what a run of (R1 record, R2 record) pairs 
     bool any = false;
     std::string first, last;
     int64_t first_end = 0, pairs = 0, unpaired = 0;
+    int64_t soff_main = 0, soff_orph = 0;     // (sink form) word offsets of the two local streams in the staging arrays
     PairSink() { main.with_q = true; orph.with_q = true; }
     void keep(const char *s1, size_t l1, const char *q1, size_t q1n, const char *s2, size_t l2, const char *q2, size_t q2n,
               const char *bc, size_t bcn)
@@ -1071,16 +1073,25 @@ int paired_tail(int fd1, size_t a1, size_t n1, int fd2, size_t a2, size_t n2, ui
     return PG_OK;
 }
 
-int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r1, const char *r2, pg_reads *R, int T)
+// With a sink (pg_ingest_fastq_pair_device) R1 is cut into pieces of PG_INGEST_PIECE bytes that the threads take from a queue; the
+// local streams of a finished piece go to the sink (a copy to the GPU) while the others parse on, and the placement is left to
+// the device (pg_ingest_place_pair); without one there is a piece per thread, placed in host arrays.
+int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r1, const char *r2, pg_reads *R, int T, const pg_piece_sink *sink = nullptr)
 {
+    int P = T;                                                  // pieces of R1
+    if (sink) {
+        size_t piece = (size_t)16 << 20;
+        if (const char *e = getenv("PG_INGEST_PIECE")) { long v = atol(e); if (v >= 64) piece = (size_t)v; }
+        P = (int)std::max<size_t>(1, std::min<size_t>((n1 + piece - 1) / piece, (size_t)1 << 20));
+    }
     PhaseTimer tm;
     const size_t block = reader_block((size_t)1 << 20);
-    // ---- A. lines of both files; R1 in T ranges (the threads' shares), R2 in finer blocks (to find a record's start)
-    const int B2 = 16 * T;
+    // ---- A. lines of both files; R1 in P ranges (the pieces), R2 in finer blocks (to find a record's start)
+    const int B2 = 16 * std::max(T, std::min(P, 4096));
     std::vector<uint64_t> nl1, nl2;
     uint64_t lines1 = 0, lines2 = 0;
     int rc;
-    if ((rc = count_lines_blocks(fd1, n1, T, T, nl1, lines1, r1))) return rc;
+    if ((rc = count_lines_blocks(fd1, n1, P, T, nl1, lines1, r1))) return rc;
     if ((rc = count_lines_blocks(fd2, n2, B2, T, nl2, lines2, r2))) return rc;
     const uint64_t full = std::min(lines1 / 4, lines2 / 4);     // records that are complete in both files
     tm.lap("lines");
@@ -1099,21 +1110,40 @@ int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r
     }
     tm.lap("latch");
     // ---- B. every thread: first record of its R1 range, the same record in R2, then pairs up to the next thread's first record
-    std::vector<uint64_t> rec0(T + 1, full);
-    std::vector<char> at_line_start(T, 1), bad(T, 0);
-    for (int t = 0; t < T; ++t) {
-        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)T);
+    std::vector<uint64_t> rec0(P + 1, full);
+    std::vector<char> at_line_start(P, 1), bad(P, 0);
+    for (int t = 0; t < P; ++t) {
+        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)P);
         if (t > 0 && a > 0) { char c = 0; if (pread(fd1, &c, 1, (off_t)(a - 1)) != 1) return pg_fail(PG_EIO, "read error in %s", r1); at_line_start[t] = c == '\n'; }
         const uint64_t line = nl1[t] + (at_line_start[t] ? 0 : 1);       // first line that starts in the range
         rec0[t] = std::min<uint64_t>((line + 3) / 4, full);
     }
-    std::vector<PairSink> out(T + 1);                           // [T] = the tail
-    std::vector<uint64_t> bad_rec(T, UINT64_MAX);
-    run_threads(T, [&](int t) {
+    std::vector<PairSink> out(P + 1);                           // [P] = the tail
+    std::vector<uint64_t> bad_rec(P, UINT64_MAX);
+    std::atomic<int> next_piece{0};
+    std::atomic<int64_t> staged{0};
+    std::atomic<int> sink_rc{0};
+    // the two local streams of a finished piece -> the sink; their vectors are given back (n, any_q and the sparse lists stay)
+    auto to_sink = [&](PairSink &o, int worker) {
+        int64_t *soff[2] = {&o.soff_main, &o.soff_orph};
+        LocalStream *ls[2] = {&o.main, &o.orph};
+        for (int i = 0; i < 2; ++i) {
+            ls[i]->finish();
+            const int64_t nw = (int64_t)ls[i]->codes.size();
+            *soff[i] = staged.fetch_add(nw, std::memory_order_relaxed);
+            if (nw) {
+                const int rc_ = *soff[i] + nw <= sink->capacity_words
+                              ? sink->copy(sink->ctx, worker, *soff[i], ls[i]->codes.data(), ls[i]->valid.data(), ls[i]->lowq.data(), nw) : PG_EINVAL;
+                if (rc_) { int zero = 0; sink_rc.compare_exchange_strong(zero, rc_); }
+            }
+            std::vector<uint64_t>().swap(ls[i]->codes); std::vector<uint32_t>().swap(ls[i]->valid); std::vector<uint32_t>().swap(ls[i]->lowq);
+        }
+    };
+    auto one_piece = [&](int t, int worker) {
         PairSink &o = out[t];
         const uint64_t ra = rec0[t], rb = rec0[t + 1];
         if (ra >= rb) return;
-        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)T);
+        const size_t a = (size_t)((unsigned __int128)n1 * (unsigned)t / (unsigned)P);
         UnitReader rd1(fd1, a, n1, block);
         uint64_t line = nl1[t];
         if (!at_line_start[t]) { if (!rd1.skip_line()) { bad[t] = 2; return; } ++line; }
@@ -1137,10 +1167,15 @@ int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r
                 o.skip(u.p[1], u.n[1], u.p[3], u.n[3], v.p[1], v.n[1], v.p[3], v.n[3]);
             }
         }
-        if (rd1.io_error() || rd2.io_error()) bad[t] = 6;
+        if (rd1.io_error() || rd2.io_error()) { bad[t] = 6; return; }
+        if (sink) to_sink(o, worker);
+    };
+    run_threads(T, [&](int worker) {
+        if (!sink) { one_piece(worker, worker); return; }
+        for (int p; (p = next_piece.fetch_add(1, std::memory_order_relaxed)) < P;) one_piece(p, worker);
     });
     uint64_t first_bad = UINT64_MAX;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < P; ++t) {
         if (bad[t]) return pg_fail(PG_EIO, "read error in %s / %s (stage %d, thread %d)", r1, r2, (int)bad[t], t);
         first_bad = std::min(first_bad, bad_rec[t]);
     }
@@ -1151,32 +1186,45 @@ int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r
     int mode = MODE_UNSET;
     {
         size_t a1 = 0, a2 = 0;
-        if ((rc = offset_of_line(fd1, n1, T, nl1, 4 * full, a1, r1)) || (rc = offset_of_line(fd2, n2, B2, nl2, 4 * full, a2, r2))) return rc;
-        if ((rc = paired_tail(fd1, a1, n1, fd2, a2, n2, full, L, mode, out[T], r1))) return rc;
+        if ((rc = offset_of_line(fd1, n1, P, nl1, 4 * full, a1, r1)) || (rc = offset_of_line(fd2, n2, B2, nl2, 4 * full, a2, r2))) return rc;
+        if ((rc = paired_tail(fd1, a1, n1, fd2, a2, n2, full, L, mode, out[P], r1))) return rc;
         if (L.header != UINT64_MAX) mode = L.mode;
+        if (sink) to_sink(out[P], 0);
+    }
+    if (sink) {
+        if (sink_rc.load() == PG_EINVAL && staged.load() > sink->capacity_words)
+            return pg_fail(PG_EINVAL, "staging arrays of %lld words are too small for %s / %s (pg_ingest_pair_staging_words)", (long long)sink->capacity_words, r1, r2);
+        if (sink_rc.load()) return sink_rc.load();               // (the sink recorded its message)
     }
     // ---- C. place: kept pairs of the threads and of the tail, then the reads of the skipped pairs in the same order
     std::vector<LocalStream *> piece;
-    for (int t = 0; t <= T; ++t) { out[t].main.finish(); piece.push_back(&out[t].main); }
-    for (int t = 0; t <= T; ++t) { out[t].orph.finish(); piece.push_back(&out[t].orph); }
-    const int P = (int)piece.size();
-    std::vector<int64_t> cstart(P + 1, 0);
-    for (int i = 0; i < P; ++i) cstart[i + 1] = cstart[i] + piece[i]->n;
-    const int64_t total = cstart[P];
+    for (int t = 0; t <= P; ++t) { if (!sink) out[t].main.finish(); piece.push_back(&out[t].main); }
+    for (int t = 0; t <= P; ++t) { if (!sink) out[t].orph.finish(); piece.push_back(&out[t].orph); }
+    const int NP = (int)piece.size();
+    std::vector<int64_t> cstart(NP + 1, 0);
+    for (int i = 0; i < NP; ++i) cstart[i + 1] = cstart[i] + piece[i]->n;
+    const int64_t total = cstart[NP];
+    bool any_q = false, any_lower = false;
+    for (int i = 0; i < NP; ++i) { any_q |= piece[i]->any_q; any_lower |= !piece[i]->lower.empty(); }
+    if (sink) {                                       // the device does it: pg_ingest_place_pair
+        R->set_stream_size(total);
+        R->piece_soff.resize(NP);
+        for (int t = 0; t <= P; ++t) { R->piece_soff[t] = out[t].soff_main; R->piece_soff[P + 1 + t] = out[t].soff_orph; }
+        R->piece_cstart = cstart;
+        R->staged_lowq = any_q;
+    } else {
     if (!R->alloc_stream(total)) return pg_fail(PG_ENOMEM, "out of memory while ingesting %s", r1);
     uint64_t *gc = R->codes_w; uint32_t *gv = R->valid_w;
-    bool any_q = false, any_lower = false;
-    for (int i = 0; i < P; ++i) { any_q |= piece[i]->any_q; any_lower |= !piece[i]->lower.empty(); }
     if (any_q) R->lowq_plane.assign((size_t)R->n_words, 0u);
     uint32_t *gq = any_q ? R->lowq_plane.data() : nullptr;
     for (int64_t w = (total + 31) >> 5; w < R->n_words; ++w) { gc[w] = 0; gv[w] = 0; }
-    for (int i = 0; i < P; ++i)
+    for (int i = 0; i < NP; ++i)
         if (piece[i]->n) {
             const int64_t a = cstart[i] >> 5, b = (cstart[i + 1] - 1) >> 5;
             gc[a] = 0; gv[a] = 0; gc[b] = 0; gv[b] = 0;
         }
     run_threads(T, [&](int t) {
-        for (int i = t; i < P; i += T) {
+        for (int i = t; i < NP; i += T) {
             const LocalStream &ls = *piece[i];
             if (ls.n == 0) continue;
             const int64_t w0 = cstart[i] >> 5, w1 = (cstart[i + 1] - 1) >> 5;
@@ -1196,9 +1244,10 @@ int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r
         }
     });
     if (any_q) R->lowq_w = R->lowq_plane.data();
+    }
     if (any_lower) {
         R->lower_plane.assign((size_t)R->n_words, 0u);
-        for (int i = 0; i < P; ++i)
+        for (int i = 0; i < NP; ++i)
             for (const LowerMask &m : piece[i]->lower) {
                 const int64_t pos = cstart[i] + m.pos;
                 const int sh = (int)(pos & 31);
@@ -1213,7 +1262,7 @@ int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r
     R->run_off.push_back(0);
     std::string none;
     const std::string *last = &none;
-    for (int t = 0; t <= T; ++t) {
+    for (int t = 0; t <= P; ++t) {
         R->n_pairs += out[t].pairs;
         R->n_unpaired += out[t].unpaired;
         if (!out[t].any) continue;
@@ -1221,7 +1270,7 @@ int ingest_paired_threaded(int fd1, size_t n1, int fd2, size_t n2, const char *r
         for (const Change &c : out[t].changes) { R->run_off.push_back(cstart[t] + c.end_pos); R->run_name.push_back(c.prev); }
         last = &out[t].last;
     }
-    R->run_off.push_back(cstart[T + 1]);
+    R->run_off.push_back(cstart[P + 1]);
     R->run_name.push_back(*last);
     tm.lap("runs");
     return PG_OK;
@@ -1591,6 +1640,30 @@ extern "C" int pg_inflate_to_memfd(const char *path, int *fd_out, int64_t *bytes
     *bytes_out = (int64_t)text;
     return PG_OK;
 }
+
+// -1 / -2 input with the pieces handed to a sink; *out stays NULL (status PG_OK) when the two are not uncompressed files of some size
+int pg_internal_ingest_pair_to_sink(const char *r1, const char *r2, const pg_piece_sink *sink, pg_reads **out)
+{
+    *out = nullptr;
+    int fd1, fd2; size_t n1 = 0, n2 = 0; bool p1, p2;
+    int rc = open_plain(r1, fd1, n1, p1);
+    if (rc) return rc;
+    if ((rc = open_plain(r2, fd2, n2, p2))) { close(fd1); return rc; }
+    if (!p1 || !p2 || n1 < 64) { close(fd1); close(fd2); return PG_OK; }
+    pg_reads *R = new (std::nothrow) pg_reads();
+    if (!R) { close(fd1); close(fd2); return pg_fail(PG_ENOMEM, "out of memory"); }
+    try {
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)ingest_threads(), n1 >> 10));
+        rc = ingest_paired_threaded(fd1, n1, fd2, n2, r1, r2, R, T, sink);
+    } catch (const std::bad_alloc &) {
+        rc = pg_fail(PG_ENOMEM, "out of memory while ingesting %s", r1);
+    }
+    close(fd1); close(fd2);
+    if (rc) { delete R; return rc; }
+    *out = R;
+    return PG_OK;
+}
+bool pg_internal_reads_staged_lowq(const pg_reads *r) { return r && r->staged_lowq; }
 
 int64_t pg_internal_reads_pieces(const pg_reads *r, const int64_t **soff, const int64_t **cstart)
 {

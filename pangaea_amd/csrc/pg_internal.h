@@ -13,9 +13,12 @@ int pg_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3))
 struct pg_piece_sink {
     void *ctx;
     int64_t capacity_words;
-    int (*copy)(void *ctx, int worker, int64_t dst_word, const uint64_t *codes, const uint32_t *valid, int64_t n_words);
+    // (lowq: the low-quality plane of a piece of -1 / -2 input, NULL for interleaved input)
+    int (*copy)(void *ctx, int worker, int64_t dst_word, const uint64_t *codes, const uint32_t *valid, const uint32_t *lowq, int64_t n_words);
 };
 int pg_internal_ingest_to_sink(const char *path, int part, int n_parts, const int64_t *newlines_before, const pg_piece_sink *sink, pg_reads **out);
+int pg_internal_ingest_pair_to_sink(const char *r1, const char *r2, const pg_piece_sink *sink, pg_reads **out);
+bool pg_internal_reads_staged_lowq(const pg_reads *r);
 // the pieces of a pg_reads that came through a sink: piece p lies at word soff[p] of the staging arrays and belongs at characters
 // [cstart[p], cstart[p + 1]) of the stream; returns their number, -1 for a pg_reads with host arrays
 int64_t pg_internal_reads_pieces(const pg_reads *r, const int64_t **soff, const int64_t **cstart);

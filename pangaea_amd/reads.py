@@ -104,8 +104,9 @@ class ReadStream:
     def from_fastq(cls, reads1: str, reads2: str | None = None, device: str | torch.device = "cpu") -> "ReadStream":
         """ingest an interleaved FASTQ (``reads2`` None) or an R1/R2 pair; gzip or plain"""
         L = _lib.load()
-        if reads2 is None and torch.device(device).type == "cuda":
-            s = cls._ingest_to_device(L, str(reads1), 0, 1, None, torch.device(device))
+        if torch.device(device).type == "cuda":
+            s = (cls._ingest_to_device(L, str(reads1), 0, 1, None, torch.device(device)) if reads2 is None
+                 else cls._ingest_pair_to_device(L, str(reads1), str(reads2), torch.device(device)))
             if s is not None:
                 return s
         h = C.c_void_p()
@@ -201,6 +202,73 @@ class ReadStream:
                       L.pg_reads_mode(h).decode(), valid_lower=lower)
             del owner
         return out
+
+    @staticmethod
+    def _plain_or_inflated(L, path: str):
+        """(path to read, size of the text, descriptor to close or -1); None: a gzip file whose text may not be parked in memory"""
+        with open(path, "rb") as f:
+            gz = f.read(2) == b"\x1f\x8b"
+        if not gz:
+            return path, os.path.getsize(path), -1
+        fd, text = C.c_int(-1), C.c_int64(0)
+        _lib.check(L.pg_inflate_to_memfd(path.encode(), C.byref(fd), C.byref(text)))
+        if fd.value < 0:
+            return None
+        return f"/proc/self/fd/{fd.value}", int(text.value), fd.value
+
+    @classmethod
+    def _ingest_pair_to_device(cls, L, reads1: str, reads2: str, device) -> "ReadStream | None":
+        """``pg_ingest_fastq_pair_device``: -1 / -2 input with the copy to the GPU inside -- the threads pair and pack the records
+        of a piece of R1 (and the same records of R2) and copy its streams (codes, validity, low quality) to the GPU while the
+        others go on; placement is a kernel.  gzip files are inflated into in-memory files first, side by side.  None when the
+        input cannot go this way (tiny files, a text that does not fit in memory, ``PANGAEA_INGEST_ON_HOST=1``)."""
+        if os.environ.get("PANGAEA_INGEST_ON_HOST", "0") not in ("", "0"):
+            return None
+        opened = []
+        try:
+            try:
+                for p in (reads1, reads2):
+                    got = cls._plain_or_inflated(L, p)
+                    if got is None:
+                        return None
+                    opened.append(got)
+            except OSError:
+                return None                                  # (the host ingest reports it)
+            (p1, n1, _), (p2, n2, _) = opened
+            if device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            with torch.cuda.device(device):
+                cap = int(L.pg_ingest_pair_staging_words(n1, n2))
+                sc = torch.empty(cap, dtype=torch.int64, device=device)
+                sv = torch.empty(cap, dtype=torch.int32, device=device)
+                sq = torch.empty(cap, dtype=torch.int32, device=device)
+                torch.cuda.current_stream().synchronize()    # (the copies run on the library's own streams)
+                h = C.c_void_p()
+                _lib.check(L.pg_ingest_fastq_pair_device(p1.encode(), p2.encode(), n1, n2, C.c_void_p(sc.data_ptr()), C.c_void_p(sv.data_ptr()),
+                                                         C.c_void_p(sq.data_ptr()), cap, C.byref(h)))
+                if not h:
+                    return None
+                owner = _IngestHandle(L, h)
+                nw, nr = L.pg_reads_n_words(h), L.pg_reads_n_runs(h)
+                codes = torch.empty(nw, dtype=torch.int64, device=device)
+                valid = torch.empty(nw, dtype=torch.int32, device=device)
+                lowq = torch.empty(nw, dtype=torch.int32, device=device) if L.pg_reads_staged_lowq(h) else None
+                _lib.check(L.pg_ingest_place_pair(h, C.c_void_p(sc.data_ptr()), C.c_void_p(sv.data_ptr()), C.c_void_p(sq.data_ptr()), cap,
+                                                  C.c_void_p(codes.data_ptr()), C.c_void_p(valid.data_ptr()),
+                                                  C.c_void_p(lowq.data_ptr()) if lowq is not None else None, nw,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                lower_ptr = L.pg_reads_lower(h)
+                lower = torch.from_numpy(np.ctypeslib.as_array(C.cast(lower_ptr, C.POINTER(C.c_int32)), shape=(nw,)).copy()).to(device) if lower_ptr else None
+                run_off = np.ctypeslib.as_array(C.cast(L.pg_reads_run_off(h), C.POINTER(C.c_int64)), shape=(nr + 1,)).copy()
+                names = cls._run_names(L, h, nr)
+                out = cls(codes, valid, int(L.pg_reads_n_chars(h)), run_off, names, int(L.pg_reads_n_pairs(h)), int(L.pg_reads_n_unpaired(h)),
+                          L.pg_reads_mode(h).decode(), valid_lower=lower, valid_lowq=lowq)
+                del owner
+            return out
+        finally:
+            for _, _, fd in opened:
+                if fd >= 0:
+                    os.close(fd)
 
     @staticmethod
     def _run_names(L, h, nr: int) -> list:

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, f"declared in pangaea_feat.h but not exported: {missing}"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.load().pg_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.load().pg_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_in_tree_library_is_the_product_build():

@@ -33,6 +33,10 @@ def _same(dev_stream, host_stream):
     assert (dev_stream.valid_lower is None) == (host_stream.valid_lower is None)
     if host_stream.valid_lower is not None:
         assert np.array_equal(dev_stream.valid_lower.cpu().numpy()[:n], host_stream.valid_lower.numpy()[:n])
+    assert (dev_stream.valid_lowq is None) == (host_stream.valid_lowq is None)
+    if host_stream.valid_lowq is not None:
+        got_q = dev_stream.valid_lowq.cpu().numpy()
+        assert np.array_equal(got_q[:n], host_stream.valid_lowq.numpy()[:n]) and not got_q[n:].any()
 
 
 def _plain_goldens(tmp_path):
@@ -203,3 +207,99 @@ def test_gzip_input_goes_through_the_device_ingest(tmp_path, knobs, monkeypatch)
     n = len(calls)
     _same(ReadStream.from_fastq(big, device=DEV), ReadStream.from_fastq(plain))
     assert len(calls) == n
+
+
+def _split_pairs(interleaved: str, r1: str, r2: str, mutate=None):
+    """an interleaved FASTQ file as -1 / -2 files (records alternate); ``mutate(i, rec1, rec2)`` may change pair i"""
+    lines = open(interleaved).read().splitlines(keepends=True)
+    with open(r1, "w") as a, open(r2, "w") as b:
+        for i in range(0, len(lines) - 7, 8):
+            x, y = lines[i:i + 4], lines[i + 4:i + 8]
+            if mutate:
+                x, y = mutate(i // 8, x, y)
+            a.writelines(x); b.writelines(y)
+
+
+def test_paired_files_go_through_the_device_ingest(tmp_path, knobs, monkeypatch):
+    """-1 / -2 input (count_tnf.cpp:174-231 + the low-quality plane of feature.py:76-83) with the copy to the GPU inside
+    (pg_ingest_fastq_pair_device + pg_ingest_place_pair): same stream, runs, counters and planes as the host ingest, for pieces of
+    a few hundred bytes up to one piece, one thread and several; the golden pairs; pairs that do not match (skipped, their reads
+    behind the last run), low qualities, soft-masked bases, an R2 that is shorter; gzip pairs by way of the in-memory files"""
+    L = knobs
+    took = []                                                             # did the device form take the input (or hand it back)?
+    real = ReadStream._ingest_pair_to_device.__func__
+    monkeypatch.setattr(ReadStream, "_ingest_pair_to_device", classmethod(lambda cls, *a: (lambda r: (took.append(r is not None), r)[1])(real(cls, *a))))
+    for stem in ("pair", "pairq"):
+        r1, r2 = os.path.join(GOLDEN, f"{stem}_R1.fq"), os.path.join(GOLDEN, f"{stem}_R2.fq")
+        L.pg_set_ingest_threads(1)
+        want = ReadStream.from_fastq(r1, r2)
+        for threads, piece in ((1, None), (3, "200"), (4, "4096")):
+            L.pg_set_ingest_threads(threads)
+            if piece:
+                os.environ["PG_INGEST_PIECE"] = piece
+            else:
+                os.environ.pop("PG_INGEST_PIECE", None)
+            _same(ReadStream.from_fastq(r1, r2, device=DEV), want)
+    assert took == [True] * 6
+    # a larger pair with everything in it
+    cfg = synth.SynthConfig(n_pairs=20_000, n_barcodes=97, n_genomes=2, genome_len=30_000, fragment=3_000, n_rate=0.1, unbarcoded=0.05, seed=11)
+    fq = str(tmp_path / "i.fq")
+    synth.write_fastq(synth.generate(cfg), cfg, fq)
+    rng = np.random.RandomState(3)
+
+    def mutate(i, x, y):
+        u = rng.rand()
+        if u < 0.02:                                                      # names differ: the pair is skipped
+            y = [y[0].replace("@", "@x", 1)] + y[1:]
+        elif u < 0.3:                                                     # low qualities in one read
+            q = list(x[3].rstrip("\n"))
+            for j in rng.randint(0, len(q), size=5):
+                q[j] = "#"
+            x = x[:3] + ["".join(q) + "\n"]
+        elif u < 0.35:                                                    # a soft-masked stretch
+            sq = y[1].rstrip("\n")
+            y = [y[0], sq[:10] + sq[10:40].lower() + sq[40:] + "\n"] + y[2:]
+        return x, y
+
+    r1, r2 = str(tmp_path / "a_R1.fq"), str(tmp_path / "a_R2.fq")
+    _split_pairs(fq, r1, r2, mutate)
+    L.pg_set_ingest_threads(1)
+    os.environ.pop("PG_INGEST_PIECE", None)
+    os.environ["PANGAEA_INGEST_ON_HOST"] = "1"
+    want = ReadStream.from_fastq(r1, r2, device=DEV)                      # (host ingest + one copy)
+    os.environ.pop("PANGAEA_INGEST_ON_HOST")
+    assert want.valid_lowq is not None and want.valid_lower is not None and want.n_unpaired > 0
+    want_host = ReadStream.from_fastq(r1, r2)
+    for threads, piece in ((1, None), (4, "30000"), (8, "1000")):
+        L.pg_set_ingest_threads(threads)
+        if piece:
+            os.environ["PG_INGEST_PIECE"] = piece
+        else:
+            os.environ.pop("PG_INGEST_PIECE", None)
+        _same(ReadStream.from_fastq(r1, r2, device=DEV), want_host)
+    assert took[-3:] == [True, True, True]
+    # an R2 that ends early: what the threads cannot pair is the serial tail's
+    short2 = str(tmp_path / "short_R2.fq")
+    lines = open(r2).read().splitlines(keepends=True)
+    open(short2, "w").writelines(lines[:len(lines) // 2 // 4 * 4 - 2])
+    L.pg_set_ingest_threads(4)
+    os.environ["PG_INGEST_PIECE"] = "50000"
+    _same(ReadStream.from_fastq(r1, short2, device=DEV), ReadStream.from_fastq(r1, short2))
+    # gzip pairs: inflated side by side into in-memory files, then the same ingest
+    import gzip as gz
+    g1, g2 = str(tmp_path / "a_R1.fq.gz"), str(tmp_path / "a_R2.fq.gz")
+    for src, dst in ((r1, g1), (r2, g2)):
+        with gz.open(dst, "wb") as f:
+            f.write(open(src, "rb").read())
+    _same(ReadStream.from_fastq(g1, g2, device=DEV), want_host)
+    _same(ReadStream.from_fastq(g1, r2, device=DEV), want_host)
+    assert took[-3:] == [True, True, True]
+    os.environ.pop("PG_INGEST_PIECE", None)
+    assert not [f for f in os.listdir("/proc/self/fd") if os.path.realpath(f"/proc/self/fd/{f}").startswith("/memfd:pg_inflate")]
+    # staging arrays that are too small are refused
+    n1, n2 = os.path.getsize(r1), os.path.getsize(r2)
+    cap = int(L.pg_ingest_pair_staging_words(n1, n2))
+    sc = torch.empty(cap, dtype=torch.int64, device=DEV); sv = torch.empty(cap, dtype=torch.int32, device=DEV); sq = torch.empty(cap, dtype=torch.int32, device=DEV)
+    h = C.c_void_p()
+    rc = L.pg_ingest_fastq_pair_device(r1.encode(), r2.encode(), n1, n2, C.c_void_p(sc.data_ptr()), C.c_void_p(sv.data_ptr()), C.c_void_p(sq.data_ptr()), cap - 1, C.byref(h))
+    assert rc != 0 and not h

@@ -44,5 +44,22 @@ for piece in (None, 4 << 20, 8 << 20, 32 << 20, 64 << 20):
     if piece:
         os.environ["PG_INGEST_PIECE"] = str(piece)
     timed(f"device ingest, pieces of {(piece or 16 << 20) >> 20} MiB", lambda: ReadStream.from_fastq(fq, device=dev))
+os.environ.pop("PG_INGEST_PIECE", None)
+# the same reads as -1 / -2 files (pg_ingest_fastq_pair_device: pieces of R1, three planes)
+r1, r2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+with open(fq, "rb") as f, open(r1, "wb") as a, open(r2, "wb") as b:
+    while True:
+        chunk = [f.readline() for _ in range(8)]
+        if not chunk[7]:
+            break
+        a.writelines(chunk[:4]); b.writelines(chunk[4:])
 os.remove(fq)
+os.environ["PANGAEA_INGEST_ON_HOST"] = "1"
+timed("-1/-2: host ingest + copy", lambda: ReadStream.from_fastq(r1, r2, device=dev))
+os.environ.pop("PANGAEA_INGEST_ON_HOST")
+for piece in (None, 4 << 20, 32 << 20):
+    if piece:
+        os.environ["PG_INGEST_PIECE"] = str(piece)
+    timed(f"-1/-2: device ingest, pieces of {(piece or 16 << 20) >> 20} MiB", lambda: ReadStream.from_fastq(r1, r2, device=dev))
+os.remove(r1); os.remove(r2)
 os.rmdir(tmp)
