@@ -2455,7 +2455,9 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
     const bool merge_a2 = window > 0 && merge_ws && merge_ws_words > 0 && mini_merge_form(t, rows, vsize);
     if (word_end > word_begin) {
         if (p.bits2) {
-            const int tiles_x = 96;
+            // about one workgroup per tile of a region (from the record capacity: the count itself is on the device): with the regions'
+            // workgroups on one XCD each, 96 workgroups per region walking a dozen tiles each took 3.32 ms where 576 to 1152 take 3.05
+            const int tiles_x = (int)std::min<size_t>(2048, std::max<size_t>(8, cap / ((size_t)S2_TILE << p.bits1) + 1));
             hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
                                (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l,
                                merge_a2 ? (unsigned long long *)nullptr : kwords,
