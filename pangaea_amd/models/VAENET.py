@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 from torch.nn import functional as F
 
+from ..runtime import join_warm_blas
 from ..utils import EarlyStopping
 
 
@@ -123,6 +124,7 @@ class VAENET:
         return self.cuda and os.environ.get("PG_TRAIN_GRAPH", "1") != "0"
 
     def _capture_train_step(self, opt, abd, tnf, side):
+        join_warm_blas()                                # (runtime.warm_blas: its helper thread must not launch during a capture)
         static_abd, static_tnf = abd.clone(), tnf.clone()
         self.network.train()
         opt.zero_grad(set_to_none=True)
@@ -143,6 +145,7 @@ class VAENET:
         return step
 
     def _capture_val_step(self, abd, tnf):
+        join_warm_blas()
         static_abd, static_tnf = abd.clone(), tnf.clone()
         self.network.eval()
         graph = torch.cuda.CUDAGraph()

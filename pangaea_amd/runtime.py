@@ -87,6 +87,16 @@ def init_all(seed, threads, logfile, level, outdir, file_log: bool = True) -> No
     log.info("pangaea (MI355X feature path) starting, output in %s", outdir)
 
 
+_warm_threads: list = []
+
+
+def join_warm_blas() -> None:
+    """wait for every ``warm_blas`` thread started so far (before a HIP-graph capture: a capture does not tolerate another
+    thread of the process putting work on a stream meanwhile)"""
+    while _warm_threads:
+        _warm_threads.pop().join()
+
+
 def warm_blas(device, widths=(536, 512, 512, 32), rows: int = 4096):
     """Start the GEMM library's one-time initialisation for ``device`` on a helper thread and return the thread (or None without
     a GPU).  The first matrix product of a process loads hipBLASLt/rocBLAS and their kernel tables: 190 ms on an MI355X box
@@ -113,4 +123,5 @@ def warm_blas(device, widths=(536, 512, 512, 32), rows: int = 4096):
     # glibc aborts on the mutex it holds; the interpreter waits for the thread instead)
     t = threading.Thread(target=work, name="pangaea-warm-blas", daemon=False)
     t.start()
+    _warm_threads.append(t)
     return t
