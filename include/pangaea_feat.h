@@ -222,7 +222,7 @@ enum { PG_TABLE_DENSE = 1, PG_TABLE_HASH = 2, PG_TABLE_WIDE = 3, PG_TABLE_MINI =
 #define PG_MINI_M_SMALL 11    /* ... and for PG_MINI_MIN_K <= k <= 15 */
 #define PG_MINI_MIN_K 13
 #define PG_MINI_MAX_LOG2_BUCKETS 16
-#define PG_MINI_MAX_ROWS ((1 << 21) - 2)
+#define PG_MINI_MAX_ROWS ((1 << 20) - 2)
 #define PG_MINI_WIDE_MAX_LOG2_BUCKET_SLOTS 13
 #define PG_DENSE_MAX_K 16
 #define PG_HASH_MAX_K 21

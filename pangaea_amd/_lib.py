@@ -33,7 +33,7 @@ TNF_MAX_K = 6
 WORD_ALIGN = 256
 BUCKET_MAX_LOG2_SLOTS, BUCKET_MAX_LOG2_BUCKETS = 14, 17
 ABI_VERSION = 9
-MINI_MIN_K, MINI_MAX_LOG2_BUCKETS, MINI_MAX_ROWS, MINI_WIDE_MAX_LOG2_BUCKET_SLOTS = 13, 16, (1 << 21) - 2, 13
+MINI_MIN_K, MINI_MAX_LOG2_BUCKETS, MINI_MAX_ROWS, MINI_WIDE_MAX_LOG2_BUCKET_SLOTS = 13, 16, (1 << 20) - 2, 13
 SHUFFLE_MAX_VSIZE = 512
 DEFERRED_MAX_GROUP_LOG2 = 3
 KEY42_M1 = 0x3d7ed558ccd          # pg_key42 (include/pangaea_feat.h)

@@ -34,11 +34,11 @@ constexpr int ROUND_WORDS = S1_BLOCK;                  // words per round of the
 constexpr int MINI_CHUNK_WORDS = 4096;                 // words per chunk (one workgroup of the first pass)
 constexpr int ROUNDS_PER_CHUNK = MINI_CHUNK_WORDS / ROUND_WORDS;
 constexpr int STAGE_CAP = 8 * S1_BLOCK;                // records of a (sub-)round staged in LDS: 8 positions x 512 lanes always fit
-constexpr int META_D2_BITS = 7, META_LEN_BITS = 4, META_ROW_SHIFT = META_D2_BITS + META_LEN_BITS;
+constexpr int META_D2_BITS = 8, META_LEN_BITS = 4, META_ROW_SHIFT = META_D2_BITS + META_LEN_BITS;
 constexpr uint32_t MINI_ROW_NONE = (1u << (32 - META_ROW_SHIFT)) - 1u;
 constexpr int MINI_MAX_LEN = 1 << META_LEN_BITS;       // k-mers per record
-constexpr int MINI_BITS1 = 8;                          // first-pass digits (regions): 8, or 9 for a table of 2^16 buckets
-constexpr int MINI_MAX_BITS1 = 9;
+constexpr int MINI_BITS1 = 8;                          // first-pass digits (regions); a table of 2^16 buckets: 2^8 regions x 2^8 buckets each
+constexpr int MINI_MAX_BITS1 = 8;
 #ifndef PG_SHORT_MAX
 #define PG_SHORT_MAX 4
 #endif
@@ -400,7 +400,7 @@ template <int N1> struct Scatter1Lds {                              // N1 region
     uint32_t wave_tot[N1 / 64];
 };
 
-static_assert(2 * sizeof(Scatter1Lds<256>) <= 160 * 1024 && 2 * sizeof(Scatter1Lds<512>) <= 160 * 1024, "two first-pass workgroups share a CU's LDS");
+static_assert(2 * sizeof(Scatter1Lds<256>) <= 160 * 1024, "two first-pass workgroups share a CU's LDS");
 
 template <int W, bool DELAY, int M, int N1>
 __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
@@ -567,14 +567,17 @@ __global__ __launch_bounds__(S1_BLOCK, 4) void mini_scatter_kernel(const uint64_
 // saves them the steps that short records would leave idle.  cursor[b] is the number of short records afterwards.
 constexpr int S2_RPL = 16;
 constexpr int S2_TILE = BLOCK * S2_RPL;
-struct Scatter2Lds {
+// DIG digits: 2 classes x 128 buckets of a region (tables of up to 2^15 buckets), or x 256 (2^16 buckets: the geometry of several
+// ranks -- until round 4 those tables had 512 first-pass regions instead, whose runs of six records per round cost that pass 1.6 ms)
+template <int DIG> struct Scatter2Lds {
     uint64_t bases[S2_TILE];
     uint32_t meta[S2_TILE];
-    uint32_t cnt[256];
-    uint32_t start[257];
-    unsigned long long gbase[256];
+    uint32_t cnt[DIG];
+    uint32_t start[DIG + 1];
+    unsigned long long gbase[DIG];
     uint32_t wave_tot[WAVES];
 };
+template <int DIG>
 __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__restrict__ in_bases, const uint32_t *__restrict__ in_meta,
                                                               const unsigned long long *__restrict__ off, int bits2, int tiles_x, int short_max,
                                                               uint64_t *__restrict__ out_bases, uint32_t *__restrict__ out_meta,
@@ -586,7 +589,9 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
     // kwords[b] += the k-mers of bucket b that lie inside a row (= the words its workgroup will emit): they ride in the high
     // half of the tile's rank counters -- a tile has 4096 records of at most 9 k-mers, both halves stay below 2^16
     static_assert(S2_TILE * MINI_MAX_WINDOW < 65536, "two 16-bit halves per rank counter");
-    __shared__ Scatter2Lds L;
+    __shared__ Scatter2Lds<DIG> L;
+    constexpr int DPT = DIG / BLOCK;                            // digits per lane: threadIdx.x * DPT + q
+    constexpr uint32_t CLS = DIG / 2;                           // the class bit of a digit
     const int n_dig = 1 << bits2;
     const uint32_t dmask = (uint32_t)n_dig - 1u;
     // Workgroups go to the eight XCDs round-robin by their index, and each XCD has its own L2.  All workgroups of a region are put
@@ -600,10 +605,11 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
     const int64_t n_tiles = (r1 - r0 + S2_TILE - 1) / S2_TILE;
     auto digit_of = [&](uint32_t m) -> uint32_t {
         const int n = (int)((m >> META_D2_BITS) & (MINI_MAX_LEN - 1)) + 1;
-        return (m & dmask) | (n > short_max ? 128u : 0u);
+        return (m & dmask) | (n > short_max ? CLS : 0u);
     };
     for (int64_t tile = by_xcd ? (blockIdx.x / 8u) % (unsigned)tiles_x : blockIdx.x % tiles_x; tile < n_tiles; tile += tiles_x) {
-        L.cnt[threadIdx.x] = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) L.cnt[threadIdx.x * DPT + q] = 0;
         lds_sync();
         const int64_t t0 = r0 + tile * S2_TILE;
         uint64_t rb[S2_RPL];
@@ -625,19 +631,23 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
             }
         }
         lds_sync();
-        const uint32_t kw_mine = L.cnt[threadIdx.x] >> 16;          // (this lane's digit; scan_digits reads the same entry next)
-        L.cnt[threadIdx.x] &= 0xffffu;
-        scan_digits<256, true>(L.cnt, L.start, L.wave_tot);
+        uint32_t kw_mine[DPT];                                      // (this lane's digits; the scan reads the same entries next)
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) { kw_mine[q] = L.cnt[threadIdx.x * DPT + q] >> 16; L.cnt[threadIdx.x * DPT + q] &= 0xffffu; }
+        if constexpr (DPT == 1) scan_digits<DIG, true>(L.cnt, L.start, L.wave_tot);
+        else { lds_sync(); scan_digits_blk<DIG, BLOCK, true>(L.cnt, L.start, L.wave_tot); }
         // the returning cursor adds (one per digit and tile) are issued first and consumed after the placement
-        unsigned long long gpos = 0;
-        {
-            const uint32_t d = threadIdx.x;
+        unsigned long long gpos[DPT];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const uint32_t d = threadIdx.x * DPT + q;
             const uint32_t c = L.start[d + 1] - L.start[d];
-            if (kw_mine) atomicAdd(&kwords[b0 + (d & 127u)], (unsigned long long)kw_mine);
+            gpos[q] = 0;
+            if (kw_mine[q]) atomicAdd(&kwords[b0 + (d & (CLS - 1u))], (unsigned long long)kw_mine[q]);
             if (c) {
-                const int64_t b = b0 + (d & 127u);
-                gpos = d < 128 ? off[b] + atomicAdd(&cursor[b], (unsigned long long)c) - L.start[d]
-                               : off[b + 1] - (atomicAdd(&cursor_l[b], (unsigned long long)c) + c) - L.start[d];
+                const int64_t b = b0 + (d & (CLS - 1u));
+                gpos[q] = d < CLS ? off[b] + atomicAdd(&cursor[b], (unsigned long long)c) - L.start[d]
+                                  : off[b + 1] - (atomicAdd(&cursor_l[b], (unsigned long long)c) + c) - L.start[d];
             }
         }
 #pragma unroll
@@ -649,9 +659,10 @@ __global__ __launch_bounds__(BLOCK) void mini_scatter2_kernel(const uint64_t *__
                 L.meta[at] = rm[j];
             }
         }
-        L.gbase[threadIdx.x] = gpos;
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) L.gbase[threadIdx.x * DPT + q] = gpos[q];
         lds_sync();
-        const uint32_t total = L.start[256];
+        const uint32_t total = L.start[DIG];
         for (uint32_t i = threadIdx.x; i < total; i += BLOCK) {     // flat sweep: the digit is in the record
             const uint32_t m = L.meta[i];
             const unsigned long long g = L.gbase[digit_of(m)] + i;
@@ -2127,7 +2138,7 @@ int plan_mini(const pg_table *t, int64_t n_words, MiniPlan *p)
 {
     p->bits = t->log2_slots - t->log2_bucket_slots;
     p->bits1 = p->bits < MINI_BITS1 ? p->bits : MINI_BITS1;
-    if (p->bits - p->bits1 > META_D2_BITS) p->bits1 = p->bits - META_D2_BITS;       // 2^16 buckets: 512 regions
+    if (p->bits - p->bits1 > META_D2_BITS) p->bits1 = p->bits - META_D2_BITS;       // (cannot happen: at most 2^16 buckets)
     p->bits2 = p->bits - p->bits1;
     p->n_rounds = (n_words + ROUND_WORDS - 1) / ROUND_WORDS;
     p->n_chunks = (n_words + MINI_CHUNK_WORDS - 1) / MINI_CHUNK_WORDS;
@@ -2434,7 +2445,7 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
                                with_rows ? rows->n_rows : (int64_t)0, with_rows ? rows->strict_valid : (const uint32_t *)nullptr, \
                                (const int32_t *)round_row, bases_a, meta_a, (const unsigned long long *)chunk_tab, p.n_chunks, p.chunk_stride, \
                                (const unsigned long long *)header, (const unsigned long long *)region_off, (unsigned long long)cap, status))
-        if (p.bits1 > MINI_BITS1) { PG_MINI_LAUNCH_SCATTER(512) } else { PG_MINI_LAUNCH_SCATTER(256) }
+        PG_MINI_LAUNCH_SCATTER(256)
 #undef PG_MINI_LAUNCH_SCATTER
     }
     // (for pg_mini_wait_first_pass: what is enqueued on another stream behind this event runs beside the second pass and the count)
@@ -2458,10 +2469,16 @@ static int mini_count_impl(const uint64_t *codes, const uint32_t *valid, int64_t
             // about one workgroup per tile of a region (from the record capacity: the count itself is on the device): with the regions'
             // workgroups on one XCD each, 96 workgroups per region walking a dozen tiles each took 3.32 ms where 576 to 1152 take 3.05
             const int tiles_x = (int)std::min<size_t>(2048, std::max<size_t>(8, cap / ((size_t)S2_TILE << p.bits1) + 1));
-            hipLaunchKernelGGL(mini_scatter2_kernel, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
-                               (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l,
-                               merge_a2 ? (unsigned long long *)nullptr : kwords,
-                               (const unsigned long long *)header, (unsigned long long)cap, status);
+            if (p.bits2 > 7)
+                hipLaunchKernelGGL(mini_scatter2_kernel<512>, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
+                                   (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l,
+                                   merge_a2 ? (unsigned long long *)nullptr : kwords,
+                                   (const unsigned long long *)header, (unsigned long long)cap, status);
+            else
+                hipLaunchKernelGGL(mini_scatter2_kernel<256>, dim3((unsigned)(tiles_x << p.bits1)), dim3(BLOCK), 0, s, (const uint64_t *)bases_a, (const uint32_t *)meta_a,
+                                   (const unsigned long long *)off, p.bits2, tiles_x, mini_cap(t->k) > SHORT_MAX ? SHORT_MAX : 0, bases_b, meta_b, cur2, cur2l,
+                                   merge_a2 ? (unsigned long long *)nullptr : kwords,
+                                   (const unsigned long long *)header, (unsigned long long)cap, status);
         }
     }
     const bool slots_form = window > 0 && mini_slots_form(t, rows);
