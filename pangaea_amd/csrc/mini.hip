@@ -2785,7 +2785,18 @@ extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, c
             hipLaunchKernelGGL((mini_lookup_half_merge_kernel<CAP_, BIG_BLOCK, DIG_>), dim3(nb), dim3(BIG_BLOCK), lds_, s2, off, n_short, wbeg, ring, occ, \
                                bins_in, (const long long *)bin_elem, local->log2_bucket_slots, ctx.vbits, (const uint32_t *)merge_ws, meta_b, sh, status); \
         } while (0)
-#define PG_LOOKUP_HALF_MC(CAP_) do { if (ctx.gb1 > 10) PG_LOOKUP_HALF_M(CAP_, 2048); else PG_LOOKUP_HALF_M(CAP_, 1024); } while (0)
+        // buckets of at most 2^13 slots (what a rank's own reads need at 4+ ranks): 512-thread workgroups, two per CU -- this kernel
+        // starts cold (bins, meta words and provisional slots all come from HBM, where the one-GPU kernel's lookup phase finds
+        // them in L2), and a second workgroup on the CU hides what one alone waits for: 7.8 -> 5.9 ms, rehearsed 8-rank step
+        // 34.3 -> 32.3 ms on one box (PG_LOOKUP_HALF_1024=1: the one-workgroup form)
+#define PG_LOOKUP_HALF_M5(CAP_)                                                                                             \
+        do {                                                                                                                \
+            const size_t lds_ = MergeLds<512, 1024>::END;                                                                   \
+            if ((rc = raise_lds_limit((const void *)(mini_lookup_half_merge_kernel<CAP_, 512, 1024>), lds_, "pg_mini_lookup_half"))) return rc; \
+            hipLaunchKernelGGL((mini_lookup_half_merge_kernel<CAP_, 512, 1024>), dim3(nb), dim3(512), lds_, s2, off, n_short, wbeg, ring, occ, \
+                               bins_in, (const long long *)bin_elem, local->log2_bucket_slots, ctx.vbits, (const uint32_t *)merge_ws, meta_b, sh, status); \
+        } while (0)
+#define PG_LOOKUP_HALF_MC(CAP_) do { if (ctx.gb1 > 10) PG_LOOKUP_HALF_M(CAP_, 2048); else if (local->log2_bucket_slots <= 13 && !getenv("PG_LOOKUP_HALF_1024")) PG_LOOKUP_HALF_M5(CAP_); else PG_LOOKUP_HALF_M(CAP_, 1024); } while (0)
         switch (cap_k) {
         case 1: case 2: case 3: case 4: PG_LOOKUP_HALF_MC(4); break;
         case 5: case 6: PG_LOOKUP_HALF_MC(6); break;
@@ -2793,6 +2804,7 @@ extern "C" int pg_mini_lookup_half(const pg_table *local, const pg_rows *rows, c
         default: PG_LOOKUP_HALF_MC(9); break;
         }
 #undef PG_LOOKUP_HALF_MC
+#undef PG_LOOKUP_HALF_M5
 #undef PG_LOOKUP_HALF_M
         return check_launch("pg_mini_lookup_half");
     }
