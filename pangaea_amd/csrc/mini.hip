@@ -1906,58 +1906,86 @@ __global__ __launch_bounds__(BIG_BLOCK) void mini_merge_bins_kernel(const unsign
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) tab[i] = 0ull;
     __syncthreads();
     bool full = false;
+    // Insert: four entries of the lane in flight (their loads, then their first probes, issued together); the slot an entry ends up
+    // in is left where its bin will go -- the second sweep then needs neither the entry nor its hash nor a probe, only the slot's
+    // final count (until round 4 it read the 8-byte entries again and probed again: 3.16 ms for the 8-rank geometry)
+    constexpr int U = 4;
+    const uint64_t out_cap = (uint64_t)n_parts * (uint64_t)part_stride;
     for (int p = 0; p < n_parts; ++p) {
         const long long a = seg[(long long)p * (n_owned + 1) + blockIdx.x], b = seg[(long long)p * (n_owned + 1) + blockIdx.x + 1];
-        for (long long e = a + threadIdx.x; e < b; e += BIG_BLOCK) {
-            const unsigned long long x = recv[(long long)p * part_stride + e];
-            const uint64_t code = x >> HASH_CBITS;
-            const uint32_t c = (uint32_t)(x & HASH_CMASK);
-            uint32_t s = mini_slot_hash<false>(code) & smask;
-            bool done = false;
-            for (uint32_t i = 0; i < limit && !done; ++i) {
-                unsigned long long cur = tab[s];
-                if (cur == 0ull) {
-                    cur = atomicCAS(&tab[s], 0ull, x);
-                    if (cur == 0ull) { done = true; break; }
-                }
-                if ((cur >> HASH_CBITS) == code) {               // add, saturating: parts of up to SAT each must not carry into the code
-                    for (;;) {
-                        const uint32_t sum = (uint32_t)(cur & HASH_CMASK) + c;
-                        const unsigned long long nv = (cur & ~(unsigned long long)HASH_CMASK) | (sum > HASH_SAT ? HASH_SAT : sum);
-                        const unsigned long long old = atomicCAS(&tab[s], cur, nv);
-                        if (old == cur) break;
-                        cur = old;
-                    }
-                    done = true;
-                    break;
-                }
-                s = (s + 1) & smask;
+        for (long long e0 = a + threadIdx.x; e0 < b; e0 += (long long)U * BIG_BLOCK) {
+            unsigned long long x[U], cur[U];
+            uint32_t s[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long e = e0 + (long long)u * BIG_BLOCK;
+                x[u] = e < b ? recv[(long long)p * part_stride + e] : 0ull;
             }
-            full |= !done;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                s[u] = mini_slot_hash<false>(x[u] >> HASH_CBITS) & smask;
+                cur[u] = tab[s[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long e = e0 + (long long)u * BIG_BLOCK;
+                if (e >= b) continue;
+                const uint64_t code = x[u] >> HASH_CBITS;
+                const uint32_t c = (uint32_t)(x[u] & HASH_CMASK);
+                uint32_t at = s[u];
+                unsigned long long cv = cur[u];
+                bool done = false;
+                for (uint32_t i = 0; i < limit && !done; ++i) {
+                    if (i) cv = tab[at];
+                    if (cv == 0ull) {
+                        cv = atomicCAS(&tab[at], 0ull, x[u]);
+                        if (cv == 0ull) { done = true; break; }
+                    }
+                    if ((cv >> HASH_CBITS) == code) {            // add, saturating: parts of up to SAT each must not carry into the code
+                        for (;;) {
+                            const uint32_t sum = (uint32_t)(cv & HASH_CMASK) + c;
+                            const unsigned long long nv = (cv & ~(unsigned long long)HASH_CMASK) | (sum > HASH_SAT ? HASH_SAT : sum);
+                            const unsigned long long old = atomicCAS(&tab[at], cv, nv);
+                            if (old == cv) break;
+                            cv = old;
+                        }
+                        done = true;
+                        break;
+                    }
+                    at = (at + 1) & smask;
+                }
+                full |= !done;
+                // (a k-mer that found no place -- the table is full and reported so -- has no slot and no bin)
+                gstore(bins_out, (uint64_t)((long long)p * part_stride + e), out_cap, (uint16_t)(done ? at : 0xffffu), status);
+            }
         }
     }
     if (full) atomicOr(status, PG_STATUS_TABLE_FULL);
     __syncthreads();
     const uint64_t slice0 = (uint64_t)(bucket0 + blockIdx.x) << t.log2_bucket;
     for (uint32_t i = threadIdx.x; i < n_slots; i += BIG_BLOCK) gstore(t.slots, slice0 + i, 1ull << t.log2_slots, tab[i], status);
+    // slots -> bins (every lane reads back what it wrote itself: the same entries in the same order)
     const float rcp_window = 1.0f / (float)window;
     for (int p = 0; p < n_parts; ++p) {
         const long long a = seg[(long long)p * (n_owned + 1) + blockIdx.x], b = seg[(long long)p * (n_owned + 1) + blockIdx.x + 1];
-        for (long long e = a + threadIdx.x; e < b; e += BIG_BLOCK) {
-            const uint64_t code = recv[(long long)p * part_stride + e] >> HASH_CBITS;
-            uint32_t s = mini_slot_hash<false>(code) & smask;
-            uint32_t out = 0xffffu;                              // (a k-mer that found no place -- the table is full and reported so -- has no bin)
-            for (uint32_t i = 0; i < limit; ++i) {
-                const unsigned long long cur = tab[s];
-                if (cur == 0ull) break;
-                if ((cur >> HASH_CBITS) == code) {
-                    const uint32_t bin = div_uniform((uint32_t)(cur & HASH_CMASK), window, rcp_window);
-                    out = bin < vsize ? bin + 1u : 0xffffu;
-                    break;
-                }
-                s = (s + 1) & smask;
+        for (long long e0 = a + threadIdx.x; e0 < b; e0 += (long long)U * BIG_BLOCK) {
+            uint32_t sl[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long e = e0 + (long long)u * BIG_BLOCK;
+                sl[u] = e < b ? (uint32_t)bins_out[(long long)p * part_stride + e] : 0xffffu;
             }
-            gstore(bins_out, (uint64_t)((long long)p * part_stride + e), (uint64_t)n_parts * (uint64_t)part_stride, (uint16_t)out, status);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long e = e0 + (long long)u * BIG_BLOCK;
+                if (e >= b) continue;
+                uint32_t out = 0xffffu;
+                if (sl[u] != 0xffffu) {
+                    const uint32_t bin = div_uniform((uint32_t)(tab[sl[u] & smask] & HASH_CMASK), window, rcp_window);
+                    out = bin < vsize ? bin + 1u : 0xffffu;
+                }
+                gstore(bins_out, (uint64_t)((long long)p * part_stride + e), out_cap, (uint16_t)out, status);
+            }
         }
     }
 }
