@@ -383,7 +383,7 @@ __device__ __forceinline__ void scan_digits_blk(const uint32_t *cnt, uint32_t *s
 // occupancy (the first pass: 6.9 -> see DESIGN.md), and the stage shrinks from 13 to 4 bytes per record.
 constexpr int REF_E_SHIFT = 16, REF_LANE_SHIFT = 21;               // ref = lane << 21 | e << 16 | bucket
 static_assert(PG_MINI_MAX_LOG2_BUCKETS <= REF_E_SHIFT && S1_BLOCK <= (1 << (32 - REF_LANE_SHIFT)), "fields of a stage reference");
-template <int N1> struct Scatter1Lds {                              // N1 regions: 256, or 512 for a table of 2^16 buckets
+template <int N1> struct Scatter1Lds {                              // N1 regions: 256 (until round 4 also 512, for tables of 2^16 buckets: see Scatter2Lds)
     uint32_t ref[STAGE_CAP];
     uint16_t col[32 * S1_BLOCK];                                    // the bucket of every position of the lanes' words (a column per lane)
     uint64_t cw[S1_BLOCK], pw[S1_BLOCK];                            // the lanes' words and the words before them
