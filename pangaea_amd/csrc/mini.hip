@@ -7,7 +7,7 @@
 // passes and two LDS-table passes (20.8 GB per trip at 10 M read pairs).  Here a k-mer's bucket is a hash of its MINIMIZER
 // (pg_device.hpp), consecutive k-mers of a read share it, and what travels is the SUPER-k-mer: one 12-byte record
 //     bases : uint64  the 32 characters ending at the record's last character, stream order (oldest in the low bits)
-//     meta  : uint32  row << 11 | (n - 1) << 7 | d2      row = index of the row the k-mers lie in (MINI_ROW_NONE: none),
+//     meta  : uint32  row << 12 | (n - 1) << 8 | d2      row = index of the row the k-mers lie in (MINI_ROW_NONE: none),
 //                                                        n = k-mers in the record (they end at the last n characters),
 //                                                        d2 = the bucket's second-pass digit
 // for a run of n <= 16 k-mers (about 4.3 on 150 bp reads, k = 21), i.e. under 3 bytes per occurrence.  The bucket

@@ -365,7 +365,7 @@ class KmerTable:
         n_words = word_end - word_begin
         keep = rows if (rows is not None and rows.shuffle_ok and rows.n_rows <= _lib.MINI_MAX_ROWS) else None
         if rows is not None and keep is None:
-            raise ValueError("mini tables need sorted, disjoint, non-empty rows (at most 2^21 - 2 of them)")
+            raise ValueError("mini tables need sorted, disjoint, non-empty rows (at most 2^20 - 2 of them)")
         fuse = (emit is not None and keep is not None and n_words > 0 and 1 <= emit[1] <= _lib.SHUFFLE_MAX_VSIZE and emit[0] >= 1
                 and (self.kind == "miniw" or emit[0] * emit[1] <= _lib.HASH_COUNT_SAT))
         # a stream whose scratch would not fit in one piece (about 3.4 KB per 150 bp read pair; PANGAEA_MINI_PIECE_WORDS forces a
