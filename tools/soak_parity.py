@@ -25,6 +25,8 @@ while time.time() < t_end:
     log2_slots = int(min(lb + 16, need + rng.randint(0, 2)))
     if log2_slots < need:
         lb = min(14 if k <= 21 else 13, need - 16 if need - 16 > lb else lb); log2_slots = max(need, lb)
+    if rng.rand() < 0.3:                                     # tables of 2^16 buckets (the 512-digit second pass), whatever the data need
+        lb = int(rng.randint(8, 13)); log2_slots = lb + 16
     window, vsize = int(rng.choice([1, 2, 3, 10, 25])), int(rng.choice([6, 50, 64, 400, 512]))
     min_len = int(rng.choice([0, 302, 600, 2000]))
     cfg = synth.SynthConfig(n_pairs=n_pairs, n_barcodes=max(1, n_pairs // int(rng.choice([7, 20, 200]))), n_genomes=3, genome_len=int(rng.choice([20_000, 300_000])),
